@@ -1,0 +1,741 @@
+"""
+oracle/pac_oracle.py -- CPU restatement of the reference's per-frame encode hot path.
+
+*** TEST INFRASTRUCTURE, NOT PRODUCT CODE. ***
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (audio-codec_amd/) never does: its arithmetic
+runs in the HIP library behind include/pacx.h and it raises when that library is
+missing.
+
+What this file is: a NumPy (float64) restatement of the algorithm the reference
+implements in coder/{window,mdct,psychoac,bitalloc,quantize,codec}.py plus the
+parts of coder/{pcmfile,pacfile,bitpack,detect_transients}.py that sit either
+side of the path (input contract, .pac bit layout, driver loop).  Every function
+names the reference file:line it follows (paths relative to /root/reference).
+
+Parity pin: tests/golden/*.npz were produced by importing the reference itself
+in the build container (tests/golden/make_golden.py, committed) and
+tests/test_oracle_golden.py checks this restatement against them bit for bit;
+the reference in turn reproduces its own committed
+test_decoded_full/harpsichord_coded_128.pac byte for byte.
+
+Third-party arithmetic the reference leans on (NumPy pocketfft, ufuncs,
+pairwise np.sum) is reached here through the same NumPy calls, so this file is
+bit-identical to the reference under one NumPy build.  No version is pinned by
+the reference (it has no requirements file).
+"""
+import struct
+
+import numpy as np
+
+EPS = np.finfo(float).eps
+DB_PER_BIT = 6.2          # coder/bitalloc.py:61
+SHORT_WINDOW = 256        # coder/codec.py:27
+SHORT_LINES = 128         # coder/pacfile.py:490
+TONAL_DROP = 16           # coder/psychoac.py:65-66
+
+# 25 Zwicker critical-band upper edges in Hz, coder/psychoac.py:100-103
+CRITICAL_BAND_EDGES = np.array([
+    100, 200, 300, 400, 510, 630, 770, 920, 1080, 1270, 1480, 1720, 2000, 2320,
+    2700, 3150, 3700, 4400, 5300, 6400, 7700, 9500, 12000, 15500, 24000
+])
+
+
+# --------------------------------------------------------------------------- A0
+def pcm16_to_fraction(codes):
+    """int16 PCM codes -> signed fractions.
+
+    Follows coder/pcmfile.py:89-99 + coder/quantize.py:82-95: magnitude is
+    taken, the low 15 bits are the code, bit 15 of the magnitude (only set for
+    -32768) gives an inner sign that multiplies an integer zero, then the outer
+    sign is re-applied in floating point.  Net effect: +-2|c|/65535, and
+    -32768 -> -0.0.
+    """
+    c = np.asarray(codes).astype(np.int64)
+    neg = np.signbit(c)
+    mag = c.copy()
+    mag[neg] *= -1
+    inner = np.ones_like(mag)
+    inner[(mag & (1 << 15)) != 0] = -1
+    val = inner * 2 * (mag & 32767) / 65535
+    val[neg] *= -1.0
+    return val
+
+
+# ----------------------------------------------------------------------- A1..A3
+def sine_window(n):
+    """coder/window.py:22-24."""
+    k = np.arange(n)
+    return np.sin(np.pi * (k + 0.5) / n)
+
+
+def hann_window(n):
+    """coder/window.py:37-39 (the n+1/2 Hann used on the side chain data)."""
+    k = np.arange(n)
+    return 0.5 * (1 - np.cos(2 * np.pi * (k + 0.5) / n))
+
+
+def start_window(n_long, n_short):
+    """coder/window.py:61-71.  The reference builds the pieces by windowing
+    vectors of ones, i.e. window*1.0, which is the window itself."""
+    pad = n_long // 4 - n_short // 4
+    long_w = sine_window(n_long) * np.ones(n_long)
+    short_w = sine_window(n_short) * np.ones(n_short)
+    return np.concatenate((long_w[:n_long // 2], np.ones(pad),
+                           short_w[n_short // 2:], np.zeros(pad)))
+
+
+def stop_window(n_long, n_short):
+    """coder/window.py:73-80: the start window applied to ones, flipped."""
+    return np.flip(start_window(n_long, n_short) * np.ones(n_long))
+
+
+def start_stop_window(n_long, n_short):
+    """coder/window.py:82-92."""
+    pad = n_long // 4 - n_short // 4
+    short_w = sine_window(n_short) * np.ones(n_short)
+    return np.concatenate((np.zeros(pad), short_w[:n_short // 2],
+                           np.ones(2 * pad), short_w[n_short // 2:],
+                           np.zeros(pad)))
+
+
+WINDOW_SINE, WINDOW_START, WINDOW_STOP, WINDOW_STARTSTOP = 0, 1, 2, 3
+
+
+def window_kind(last_trans, cur_trans, next_trans):
+    """coder/codec.py:30-44: cur -> sine; last&next -> start-stop;
+    last -> stop; next -> start; else sine."""
+    if cur_trans:
+        return WINDOW_SINE
+    if last_trans and next_trans:
+        return WINDOW_STARTSTOP
+    if last_trans:
+        return WINDOW_STOP
+    if next_trans:
+        return WINDOW_START
+    return WINDOW_SINE
+
+
+def window_table(kind, n):
+    """Window of length n for a window kind; transition windows use
+    N_short = 256 as coder/codec.py:36-42 passes SHORT."""
+    if kind == WINDOW_SINE:
+        return sine_window(n)
+    if kind == WINDOW_START:
+        return start_window(n, SHORT_WINDOW)
+    if kind == WINDOW_STOP:
+        return stop_window(n, SHORT_WINDOW)
+    return start_stop_window(n, SHORT_WINDOW)
+
+
+def apply_window(data, last_trans=False, cur_trans=False, next_trans=False):
+    """window * data, as every reference window function returns."""
+    data = np.asarray(data, dtype=np.float64)
+    return window_table(window_kind(last_trans, cur_trans, next_trans),
+                        data.shape[-1]) * data
+
+
+# --------------------------------------------------------------------------- A4
+def mdct_forward(x, a, b):
+    """Forward MDCT of windowed block(s) x[..., a+b] -> [..., (a+b)/2] lines.
+
+    coder/mdct.py:53-55,64-69: n0=(b+1)/2; pre-twiddle exp(-j*2*pi*n/(2N));
+    N-point complex FFT, keep N/2 bins; post-twiddle
+    exp(-j*2*pi*n0*(k+1/2)/N); real part; times 2/N.
+    """
+    n = a + b
+    n0 = (b + 1) / 2
+    pre = x * np.exp(-1j * 2 * np.pi * np.arange(n) / (2 * n))
+    spec = np.fft.fft(pre, n)[..., :n // 2]
+    out = (spec * np.exp(-1j * 2 * np.pi * n0 *
+                         (np.arange(n // 2) + 0.5) / n)).real
+    out *= 2 / n
+    return out
+
+
+def mdct_inverse(lines, a, b):
+    """coder/mdct.py:56-62: inverse, N output samples (gain 2N on the ifft)."""
+    n = a + b
+    n0 = (b + 1) / 2
+    pre = lines * np.exp(1j * 2 * np.pi * np.arange(n // 2) * n0 / n)
+    t = np.fft.ifft(pre, n)
+    out = (t * np.exp(1j * 2 * np.pi * (np.arange(n) + n0) / (2 * n))).real
+    out *= 2 * n
+    return out
+
+
+def mdct_slow(x, a, b):
+    """O(N^2) definition, coder/mdct.py:22-24,32-36 (used to pin mdct_forward
+    the way the reference's own __main__ does, coder/mdct.py:100-104)."""
+    n = a + b
+    n0 = (b + 1) / 2.0
+    out = []
+    for k in range(n // 2):
+        out.append(np.sum(x * np.cos(2 * np.pi / n * (np.arange(n) + n0) *
+                                     (k + 0.5))) * (2 / n))
+    return np.array(out)
+
+
+# ----------------------------------------------------------------------- A5, A12
+def quantize_uniform(x, n_bits):
+    """Scalar midtread quantiser, coder/quantize.py:22-36."""
+    if n_bits <= 0:
+        return 0
+    s = 0 if np.sign(x) >= 0 else 1
+    if abs(x) >= 1:
+        code = 2 ** (n_bits - 1) - 1
+    else:
+        code = int(((2 ** n_bits - 1) * abs(x) + 1) // 2)
+    return int((s << (n_bits - 1)) + code)
+
+
+def dequantize_uniform(code, n_bits):
+    """coder/quantize.py:46-57."""
+    if n_bits <= 0:
+        return 0
+    sign = -1 if code & (1 << (n_bits - 1)) else 1
+    return sign * 2 * (code & (2 ** (n_bits - 1) - 1)) / (2 ** n_bits - 1)
+
+
+def quantize_uniform_vec(x, n_bits):
+    """Vector midtread quantiser, coder/quantize.py:70-78.  Sign bit and
+    magnitude are assembled in floating point, then cast."""
+    x = np.array(x)
+    sign_part = np.zeros_like(x)
+    sign_part[x < 0] = 1 << (n_bits - 1)
+    mag = (((2 ** n_bits - 1) * abs(x) + 1) // 2).astype(int)
+    mag[abs(x) >= 1] = 2 ** (n_bits - 1) - 1
+    return (sign_part + abs(mag)).astype(int)
+
+
+def dequantize_uniform_vec(codes, n_bits):
+    """coder/quantize.py:88-95."""
+    s = np.bitwise_and(codes, (1 << (n_bits - 1)))
+    mag = np.bitwise_and(codes, (2 ** (n_bits - 1) - 1))
+    sign = np.ones_like(codes)
+    sign[s != 0] = -1
+    return sign * 2 * mag / (2 ** n_bits - 1)
+
+
+def scale_factor(x, n_scale_bits=3, n_mant_bits=5):
+    """Leading-zero count of the R-bit magnitude code, R = 2^nScaleBits-1+nMantBits,
+    counted from bit R-2 down and capped at 2^nScaleBits-1.
+    coder/quantize.py:107-125."""
+    r = 2 ** n_scale_bits - 1 + n_mant_bits
+    mag = quantize_uniform(x, r) & (2 ** (r - 1) - 1)
+    zeros = 0
+    probe = 1 << (r - 2)
+    while probe and not (probe & mag):
+        zeros += 1
+        probe >>= 1
+    return int(min(zeros, 2 ** n_scale_bits - 1))
+
+
+def mantissa_vec(x, scale, n_scale_bits=3, n_mant_bits=5):
+    """Block-floating-point mantissas, coder/quantize.py:238-250: quantise to
+    R bits, keep sign, drop `scale` leading zeros and truncate to
+    nMantBits-1 magnitude bits (no shift at the top scale)."""
+    r = 2 ** n_scale_bits - 1 + n_mant_bits
+    codes = quantize_uniform_vec(x, r)
+    sign = np.bitwise_and(codes, (1 << (r - 1)))
+    sign[sign > 0] = 1 << (n_mant_bits - 1)
+    mag = np.bitwise_and(codes, (2 ** (r - 1) - 1))
+    keep = 2 ** (n_mant_bits - 1) - 1
+    if scale == (2 ** n_scale_bits - 1):
+        return sign + (mag & keep)
+    return sign + ((mag >> (r - scale - n_mant_bits)) & keep)
+
+
+def dequantize_vec(scale, mant, n_scale_bits=3, n_mant_bits=5):
+    """coder/quantize.py:260-274."""
+    r = 2 ** n_scale_bits - 1 + n_mant_bits
+    mant = np.asarray(mant)
+    out = np.zeros_like(mant, dtype=int)
+    s = np.bitwise_and(mant, (1 << (n_mant_bits - 1)))
+    s[s > 0] = 1 << (r - 1)
+    mag = np.bitwise_and(mant, (2 ** (n_mant_bits - 1) - 1))
+    out += s
+    out += np.left_shift(mag, max(r - scale - n_mant_bits, 0))
+    if scale < (2 ** n_scale_bits - 1):
+        out[mag > 0] += (1 << (r - scale - n_mant_bits - 1))
+    return dequantize_uniform_vec(out, r)
+
+
+# --------------------------------------------------------------------------- A7
+def band_line_counts(n_lines, sample_rate, edges=CRITICAL_BAND_EDGES):
+    """MDCT lines per critical band, coder/psychoac.py:113-124 (float array)."""
+    width = sample_rate / (2 * n_lines)
+    centers = np.floor((edges / width - 0.5))
+    counts = centers - np.concatenate([[-1], centers[:-1]])
+    for i in range(len(counts)):
+        if edges[i] > sample_rate / 2:
+            counts[i] = n_lines - np.sum(counts[0:i])
+            counts[i + 1:] = 0
+            break
+    return counts
+
+
+class BandTable:
+    """Scale-factor bands: merge every band of <=12 lines into its right
+    neighbour, then derive lower/upper line.  coder/psychoac.py:136-160."""
+
+    def __init__(self, counts):
+        n = np.array(counts, dtype=int)
+        i = 1
+        while i < len(n):
+            if n[i - 1] <= 12:
+                n[i] += n[i - 1]
+                n = np.delete(n, i - 1)
+            else:
+                i += 1
+        self.nLines = n
+        self.nBands = len(n)
+        self.lowerLine = np.zeros((self.nBands,), dtype=int)
+        for i in range(1, self.nBands):
+            self.lowerLine[i] = self.lowerLine[i - 1] + n[i - 1]
+        self.upperLine = (self.lowerLine + n - 1).astype(int)
+
+
+def band_table(n_lines, sample_rate):
+    return BandTable(band_line_counts(n_lines, sample_rate))
+
+
+def omitted_bands(bands, factor=2):
+    """coder/sbr.py:6-9."""
+    cut = bands.upperLine[-1] // factor
+    return np.where(bands.lowerLine >= cut)[0]
+
+
+# ---------------------------------------------------------------------- A8..A10
+def spl_of(intensity):
+    """coder/psychoac.py:10-25.  Scalars: exact 0 -> -30.  Arrays: exact 0 is
+    replaced by 1e-8 IN PLACE.  Then 96+10log10(|I|+eps), floored at -30."""
+    if len(intensity.shape) == 0:
+        if intensity == 0:
+            return -30
+    else:
+        intensity[intensity == 0] = 1e-8
+    spl = 96 + 10 * np.log10(abs(intensity) + EPS)
+    if type(intensity) is np.ndarray:
+        spl[spl < -30] = -30
+    elif spl < -30:
+        spl = -30
+    return spl
+
+
+def intensity_of(spl):
+    """coder/psychoac.py:32."""
+    return 10 ** ((spl - 96) / 10)
+
+
+def thresh_quiet(f):
+    """Threshold in quiet, coder/psychoac.py:37-40 (clips f<10 Hz in place)."""
+    f[f < 10] = 10
+    return 3.64 * (f / 1000) ** (-0.8) - 6.5 * np.exp(
+        -0.6 * (f / 1000 - 3.3) ** 2) + 10 ** (-3) * (f / 1000) ** 4
+
+
+def bark_of(f):
+    """coder/psychoac.py:45-46."""
+    return 13.0 * np.arctan(0.76 * f / 1000.0) + 3.5 * np.arctan(
+        (f / 7500.0) ** 2)
+
+
+def sidechain_intensity(data):
+    """norm*|rfft(hann*data)|^2 with norm = 4/(N^2*mean(np.hanning(N)^2)).
+    coder/psychoac.py:171-175,179 (np.hanning is the symmetric Hann; the data
+    window is the n+1/2 Hann)."""
+    n = data.shape[-1]
+    norm = 4 / (n ** 2 * np.mean(np.hanning(n) ** 2))
+    spec = np.fft.rfft(hann_window(n) * data)
+    return norm * abs(spec) ** 2
+
+
+def find_peaks(inten, freqs):
+    """Strict local maxima of inten[1:], last bin compared to the left only;
+    per peak: SPL of the two-bin energy inten[f-1]+inten[f] and the
+    energy-weighted mean frequency of those two bins.
+    coder/psychoac.py:310-329."""
+    n = len(inten)
+    idx = []
+    for i in range(1, n):
+        left_ok = inten[i] > inten[i - 1]
+        right_ok = True if i + 1 >= n else inten[i] > inten[i + 1]
+        if left_ok and right_ok:
+            idx.append(i)
+    out_f, out_spl = [], []
+    for f in idx:
+        pair = inten[f - 1:f + 1]
+        out_spl.append(spl_of(np.sum(pair)))
+        out_f.append(np.sum(freqs[f - 1:f + 1] * pair) / np.sum(pair))
+    return out_f, out_spl
+
+
+def masker_curve_spl(f, spl, z_lines):
+    """SPL(Intensity(.)) of one tonal masker at Bark positions z_lines.
+    coder/psychoac.py:64,90-96 then :192."""
+    z0 = bark_of(f)
+    dz = z_lines - z0
+    gain = np.zeros_like(z_lines)
+    gain[dz < -0.5] = -27 * (abs(dz[dz < -0.5]) - 0.5)
+    gain[dz > 0.5] = (-27 + 0.367 * max(spl - 40, 0)) * (
+        abs(dz[dz > 0.5]) - 0.5)
+    return spl_of(intensity_of(spl + gain - TONAL_DROP))
+
+
+def masked_threshold(data, n_lines, sample_rate):
+    """coder/psychoac.py:171-217.  Tonal maskers + threshold in quiet only: the
+    reference's noise-masker loop (:197-211) never appends its curve."""
+    n = len(data)
+    inten = sidechain_intensity(data)
+    freqs = np.fft.rfftfreq(n, d=1 / sample_rate)
+    pk_f, pk_spl = find_peaks(inten, freqs)
+    spacing = sample_rate / (2 * n_lines)
+    line_f = spacing * (np.arange(n_lines) + 0.5)
+    z_lines = bark_of(line_f)
+    curves = [masker_curve_spl(f, s, z_lines) for f, s in zip(pk_f, pk_spl)]
+    curves.append(thresh_quiet(line_f))
+    return np.amax(curves, axis=0)
+
+
+def calc_smrs(data, mdct_scaled, scale, sample_rate, bands):
+    """Per-band max of (MDCT SPL - masked threshold), coder/psychoac.py:246-291.
+    MDCT SPL = SPL(4*(X/2^scale)^2) (:250-254)."""
+    thr = masked_threshold(data, len(mdct_scaled), sample_rate)
+    x = mdct_scaled / 2 ** scale
+    line_spl = spl_of(x ** 2 * (2 / (1 / 2)))
+    smr = np.zeros((bands.nBands,))
+    for b in range(bands.nBands):
+        lo, hi = bands.lowerLine[b], bands.upperLine[b] + 1
+        smr[b] = np.amax(line_spl[lo:hi] - thr[lo:hi])
+    return smr
+
+
+# -------------------------------------------------------------------------- A11
+def bit_alloc(budget, max_mant_bits, n_bands, n_lines, smr):
+    """Water-filling allocation, coder/bitalloc.py:77-121, quirks included:
+    np.round is half-to-even; when the flip counter overruns the sorted
+    fractions only the counter steps back (bits stay); hard stop after the
+    201st pass."""
+    if max_mant_bits > 16:
+        max_mant_bits = 16
+    bits = np.zeros(n_bands, dtype=int)
+    dropped = np.zeros(n_bands, dtype=bool)
+    n_flip = 0
+    passes = 0
+    while True:
+        live = np.logical_not(dropped)
+        total = np.sum(n_lines[live])
+        if total == 0:
+            total += 1e-12
+        want = budget / total + (1.0 / DB_PER_BIT) * (
+            smr[live] - np.sum(n_lines[live] * smr[live]) / total)
+        frac = want - np.floor(want) - 0.5
+        ladder = np.sort(frac[frac > 0])
+        if n_flip > len(ladder):
+            n_flip -= 1
+        else:
+            level = 0. if n_flip == 0 else ladder[n_flip - 1]
+            bits[live] = np.round(want - level)
+        bits[bits > max_mant_bits] = max_mant_bits
+        dropped = bits < 2
+        bits[dropped] = 0
+        stable = np.logical_xor(dropped, live).all()
+        spent = np.sum(np.multiply(bits, n_lines))
+        if stable & (spent <= budget):
+            break
+        if stable & (spent > budget):
+            n_flip += 1
+        passes += 1
+        if passes > 200:
+            break
+    return bits
+
+
+# ---------------------------------------------------------------- A13 (+A14 flags)
+class Params:
+    """Attribute bag standing in for coder/audiofile.py:51-53 CodingParams."""
+    pass
+
+
+def make_params(sample_rate, n_channels, kbps_per_channel, n_lines=1024,
+                n_scale_bits=4, n_mant_size_bits=12):
+    """The driver's settings, coder/pacfile.py:699-707,323-330, scalar path."""
+    p = Params()
+    p.sampleRate = sample_rate
+    p.nChannels = n_channels
+    p.nMDCTLines = p.nSamplesPerBlock = n_lines
+    p.nScaleBits = n_scale_bits
+    p.nMantSizeBits = n_mant_size_bits
+    p.targetBitsPerSample = kbps_per_channel / (sample_rate / 1000)
+    p.useSBR = False
+    p.useVQ = False
+    p.sfBands = band_table(n_lines, sample_rate)
+    p.sfBandsShort = band_table(SHORT_LINES, sample_rate)
+    p.omittedBands = []
+    p.bitsPerSample = 16
+    return p
+
+
+def bit_budget(p, last_trans, cur_trans, next_trans):
+    """coder/codec.py:288-299 (scalar-mantissa branch)."""
+    half_n = p.nMDCTLines
+    bands = p.sfBandsShort if cur_trans else p.sfBands
+    n_eff = int(1.45 * half_n) if cur_trans else half_n
+    if last_trans or next_trans:
+        n_eff = int(0.85 * n_eff)
+    budget = p.targetBitsPerSample * n_eff
+    budget -= p.nScaleBits * (bands.nBands + 1)
+    budget -= p.nMantSizeBits * bands.nBands
+    return budget
+
+
+def encode_channel(data, p, last_trans=False, cur_trans=False,
+                   next_trans=False, stages=None):
+    """One channel-frame, coder/codec.py:274-380 with useVQ False.
+    Returns (scaleFactor int32[nBands], bitAlloc int[nBands],
+    mantissa int32[nMant], overallScale int).  `stages`, if a dict, receives
+    the intermediate arrays (test use)."""
+    half_n = p.nMDCTLines
+    n_scale_bits = p.nScaleBits
+    max_mant = min(1 << p.nMantSizeBits, 16)
+    bands = p.sfBandsShort if cur_trans else p.sfBands
+    budget = bit_budget(p, last_trans, cur_trans, next_trans)
+
+    windowed = apply_window(data, last_trans, cur_trans, next_trans)
+    lines = mdct_forward(windowed, half_n, half_n)[:half_n]
+    if stages is not None:
+        stages['windowed'] = windowed.copy()
+        stages['mdct'] = lines.copy()
+    overall = scale_factor(np.max(np.abs(lines)), n_scale_bits)
+    lines *= (1 << overall)
+
+    smr = calc_smrs(data, lines, overall, p.sampleRate, bands)
+    alloc = bit_alloc(budget, max_mant, bands.nBands, bands.nLines, smr)
+    if stages is not None:
+        stages['smr'] = smr.copy()
+        stages['budget'] = budget
+
+    sf = np.empty(bands.nBands, dtype=np.int32)
+    n_mant = half_n
+    for b in range(bands.nBands):
+        if not alloc[b]:
+            n_mant -= bands.nLines[b]
+    mant = np.empty(n_mant, dtype=np.int32)
+    at = 0
+    for b in range(bands.nBands):
+        lo, hi = bands.lowerLine[b], bands.upperLine[b] + 1
+        sf[b] = scale_factor(np.max(np.abs(lines[lo:hi])), n_scale_bits,
+                             alloc[b])
+        if alloc[b]:
+            mant[at:at + bands.nLines[b]] = mantissa_vec(
+                lines[lo:hi], sf[b], n_scale_bits, alloc[b])
+            at += bands.nLines[b]
+    return sf, alloc, mant, overall
+
+
+def encode(data, p, last_trans=False, cur_trans=False, next_trans=False):
+    """coder/codec.py:249-263: loop channels, return four lists."""
+    out = ([], [], [], [])
+    for ch in range(p.nChannels):
+        r = encode_channel(data[ch], p, last_trans, cur_trans, next_trans)
+        for dst, v in zip(out, r):
+            dst.append(v)
+    return out
+
+
+# -------------------------------------------------- section 8f-2: block-switch flags
+def transient_detect(block, thresh=4.5):
+    """Peak-to-average detector over a [nCh, 2*hop] block,
+    coder/detect_transients.py:9-23 (axis=1).  Returns 0/False/True like the
+    reference does."""
+    mag = np.abs(block)
+    peak = np.max(mag, axis=1)
+    upto = np.argmax(mag, axis=1) + 500
+    cols = np.arange(min(max(upto), block.shape[1]))
+    if len(cols) != 0:
+        avg = np.mean(np.abs(np.take(block, cols, axis=1)))
+    else:
+        avg = np.mean(mag)
+    if np.any(avg == 0):
+        return 0
+    return bool(np.any(peak / avg > thresh))
+
+
+# ------------------------------------------------------ section 8f-1: .pac bit layout
+class BitWriter:
+    """MSB-first bit packer with the semantics of coder/bitpack.py:37-102
+    (low nBits of each value, bytes filled from the top bit down)."""
+
+    def __init__(self, n_bytes):
+        self.buf = bytearray(n_bytes)
+        self.pos = 0
+
+    def put(self, value, n_bits):
+        value = int(value) & ((1 << n_bits) - 1) if n_bits else 0
+        for i in range(n_bits - 1, -1, -1):
+            if (value >> i) & 1:
+                self.buf[self.pos >> 3] |= 0x80 >> (self.pos & 7)
+            self.pos += 1
+
+    def bytes(self):
+        return bytes(self.buf)
+
+
+class BitReader:
+    """MSB-first reader (the inverse of BitWriter; coder/bitpack.py:105-173)."""
+
+    def __init__(self, data):
+        self.buf = bytes(data)
+        self.pos = 0
+
+    def get(self, n_bits):
+        v = 0
+        for _ in range(n_bits):
+            v = (v << 1) | ((self.buf[self.pos >> 3] >> (7 - (self.pos & 7))) & 1)
+            self.pos += 1
+        return v
+
+
+def block_bits(p, alloc, cur_trans=False):
+    """Bits of one (sub-)block body, coder/pacfile.py:342-361 (no SBR)."""
+    bands = p.sfBandsShort if cur_trans else p.sfBands
+    n = p.nScaleBits
+    for b in range(bands.nBands):
+        n += p.nMantSizeBits + p.nScaleBits
+        if alloc[b]:
+            n += alloc[b] * bands.nLines[b]
+    return n
+
+
+def write_block_body(bw, p, overall, alloc, sf, mant, cur_trans=False):
+    """coder/pacfile.py:418-447: overall scale, then per band
+    (alloc-1 or 0), scale factor, mantissas of allocated bands."""
+    bands = p.sfBandsShort if cur_trans else p.sfBands
+    bw.put(overall, p.nScaleBits)
+    at = 0
+    for b in range(bands.nBands):
+        ba = int(alloc[b])
+        bw.put(ba - 1 if ba else 0, p.nMantSizeBits)
+        bw.put(sf[b], p.nScaleBits)
+        if ba:
+            for j in range(bands.nLines[b]):
+                bw.put(mant[at + j], ba)
+            at += bands.nLines[b]
+
+
+def pack_channel_block(p, flags, parts):
+    """One channel's payload for one hop: 3 flag bits then the body (long) or
+    the 8 sub-block bodies (short); size rule coder/pacfile.py:552-565.
+    parts = list of (sf, alloc, mant, overall) -- one entry for a long block,
+    eight for a short one.  Returns (nBytes, payload bytes)."""
+    last_t, cur_t, next_t = flags
+    n_bits = sum(block_bits(p, a, bool(cur_t)) for (_, a, _, _) in parts) + 4
+    n_bytes = n_bits // 8 if n_bits % 8 == 0 else n_bits // 8 + 1
+    bw = BitWriter(n_bytes)
+    bw.put(last_t, 1)
+    bw.put(cur_t, 1)
+    bw.put(next_t, 1)
+    for (sf, alloc, mant, overall) in parts:
+        write_block_body(bw, p, overall, alloc, sf, mant, bool(cur_t))
+    return n_bytes, bw.bytes()
+
+
+def pac_header(p, num_samples):
+    """coder/pacfile.py:306-333: tag, '<LHLLHHHH', nBands, nLines.  numSamples
+    gets +nMDCTLines only when it already IS a multiple (the reference's
+    inverted test, :309-313; the added amount is then a full block), then
+    +nMDCTLines for the delay block (:315)."""
+    n = num_samples
+    if not n % p.nMDCTLines:
+        n += p.nMDCTLines - n % p.nMDCTLines
+    n += p.nMDCTLines
+    out = b'PAC ' + struct.pack('<LHLLHHHH', p.sampleRate, p.nChannels, n,
+                                p.nMDCTLines, p.nScaleBits, p.nMantSizeBits,
+                                int(p.useSBR), int(p.useVQ))
+    out += struct.pack('<L', p.sfBands.nBands)
+    out += struct.pack('<' + str(p.sfBands.nBands) + 'H',
+                       *(p.sfBands.nLines.tolist()))
+    return out
+
+
+def encode_hop(p, prior, hop, flags):
+    """coder/pacfile.py:460-547: frame = prior || hop per channel; long block
+    -> one encode per channel; short block -> 8 sub-blocks of 256 samples at
+    n = 448 + 128 j, and the WHOLE hop is dropped (None) if any sub-block of
+    any channel is all zeros (:530-533)."""
+    last_t, cur_t, next_t = flags
+    n_ch = p.nChannels
+    full = [np.concatenate((prior[ch], hop[ch])) for ch in range(n_ch)]
+    if not cur_t:
+        return [[encode_channel(full[ch], p, last_t, cur_t, next_t)]
+                for ch in range(n_ch)]
+    long_n = p.nMDCTLines
+    short_n = SHORT_LINES
+    pad = long_n // 2 - short_n // 2
+    per_ch = [[] for _ in range(n_ch)]
+    p.nMDCTLines = p.nSamplesPerBlock = short_n
+    try:
+        for n in range(pad, 2 * long_n - short_n - pad, short_n):
+            for ch in range(n_ch):
+                if np.all(full[ch][n:n + 2 * short_n] == 0):
+                    return None
+            for ch in range(n_ch):
+                per_ch[ch].append(encode_channel(full[ch][n:n + 2 * short_n],
+                                                 p, last_t, cur_t, next_t))
+    finally:
+        p.nMDCTLines = p.nSamplesPerBlock = long_n
+    return per_ch
+
+
+def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False,
+                  max_hops=None, collect=None):
+    """Whole-file scalar-path encode: the driver loop of
+    coder/pacfile.py:716-757 plus Close (:612-625) on int16 PCM [nSamples, nCh].
+    Returns the .pac bytes.  The last hop is written twice (the loop body runs
+    once more after EOF with the stale lookahead) and Close pushes a zero hop
+    with flags (0,0,0).  `collect`, if a list, receives
+    (flags, per-channel parts or None) per written hop."""
+    pcm = np.asarray(pcm)
+    n_samples, n_ch = pcm.shape
+    p = make_params(sample_rate, n_ch, kbps_per_channel)
+    hop_n = p.nMDCTLines
+    out = [pac_header(p, n_samples)]
+    n_hops = -(-n_samples // hop_n)
+    if max_hops is not None:
+        n_hops = min(n_hops, max_hops)
+    prior = [np.zeros(hop_n) for _ in range(n_ch)]
+    look = np.zeros((n_ch, 2 * hop_n))
+    last_t = cur_t = False
+
+    def emit(hop, flags):
+        nonlocal prior
+        parts = encode_hop(p, prior, hop, flags)
+        prior = hop
+        if collect is not None:
+            collect.append((flags, parts))
+        if parts is None:
+            return
+        for ch in range(n_ch):
+            n_bytes, payload = pack_channel_block(p, flags, parts[ch])
+            out.append(struct.pack('<L', int(n_bytes)))
+            out.append(payload)
+
+    for h in range(n_hops + 1):
+        have = h < n_hops
+        if have:
+            chunk = pcm[h * hop_n:(h + 1) * hop_n]
+            if len(chunk) < hop_n:
+                chunk = np.concatenate(
+                    (chunk, np.zeros((hop_n - len(chunk), n_ch), pcm.dtype)))
+            data = np.array([pcm16_to_fraction(chunk[:, ch])
+                             for ch in range(n_ch)])
+            look = np.concatenate((np.copy(data), look[:, hop_n:]), axis=1)
+            nxt = transient_detect(look) if block_switching else False
+        else:
+            nxt = False
+        hop = look[:, :hop_n]
+        emit([hop[ch] for ch in range(n_ch)], (last_t, cur_t, nxt))
+        last_t, cur_t = cur_t, nxt
+    emit([np.zeros(hop_n) for _ in range(n_ch)], (False, False, False))
+    return b''.join(out)

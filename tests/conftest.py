@@ -1,0 +1,32 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line(
+        "markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def tables():
+    return np.load(os.path.join(GOLDEN, "tables.npz"))
+
+
+@pytest.fixture(scope="session")
+def stages():
+    return np.load(os.path.join(GOLDEN, "stages.npz"))
+
+
+def load_excerpt(name):
+    return np.load(os.path.join(GOLDEN, f"excerpt_{name}.npz"))
+
+
+EXCERPTS = ["castanet", "harpsichord", "quar48_1", "spmg"]
