@@ -1,0 +1,260 @@
+/*
+ * pacx_exact.h -- the order-sensitive scalar arithmetic of the encode path,
+ * written once for device (hipcc) and host (g++, tests/hostcheck) builds.
+ *
+ * Everything here must be compiled with -ffp-contract=off: the reference does
+ * these steps as individually rounded IEEE double operations and the integer
+ * codes only match bit for bit if the same roundings happen.
+ */
+#ifndef PACX_EXACT_H
+#define PACX_EXACT_H
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PACX_HD __host__ __device__ __forceinline__
+#else
+#define PACX_HD static inline
+#endif
+
+#define PACX_MAX_BANDS 32          /* bands of one (sub-)block; 25 critical bands at most */
+#define PACX_ALLOC_MAX_PASSES 200  /* coder/bitalloc.py:116-119                    */
+#define PACX_DB_PER_BIT 6.2        /* coder/bitalloc.py:61                         */
+#define PACX_EPS 2.220446049250313e-16 /* np.finfo(float).eps, coder/psychoac.py:20 */
+
+/* A0 -- coder/pcmfile.py:89-99 + coder/quantize.py:82-95:
+ * value = +-(2*(|c| & 32767)) / 65535 with a correctly rounded division
+ * (one multiply by RN(1/65535) plus one FMA residual step; checked over all
+ * 65536 codes against the reference's own conversion in tests). */
+PACX_HD double pacx_pcm16_to_f64(int c)
+{
+    const int neg = c < 0;
+    const int mag = (neg ? -c : c) & 32767;
+    const double n = (double)(2 * mag);
+    const double inv = 1.0 / 65535.0;
+    double q = n * inv;
+    const double e = fma(-q, 65535.0, n);
+    q = fma(e, inv, q);
+    return neg ? -q : q;
+}
+
+/* A5/A12 -- magnitude code of the R-bit midtread quantiser for |x| = ax
+ * (coder/quantize.py:29-32 scalar, :73-74 vector): clip at 1, else
+ * floor(((2^R - 1)*ax + 1) / 2). */
+PACX_HD int64_t pacx_quant_mag(double ax, int r_bits)
+{
+    if (ax >= 1.0)
+        return ((int64_t)1 << (r_bits - 1)) - 1;
+    const double t = (double)(((int64_t)1 << r_bits) - 1) * ax + 1.0;
+    return (int64_t)floor(t * 0.5);
+}
+
+PACX_HD int pacx_clz64(uint64_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)v);
+#else
+    return __builtin_clzll(v);
+#endif
+}
+
+/* A5 -- ScaleFactor(aNum, nScaleBits, nMantBits), coder/quantize.py:107-125:
+ * zeros above the first set bit of the (R-1)-bit magnitude, capped. */
+PACX_HD int pacx_scale_factor(double ax, int n_scale_bits, int n_mant_bits)
+{
+    const int r_bits = (1 << n_scale_bits) - 1 + n_mant_bits;
+    const int64_t mag = pacx_quant_mag(ax, r_bits) & (((int64_t)1 << (r_bits - 1)) - 1);
+    int zeros;
+    if (mag == 0)
+        zeros = r_bits - 1;
+    else
+        zeros = (r_bits - 2) - (63 - pacx_clz64((uint64_t)mag));
+    const int cap = (1 << n_scale_bits) - 1;
+    return zeros < cap ? zeros : cap;
+}
+
+/* A12 -- one block-floating-point mantissa, coder/quantize.py:238-250. */
+PACX_HD int32_t pacx_mantissa(double x, int scale, int n_scale_bits, int n_mant_bits)
+{
+    const int r_bits = (1 << n_scale_bits) - 1 + n_mant_bits;
+    const int64_t mag = pacx_quant_mag(fabs(x), r_bits);
+    const int64_t keep = ((int64_t)1 << (n_mant_bits - 1)) - 1;
+    const int64_t sign = (x < 0.0) ? ((int64_t)1 << (n_mant_bits - 1)) : 0;
+    int64_t m;
+    if (scale == (1 << n_scale_bits) - 1)
+        m = mag & keep;
+    else
+        m = (mag >> (r_bits - scale - n_mant_bits)) & keep;
+    return (int32_t)(sign + m);
+}
+
+/* np.sum of a contiguous float64 vector (NumPy pairwise_sum: plain loop below
+ * 8 elements, else 8 running accumulators folded as ((0+1)+(2+3))+((4+5)+(6+7))
+ * and a scalar tail; n <= 128 here so no recursive split). */
+PACX_HD double pacx_np_sum(const double *a, int n)
+{
+    if (n < 8) {
+        double r = -0.0;
+        for (int i = 0; i < n; ++i)
+            r = r + a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 = r0 + a[i + 0]; r1 = r1 + a[i + 1]; r2 = r2 + a[i + 2]; r3 = r3 + a[i + 3];
+        r4 = r4 + a[i + 4]; r5 = r5 + a[i + 5]; r6 = r6 + a[i + 6]; r7 = r7 + a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i)
+        res = res + a[i];
+    return res;
+}
+
+/* Budget rule of coder/codec.py:288-299 (scalar-mantissa branch). */
+PACX_HD double pacx_bit_budget(double target_bits_per_sample, int half_n, int is_short,
+                               int last_or_next, int n_scale_bits, int n_mant_size_bits,
+                               int n_bands)
+{
+    int n_eff = is_short ? (int)(1.45 * half_n) : half_n;
+    if (last_or_next)
+        n_eff = (int)(0.85 * n_eff);
+    double budget = target_bits_per_sample * (double)n_eff;
+    budget = budget - (double)(n_scale_bits * (n_bands + 1));
+    budget = budget - (double)(n_mant_size_bits * n_bands);
+    return budget;
+}
+
+/* A11 -- BitAlloc, coder/bitalloc.py:77-121.  Returns the number of passes;
+ * *hit_cap is set when the loop left through its 200-pass guard. */
+PACX_HD int pacx_bit_alloc(double budget, int max_mant_bits, int n_bands,
+                           const int32_t *n_lines, const double *smr,
+                           int32_t *bits, int *hit_cap)
+{
+    unsigned dropped = 0;          /* bit b set: band b flagged (gets no bits) */
+    int n_flip = 0;
+    int passes = 0;
+    if (max_mant_bits > 16)
+        max_mant_bits = 16;
+    for (int b = 0; b < n_bands; ++b)
+        bits[b] = 0;
+    *hit_cap = 0;
+    for (;;) {
+        double prod[PACX_MAX_BANDS];
+        double want[PACX_MAX_BANDS];
+        double ladder[PACX_MAX_BANDS];
+        int idx[PACX_MAX_BANDS];
+        int nv = 0;
+        int64_t total_i = 0;
+        for (int b = 0; b < n_bands; ++b) {
+            if (!((dropped >> b) & 1u)) {
+                idx[nv] = b;
+                prod[nv] = (double)n_lines[b] * smr[b];
+                total_i += n_lines[b];
+                ++nv;
+            }
+        }
+        double total = (double)total_i;
+        if (total_i == 0)
+            total = total + 1e-12;
+        const double mean = pacx_np_sum(prod, nv) / total;
+        const double base = budget / total;
+        const double per_db = 1.0 / PACX_DB_PER_BIT;
+        int nd = 0;
+        for (int i = 0; i < nv; ++i) {
+            want[i] = base + per_db * (smr[idx[i]] - mean);
+            const double frac = (want[i] - floor(want[i])) - 0.5;
+            if (frac > 0.0) {              /* insertion into the ascending ladder */
+                int j = nd++;
+                while (j > 0 && ladder[j - 1] > frac) {
+                    ladder[j] = ladder[j - 1];
+                    --j;
+                }
+                ladder[j] = frac;
+            }
+        }
+        if (n_flip > nd) {
+            n_flip -= 1;                   /* bits keep their previous values */
+        } else {
+            const double level = (n_flip == 0) ? 0.0 : ladder[n_flip - 1];
+            for (int i = 0; i < nv; ++i)
+                bits[idx[i]] = (int32_t)rint(want[i] - level);   /* np.round: half to even */
+        }
+        unsigned now_dropped = 0;
+        int64_t spent = 0;
+        for (int b = 0; b < n_bands; ++b) {
+            if (bits[b] > max_mant_bits)
+                bits[b] = max_mant_bits;
+            if (bits[b] < 2) {
+                now_dropped |= 1u << b;
+                bits[b] = 0;
+            }
+            spent += (int64_t)bits[b] * n_lines[b];
+        }
+        const int stable = (now_dropped == dropped);
+        dropped = now_dropped;
+        if (stable && (double)spent <= budget)
+            break;
+        if (stable && (double)spent > budget)
+            n_flip += 1;
+        ++passes;
+        if (passes > PACX_ALLOC_MAX_PASSES) {
+            *hit_cap = 1;
+            break;
+        }
+    }
+    return passes;
+}
+
+/* coder/psychoac.py:10-25, array flavour: exact zero -> 1e-8, floor at -30. */
+PACX_HD double pacx_spl_array(double intensity)
+{
+    if (intensity == 0.0)
+        intensity = 1e-8;
+    double spl = 96.0 + 10.0 * log10(fabs(intensity) + PACX_EPS);
+    if (spl < -30.0)
+        spl = -30.0;
+    return spl;
+}
+
+/* coder/psychoac.py:10-25, scalar flavour: exact zero -> -30. */
+PACX_HD double pacx_spl_scalar(double intensity)
+{
+    if (intensity == 0.0)
+        return -30.0;
+    double spl = 96.0 + 10.0 * log10(fabs(intensity) + PACX_EPS);
+    if (spl < -30.0)
+        spl = -30.0;
+    return spl;
+}
+
+/* coder/psychoac.py:45-46 */
+PACX_HD double pacx_bark(double f)
+{
+    const double t = f / 7500.0;
+    return 13.0 * atan(0.76 * f / 1000.0) + 3.5 * atan(t * t);
+}
+
+/* coder/psychoac.py:37-40 */
+PACX_HD double pacx_thresh_quiet(double f)
+{
+    if (f < 10.0)
+        f = 10.0;
+    const double k = f / 1000.0;
+    const double d = k - 3.3;
+    return 3.64 * pow(k, -0.8) - 6.5 * exp(-0.6 * (d * d)) + 0.001 * (k * k * k * k);
+}
+
+/* codec.getCorrectWindow, coder/codec.py:30-44 */
+PACX_HD int pacx_window_kind(unsigned flags)
+{
+    const int last_t = flags & 1u, cur_t = (flags >> 1) & 1u, next_t = (flags >> 2) & 1u;
+    if (cur_t) return 0;
+    if (last_t && next_t) return 3;
+    if (last_t) return 2;
+    if (next_t) return 1;
+    return 0;
+}
+
+#endif /* PACX_EXACT_H */

@@ -1,0 +1,246 @@
+/*
+ * pacx.h -- C ABI of the MI355X (gfx950) batched audio-frame encode path.
+ *
+ * Drop-in boundary for the per-frame hot loop of Abhipray/audio-codec.  The
+ * reference has no FFI layer: the path sits behind plain Python calls,
+ *     PACFile.Encode        coder/pacfile.py:627-643
+ *     codec.Encode          coder/codec.py:225-263
+ *     codec.EncodeSingleChannel  coder/codec.py:266-380
+ * and the five modules those call (window.py, mdct.py, psychoac.py,
+ * bitalloc.py, quantize.py).  Each entry point below names the reference
+ * function(s) it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative PACX_E_* code and
+ *     never throws; pacx_last_error() gives the text;
+ *   - the CALLER owns every data buffer.  All `const void*` / `T*` data
+ *     arguments are DEVICE pointers (hipMalloc / torch tensor .data_ptr())
+ *     unless the parameter is documented as host;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*, NULL =
+ *     default stream) and is asynchronous; the library keeps a grow-only
+ *     device workspace per handle (pacx_reserve() sizes it up front so that
+ *     no allocation happens inside a timed or graph-captured region);
+ *   - one handle per device; handles are independent (no global state).
+ *
+ * Units: a "channel-frame" (cf) is one EncodeSingleChannel call: 2*nMDCTLines
+ * samples of one channel in, nMDCTLines MDCT lines out.  cf index =
+ * frame * n_channels + channel (the order blocks appear in a .pac file).
+ */
+#ifndef PACX_H
+#define PACX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PACX_ABI_VERSION 1
+
+/* error codes */
+#define PACX_OK            0
+#define PACX_E_ARG        -1   /* bad argument                               */
+#define PACX_E_UNSUPPORTED -2  /* configuration outside what the kernels do  */
+#define PACX_E_HIP        -3   /* a HIP runtime call failed                  */
+#define PACX_E_NOMEM      -4
+
+/* sample formats of pacx_pcm.dtype */
+#define PACX_PCM_I16 0         /* 16-bit PCM codes (coder/pcmfile.py:89-99 contract) */
+#define PACX_PCM_F64 1         /* signed fractions, as codec.Encode receives them    */
+
+/* per-frame flag bits (coder/pacfile.py:575-577 order) */
+#define PACX_FLAG_LAST 1u
+#define PACX_FLAG_CUR  2u
+#define PACX_FLAG_NEXT 4u
+
+/* window kinds chosen by codec.getCorrectWindow (coder/codec.py:30-44) */
+#define PACX_WIN_SINE 0
+#define PACX_WIN_START 1
+#define PACX_WIN_STOP 2
+#define PACX_WIN_STARTSTOP 3
+
+/* per-cf status word bits written by pacx_encode_batch */
+#define PACX_ST_SHORT        1u   /* coded as 8 short sub-blocks               */
+#define PACX_ST_ZERO_SUBBLOCK 2u  /* a short sub-block was all zeros: the
+                                     reference drops the whole hop
+                                     (coder/pacfile.py:530-533)                */
+#define PACX_ST_ALLOC_CAP    4u   /* BitAlloc left through its 200-pass guard
+                                     (coder/bitalloc.py:116-119)               */
+
+#define PACX_SHORT_PER_FRAME 8    /* sub-blocks of a short frame (coder/pacfile.py:527) */
+
+typedef struct pacx_handle pacx_handle;
+
+/*
+ * Static configuration = the CodingParams attributes the path reads
+ * (coder/pacfile.py:699-707, 323-330).  Table pointers are HOST pointers,
+ * copied at create time.  Tables marked "optional" may be NULL: the library
+ * then evaluates the same formulas with the C math library (results can
+ * differ from NumPy's in the last place).
+ */
+typedef struct pacx_config {
+    int32_t abi_version;            /* PACX_ABI_VERSION                           */
+    int32_t device;                 /* HIP device ordinal                         */
+    int32_t sample_rate;            /* Hz                                         */
+    int32_t n_lines_long;           /* nMDCTLines of a long block: 1024           */
+    int32_t n_lines_short;          /* 128 (coder/pacfile.py:490)                 */
+    int32_t n_scale_bits;           /* 4                                          */
+    int32_t n_mant_size_bits;       /* 12                                         */
+    int32_t n_bands_long;           /* sfBands.nBands                             */
+    int32_t n_bands_short;          /* sfBandsShort.nBands                        */
+    double  target_bits_per_sample; /* kb/s per channel / (sampleRate/1000)       */
+    const int32_t *band_lines_long;   /* [n_bands_long]  sfBands.nLines            */
+    const int32_t *band_lines_short;  /* [n_bands_short] sfBandsShort.nLines       */
+    /* optional float64 tables, evaluated by the caller with NumPy so that they
+       are bit-identical to the reference's: */
+    const double *win_long;         /* [4][2*n_lines_long] kinds PACX_WIN_*       */
+    const double *win_short;        /* [2*n_lines_short] sine                     */
+    const double *hann_long;        /* [2*n_lines_long]  coder/window.py:37-39    */
+    const double *hann_short;       /* [2*n_lines_short]                          */
+    const double *bark_long;        /* [n_lines_long]  Bark(mdct line freq)       */
+    const double *thresh_long;      /* [n_lines_long]  Thresh(mdct line freq)     */
+    const double *bark_short;       /* [n_lines_short]                            */
+    const double *thresh_short;     /* [n_lines_short]                            */
+    double fft_norm_long;           /* 4/(N^2 mean(np.hanning(N)^2)); 0 = compute */
+    double fft_norm_short;
+    double fft_freq_step_long;      /* np.fft.rfftfreq step 1/(N*(1/sr)); 0 = compute */
+    double fft_freq_step_short;
+} pacx_config;
+
+/*
+ * Strided view of PCM input.  Sample s of frame f, channel c is element
+ *     data[f*frame_stride + c*channel_stride + s*sample_stride]   (strides in elements)
+ * for s in [0, 2*n_lines_long).  A stream with 50 % overlap
+ * (coder/pacfile.py:460-464: frame = prior hop || new hop) has
+ * frame_stride = n_lines_long * sample_stride and holds n_frames+1 hops, the
+ * first being the prior block (zeros at the start of a file,
+ * coder/pacfile.py:335-339).  Independent frames use frame_stride >= 2*n_lines_long.
+ * Fast path: dtype I16, sample_stride 1, data 16-byte aligned, strides
+ * multiples of 8.
+ */
+typedef struct pacx_pcm {
+    const void *data;
+    int32_t dtype;                  /* PACX_PCM_*                                 */
+    int32_t n_channels;
+    int64_t n_frames;
+    int64_t frame_stride;
+    int64_t channel_stride;
+    int64_t sample_stride;
+} pacx_pcm;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int  pacx_create(const pacx_config *cfg, pacx_handle **out);
+void pacx_destroy(pacx_handle *h);
+/* text of the last error on this handle (h may be NULL: last create error) */
+const char *pacx_last_error(const pacx_handle *h);
+int  pacx_abi_version(void);
+/* ints per cf in the scale_factor / bit_alloc outputs:
+   max(n_bands_long, 8*n_bands_short) */
+int  pacx_band_stride(const pacx_handle *h);
+/* bytes per cf slot in the packed-payload output of pacx_pack_batch */
+int  pacx_payload_stride(const pacx_handle *h);
+/* pre-size the device workspace for batches of up to n_cf channel-frames */
+int  pacx_reserve(pacx_handle *h, int64_t n_cf);
+
+/* ---- stage entry points (one per replaced reference module) ------------ */
+
+/*
+ * window.py + mdct.py: MDCT(window(data), halfN, halfN)[:halfN]
+ * (coder/codec.py:303-305; window choice coder/codec.py:30-44; int16 input is
+ * first mapped as coder/pcmfile.py:89-99 does).
+ *   short_blocks = 0: every frame is one long block; the window kind comes
+ *       from frame_flags (NULL = all sine).  lines: [n_cf][n_lines_long].
+ *   short_blocks = 1: every frame is cut into 8 short sub-blocks at
+ *       n = 448 + 128 j (coder/pacfile.py:526-527), sine-windowed.
+ *       lines: [n_cf][8][n_lines_short].
+ * frame_flags: device uint8 [n_frames] of PACX_FLAG_* or NULL.
+ * max_scale (optional, device int32 [n_cf] or [n_cf][8]): the overall scale
+ * factor ScaleFactor(max|line|, nScaleBits) (coder/codec.py:308-310).
+ * The lines written are NOT multiplied by 2^scale.
+ */
+int pacx_mdct_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
+                    int short_blocks, double *lines, int32_t *max_scale, void *stream);
+
+/*
+ * psychoac.py: CalcSMRs(data, mdctLines*2^scale, scale, sampleRate, sfBands)
+ * (coder/psychoac.py:220-291, with getMaskedThreshold :163-217 and
+ * estimate_peaks :308-329 inside).  `lines` are the UNSCALED MDCT lines
+ * (X / 2^scale is what the reference feeds to SPL, :250-254).
+ *   smr:       [n_cf][band_stride]  (short: sub-block j at [j*n_bands_short ...])
+ *   threshold: optional [n_cf][n_lines_long] masked threshold in dB SPL
+ *   n_peaks:   optional int32 [n_cf] (short: [n_cf][8]) tonal maskers found
+ */
+int pacx_smr_batch(pacx_handle *h, const pacx_pcm *in, const double *lines,
+                   int short_blocks, double *smr, double *threshold,
+                   int32_t *n_peaks, void *stream);
+
+/*
+ * bitalloc.py: BitAlloc(bitBudget, maxMantBits, nBands, nLines, SMRs)
+ * (coder/bitalloc.py:62-121) with the budget rule of coder/codec.py:288-299
+ * evaluated from the frame flags (scalar-mantissa variant).
+ *   bit_alloc: int32 [n_cf][band_stride]; status (optional) uint32 [n_cf].
+ */
+int pacx_bitalloc_batch(pacx_handle *h, int64_t n_cf, int n_channels,
+                        const uint8_t *frame_flags, int short_blocks,
+                        const double *smr, int32_t *bit_alloc, uint32_t *status,
+                        void *stream);
+
+/*
+ * quantize.py: per band ScaleFactor(max|line|, nScaleBits, bitAlloc) and
+ * vMantissa(lines, scale, nScaleBits, bitAlloc) (coder/codec.py:362-377) on
+ * lines * 2^overall_scale.
+ *   scale_factor: int32 [n_cf][band_stride]
+ *   mantissa:     int32 [n_cf][n_lines_long], LINE-indexed (0 where the band
+ *                 got no bits); the reference's dense layout is the
+ *                 concatenation of the allocated bands.
+ */
+int pacx_quantize_batch(pacx_handle *h, int64_t n_cf, const double *lines,
+                        const int32_t *overall_scale, const int32_t *bit_alloc,
+                        int short_blocks, int32_t *scale_factor, int32_t *mantissa,
+                        void *stream);
+
+/* ---- the whole path ---------------------------------------------------- */
+
+/*
+ * codec.Encode for a batch (coder/codec.py:225-380, scalar mantissas):
+ * window -> MDCT -> overall scale -> SMR -> BitAlloc -> scale factors and
+ * mantissas, for every channel of every frame.  Frames whose PACX_FLAG_CUR
+ * bit is set are coded as 8 short sub-blocks (coder/pacfile.py:489-547).
+ *   overall_scale: int32 [n_cf][8]      (long frames use [0])
+ *   scale_factor, bit_alloc: int32 [n_cf][band_stride]
+ *   mantissa: int32 [n_cf][n_lines_long] line-indexed
+ *   status:   uint32 [n_cf] PACX_ST_*
+ */
+int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
+                      int32_t *overall_scale, int32_t *scale_factor,
+                      int32_t *bit_alloc, int32_t *mantissa, uint32_t *status,
+                      void *stream);
+
+/*
+ * pacfile.py bit layout (coder/pacfile.py:404-447, 552-577; bitpack.py:37-102):
+ * per cf the MSB-first payload  last|cur|next | overallScale(4) |
+ * per band: (alloc-1 or 0)(nMantSizeBits) scaleFactor(nScaleBits) mantissas,
+ * eight such bodies for a short frame.
+ *   payload: uint8 [n_cf][payload_stride]; n_bytes: int32 [n_cf]
+ *   (0 for a hop the reference drops).
+ */
+int pacx_pack_batch(pacx_handle *h, int64_t n_cf, int n_channels,
+                    const uint8_t *frame_flags, const int32_t *overall_scale,
+                    const int32_t *scale_factor, const int32_t *bit_alloc,
+                    const int32_t *mantissa, const uint32_t *status,
+                    uint8_t *payload, int32_t *n_bytes, void *stream);
+
+/*
+ * Concatenate "<L nBytes" + payload of every cf in order (the body of a .pac
+ * file after its header, coder/pacfile.py:566-568,608).
+ *   body: uint8 [>= sum(4 + n_bytes)]; total_bytes: device int64 [1].
+ */
+int pacx_gather_body(pacx_handle *h, int64_t n_cf, const uint8_t *payload,
+                     const int32_t *n_bytes, uint8_t *body, int64_t body_capacity,
+                     int64_t *total_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PACX_H */

@@ -688,8 +688,41 @@ def encode_hop(p, prior, hop, flags):
     return per_ch
 
 
+def wav_effective_stream(raw, hop=1024):
+    """PCM the reference actually encodes for a WAV file image `raw`.
+
+    coder/pcmfile.py:32-64 finds 'fmt ' then 'data' and derives numSamples;
+    coder/pacfile.py:309-315 then INFLATES that same shared numSamples by one
+    hop (two if it was a multiple), so coder/pcmfile.py:66-80 keeps reading up
+    to that many bytes past the data chunk: whatever trails it in the file
+    (e.g. a LIST chunk) is decoded as samples, zero padded to a whole hop.
+    Returns (sample_rate, int16 [n, nCh], declared numSamples)."""
+    assert raw[0:4] == b"RIFF" and raw[8:12] == b"WAVE"
+    pos = 12
+    while raw[pos:pos + 4] != b"fmt ":
+        pos += 4
+    pos += 4
+    (_, tag, n_ch, sr, _, _, bits) = struct.unpack("<LHHLLHH", raw[pos:pos + 20])
+    assert tag == 1 and bits == 16
+    pos += 20
+    while raw[pos:pos + 4] != b"data":
+        pos += 4
+    pos += 4
+    n_samples = struct.unpack("<L", raw[pos:pos + 4])[0] // (n_ch * 2)
+    pos += 4
+    inflated = n_samples
+    if not inflated % hop:
+        inflated += hop - inflated % hop
+    inflated += hop
+    body = raw[pos:pos + inflated * n_ch * 2]
+    blk = hop * n_ch * 2
+    body = body + b"\0" * (-len(body) % blk)
+    pcm = np.frombuffer(body, dtype="<i2").reshape(-1, n_ch)
+    return sr, pcm, n_samples
+
+
 def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False,
-                  max_hops=None, collect=None):
+                  max_hops=None, collect=None, header_samples=None):
     """Whole-file scalar-path encode: the driver loop of
     coder/pacfile.py:716-757 plus Close (:612-625) on int16 PCM [nSamples, nCh].
     Returns the .pac bytes.  The last hop is written twice (the loop body runs
@@ -700,7 +733,7 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False,
     n_samples, n_ch = pcm.shape
     p = make_params(sample_rate, n_ch, kbps_per_channel)
     hop_n = p.nMDCTLines
-    out = [pac_header(p, n_samples)]
+    out = [pac_header(p, n_samples if header_samples is None else header_samples)]
     n_hops = -(-n_samples // hop_n)
     if max_hops is not None:
         n_hops = min(n_hops, max_hops)

@@ -1,0 +1,21 @@
+// Host build of audio-codec_amd/csrc/pacx_exact.h for the CPU test suite:
+// the same source the HIP kernels compile, exported for ctypes.
+#include "pacx_exact.h"
+
+extern "C" {
+double hc_pcm16_to_f64(int c) { return pacx_pcm16_to_f64(c); }
+long long hc_quant_mag(double ax, int r) { return pacx_quant_mag(ax, r); }
+int hc_scale_factor(double ax, int nsb, int nmb) { return pacx_scale_factor(ax, nsb, nmb); }
+int hc_mantissa(double x, int scale, int nsb, int nmb) { return pacx_mantissa(x, scale, nsb, nmb); }
+double hc_np_sum(const double *a, int n) { return pacx_np_sum(a, n); }
+double hc_bit_budget(double tbps, int half_n, int is_short, int lon, int nsb, int nmsb, int nb)
+{ return pacx_bit_budget(tbps, half_n, is_short, lon, nsb, nmsb, nb); }
+int hc_bit_alloc(double budget, int max_mant, int nb, const int32_t *n_lines, const double *smr,
+                 int32_t *bits, int *hit_cap)
+{ return pacx_bit_alloc(budget, max_mant, nb, n_lines, smr, bits, hit_cap); }
+double hc_spl_array(double v) { return pacx_spl_array(v); }
+double hc_spl_scalar(double v) { return pacx_spl_scalar(v); }
+double hc_bark(double f) { return pacx_bark(f); }
+double hc_thresh_quiet(double f) { return pacx_thresh_quiet(f); }
+int hc_window_kind(unsigned f) { return pacx_window_kind(f); }
+}

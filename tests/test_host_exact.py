@@ -1,0 +1,161 @@
+"""CPU checks of audio-codec_amd/csrc/pacx_exact.h (the order-sensitive scalar
+arithmetic shared by the HIP kernels) against the oracle: the header is built
+for the host with g++ and driven through ctypes.  No GPU needed."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import pac_oracle as po
+
+SRC = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")
+INC = os.path.join(ROOT, "audio-codec_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def hc(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("hostcheck") / "libhostcheck.so")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared",
+                           "-I", INC, SRC, "-o", out])
+    lib = ctypes.CDLL(out)
+    lib.hc_pcm16_to_f64.restype = ctypes.c_double
+    lib.hc_pcm16_to_f64.argtypes = [ctypes.c_int]
+    lib.hc_quant_mag.restype = ctypes.c_longlong
+    lib.hc_quant_mag.argtypes = [ctypes.c_double, ctypes.c_int]
+    lib.hc_scale_factor.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_int]
+    lib.hc_mantissa.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.hc_np_sum.restype = ctypes.c_double
+    lib.hc_np_sum.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.hc_bit_budget.restype = ctypes.c_double
+    lib.hc_bit_budget.argtypes = [ctypes.c_double] + [ctypes.c_int] * 6
+    lib.hc_bit_alloc.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    for f in ("hc_spl_array", "hc_spl_scalar", "hc_bark", "hc_thresh_quiet"):
+        getattr(lib, f).restype = ctypes.c_double
+        getattr(lib, f).argtypes = [ctypes.c_double]
+    lib.hc_window_kind.argtypes = [ctypes.c_uint]
+    return lib
+
+
+def c_bit_alloc(hc, budget, max_mant, n_lines, smr):
+    n_lines = np.ascontiguousarray(n_lines, dtype=np.int32)
+    smr = np.ascontiguousarray(smr, dtype=np.float64)
+    bits = np.zeros(len(n_lines), dtype=np.int32)
+    cap = ctypes.c_int(0)
+    passes = hc.hc_bit_alloc(budget, max_mant, len(n_lines), n_lines.ctypes.data,
+                             smr.ctypes.data, bits.ctypes.data, ctypes.byref(cap))
+    return bits, passes, cap.value
+
+
+def test_pcm_all_codes(hc, tables):
+    got = np.array([hc.hc_pcm16_to_f64(int(c)) for c in range(-32768, 32768)])
+    want = tables["pcm_all_fraction"]
+    assert np.array_equal(got, want)
+    assert np.array_equal(np.signbit(got), np.signbit(want))
+
+
+def test_scale_factor_and_mantissa(hc, tables):
+    sweep = tables["sf_sweep_in"]
+    for mb in (5, 0, 2, 7, 16):
+        got = [hc.hc_scale_factor(abs(float(v)), 4, mb) for v in sweep]
+        assert got == tables[f"sf_sweep_4_{mb}"].tolist()
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        ba = int(rng.integers(2, 17))
+        mag = 10.0 ** rng.uniform(-7, 0.02)
+        x = rng.uniform(-1, 1, 64) * mag
+        x[0] = 0.0
+        x[1] = -0.0
+        x[2] = -1e-300
+        sc = po.scale_factor(np.max(np.abs(x)), 4, ba)
+        assert sc == hc.hc_scale_factor(float(np.max(np.abs(x))), 4, ba)
+        want = po.mantissa_vec(x, sc, 4, ba)
+        got = [hc.hc_mantissa(float(v), sc, 4, ba) for v in x]
+        assert got == want.tolist()
+
+
+def test_np_sum_order(hc):
+    rng = np.random.default_rng(5)
+    for n in range(0, 27):
+        for _ in range(40):
+            a = np.ascontiguousarray(rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n))
+            assert hc.hc_np_sum(a.ctypes.data, n) == np.sum(a)
+
+
+def test_window_kind(hc):
+    for f in range(8):
+        assert hc.hc_window_kind(f) == po.window_kind(f & 1, (f >> 1) & 1, (f >> 2) & 1)
+
+
+def test_bit_budget(hc):
+    for sr in (48000, 44100):
+        for kbps in (128, 96):
+            p = po.make_params(sr, 1, kbps)
+            for flags in range(8):
+                last, cur, nxt = flags & 1, (flags >> 1) & 1, (flags >> 2) & 1
+                if cur:
+                    p.nMDCTLines = 128
+                want = po.bit_budget(p, last, cur, nxt)
+                nb = (p.sfBandsShort if cur else p.sfBands).nBands
+                got = hc.hc_bit_budget(p.targetBitsPerSample, p.nMDCTLines, cur,
+                                       int(bool(last or nxt)), 4, 12, nb)
+                p.nMDCTLines = 1024
+                assert got == want
+
+
+def test_bit_alloc_on_golden_smrs(hc, stages):
+    for kind in ("long", "short"):
+        for i in range(len(stages[f"{kind}_sr"])):
+            sr = int(stages[f"{kind}_sr"][i])
+            p = po.make_params(sr, 1, int(stages[f"{kind}_kbps"][i]))
+            if kind == "short":
+                p.nMDCTLines = 128
+            flags = [bool(f) for f in stages[f"{kind}_flags"][i]]
+            bands = p.sfBandsShort if kind == "short" else p.sfBands
+            nb = bands.nBands
+            budget = po.bit_budget(p, *flags)
+            bits, _, cap = c_bit_alloc(hc, budget, 16, bands.nLines, stages[f"{kind}_smr"][i][:nb])
+            assert bits.tolist() == stages[f"{kind}_ba"][i][:nb].tolist()
+            assert cap == 0
+
+
+def test_bit_alloc_random(hc):
+    rng = np.random.default_rng(21)
+    bands = [po.band_table(1024, 48000), po.band_table(1024, 44100), po.band_table(128, 48000)]
+    n_cap = 0
+    for t in range(3000):
+        b = bands[t % 3]
+        spread = rng.choice([3.0, 15.0, 40.0, 90.0])
+        smr = rng.standard_normal(b.nBands) * spread + rng.uniform(-30, 30)
+        if t % 7 == 0:
+            smr = np.round(smr)               # ties in the rounding ladder
+        if t % 11 == 0:
+            smr[:] = smr[0]
+        budget = float(rng.choice([2454.6666666666665, 2044.0, 1772.0, 157 * 2.9, 300.0, 12000.0]))
+        want = po.bit_alloc(budget, 16, b.nBands, b.nLines, smr)
+        got, passes, cap = c_bit_alloc(hc, budget, 16, b.nLines, smr)
+        n_cap += cap
+        assert got.tolist() == want.tolist(), (t, smr.tolist(), budget)
+    # all-dropped corner: every band below two bits
+    b = bands[0]
+    smr = np.full(b.nBands, -200.0)
+    assert c_bit_alloc(hc, 10.0, 16, b.nLines, smr)[0].tolist() == \
+        po.bit_alloc(10.0, 16, b.nBands, b.nLines, smr).tolist()
+
+
+def test_psycho_scalars(hc, tables):
+    rng = np.random.default_rng(2)
+    v = 10.0 ** rng.uniform(-20, 2, 500)
+    want = po.spl_of(v.copy())
+    got = np.array([hc.hc_spl_array(float(x)) for x in v])
+    assert np.max(np.abs(got - want)) < 1e-12
+    assert hc.hc_spl_array(0.0) == po.spl_of(np.array([0.0]))[0]
+    assert hc.hc_spl_scalar(0.0) == -30 and hc.hc_spl_scalar(1e-300) == -30
+    f = 48000 / 2048 * (np.arange(1024) + 0.5)
+    got = np.array([hc.hc_bark(float(x)) for x in f])
+    assert np.max(np.abs(got - tables["bark_1024_48000"])) < 1e-13
+    got = np.array([hc.hc_thresh_quiet(float(x)) for x in f])
+    assert np.max(np.abs(got - tables["thresh_1024_48000"]) / np.abs(tables["thresh_1024_48000"])) < 1e-12
