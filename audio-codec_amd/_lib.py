@@ -1,0 +1,122 @@
+"""ctypes binding of include/pacx.h.  The HIP library is the only compute path:
+if libpacx.so is missing (or no GPU is visible at create time) this raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpacx.so")
+
+PACX_ABI_VERSION = 1
+PCM_I16, PCM_F64 = 0, 1
+FLAG_LAST, FLAG_CUR, FLAG_NEXT = 1, 2, 4
+ST_SHORT, ST_ZERO_SUBBLOCK, ST_ALLOC_CAP = 1, 2, 4
+SUB = 8
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+
+class PacxConfig(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("sample_rate", ctypes.c_int32),
+        ("n_lines_long", ctypes.c_int32),
+        ("n_lines_short", ctypes.c_int32),
+        ("n_scale_bits", ctypes.c_int32),
+        ("n_mant_size_bits", ctypes.c_int32),
+        ("n_bands_long", ctypes.c_int32),
+        ("n_bands_short", ctypes.c_int32),
+        ("target_bits_per_sample", ctypes.c_double),
+        ("band_lines_long", c_int32_p),
+        ("band_lines_short", c_int32_p),
+        ("win_long", c_double_p),
+        ("win_short", c_double_p),
+        ("hann_long", c_double_p),
+        ("hann_short", c_double_p),
+        ("bark_long", c_double_p),
+        ("thresh_long", c_double_p),
+        ("bark_short", c_double_p),
+        ("thresh_short", c_double_p),
+        ("fft_norm_long", ctypes.c_double),
+        ("fft_norm_short", ctypes.c_double),
+        ("fft_freq_step_long", ctypes.c_double),
+        ("fft_freq_step_short", ctypes.c_double),
+    ]
+
+
+class PacxPcm(ctypes.Structure):
+    _fields_ = [
+        ("data", ctypes.c_void_p),
+        ("dtype", ctypes.c_int32),
+        ("n_channels", ctypes.c_int32),
+        ("n_frames", ctypes.c_int64),
+        ("frame_stride", ctypes.c_int64),
+        ("channel_stride", ctypes.c_int64),
+        ("sample_stride", ctypes.c_int64),
+    ]
+
+
+# name -> (restype, argtypes); this is the full export list of include/pacx.h
+_P = ctypes.c_void_p
+SIGNATURES = {
+    "pacx_abi_version": (ctypes.c_int, []),
+    "pacx_create": (ctypes.c_int, [ctypes.POINTER(PacxConfig), ctypes.POINTER(_P)]),
+    "pacx_destroy": (None, [_P]),
+    "pacx_last_error": (ctypes.c_char_p, [_P]),
+    "pacx_band_stride": (ctypes.c_int, [_P]),
+    "pacx_payload_stride": (ctypes.c_int, [_P]),
+    "pacx_reserve": (ctypes.c_int, [_P, ctypes.c_int64]),
+    "pacx_mdct_batch": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, ctypes.c_int, _P, _P, _P]),
+    "pacx_smr_batch": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, ctypes.c_int, _P, _P, _P, _P]),
+    "pacx_bitalloc_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, _P]),
+    "pacx_quantize_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int, _P, _P, _P]),
+    "pacx_encode_batch": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, _P, _P, _P, _P, _P, _P]),
+    "pacx_pack_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pacx_gather_body": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _P]),
+    "pacx_window_batch": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int64, _P, _P, _P]),
+    "pacx_quantize_uniform": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P]),
+    "pacx_scale_factor": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "pacx_mantissa": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "pacx_bitalloc_generic": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, ctypes.c_int, _P, _P, _P]),
+}
+WIN_SINE, WIN_START, WIN_STOP, WIN_STARTSTOP, WIN_SINE_SHORT, WIN_HANN, WIN_HANN_SHORT = range(7)
+MDCT_SHORT, MDCT_PREWINDOWED = 1, 2
+
+_lib = None
+
+
+class PacxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpacx.so and declare every prototype.  No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PacxError(
+            f"{LIB_PATH} not found: build it with `python audio-codec_amd/build.py` "
+            "(hipcc, gfx950).  There is no CPU implementation of this path.")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 (SONAME
+    # libamdhip64.so.7).  Importing torch first makes the loader resolve this
+    # library's NEEDED libamdhip64.so.7 to that already-loaded copy, so torch's
+    # device pointers and streams are valid here.  (A C host without torch
+    # resolves it through the RUNPATH to /opt/rocm.)
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pacx_abi_version() != PACX_ABI_VERSION:
+        raise PacxError("libpacx.so ABI version does not match the Python binding")
+    _lib = lib
+    return lib
+
+
+def check(lib, handle, rc, what):
+    if rc != 0:
+        msg = lib.pacx_last_error(handle)
+        raise PacxError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

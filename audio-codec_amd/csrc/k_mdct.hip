@@ -1,0 +1,231 @@
+/*
+ * k_mdct.hip -- window + MDCT kernels (reference: coder/window.py, coder/mdct.py,
+ * called at coder/codec.py:303-305; overall scale coder/codec.py:308-310).
+ *
+ * One channel-frame per wave64.  The MDCT of a windowed block x[0..N) with
+ * M = N/2 lines is computed through ONE complex FFT of Q = N/4 points
+ * (verified there against mdct.MDCT):
+ *     fold:  u[n]   = -x[3Q-1-n] - x[3Q+n],  u[Q+n] = x[n] - x[M-1-n]
+ *     pre :  t[n]   = (u[2n] + j u[M-1-2n]) * d[n],  d[n] = exp(-j pi (8n+1)/(8M))
+ *     FFT :  T      = FFT_Q(t)
+ *     post:  y[k]   = T[k] * d[k] * (2/N);  X[2k] = Re y[k], X[M-1-2k] = -Im y[k]
+ * (the single table d serves both twiddles: d[n] d[k] = exp(-j pi/(4M)) W_{2M}^{n+k}).
+ * The reference instead runs a full N-point FFT; results agree to ~2e-13 of the
+ * block maximum, which leaves every integer code downstream unchanged
+ * (SURVEY.md section 7 step 5).
+ *
+ * Data movement per cf (long, int16 fast path): 4 x 16-byte coalesced loads per
+ * lane of PCM -> LDS (4 KB), two LDS exchanges of 8 KB inside the FFT, 1024
+ * float64 lines out = 2 KB (new hop) + 8 KB algorithmic HBM bytes.
+ */
+#include "pacx_dev.h"
+#include "wave_fft.h"
+
+template <int DT> struct PcmStage;
+template <> struct PcmStage<0> {              /* int16 codes */
+    typedef short elem;
+    static __device__ __forceinline__ double get(const short *s, int i) { return pacx_pcm16_to_f64(s[i]); }
+};
+template <> struct PcmStage<1> {              /* float64 signed fractions */
+    typedef double elem;
+    static __device__ __forceinline__ double get(const double *s, int i) { return s[i]; }
+};
+
+/* copy `count` samples starting at sample `first` of frame cf into LDS */
+template <int DT, bool FAST>
+__device__ __forceinline__ void stage_samples(typename PcmStage<DT>::elem *dst, const PacxPcmView &in,
+                                              long long cf, int first, int count, int lane)
+{
+    typedef typename PcmStage<DT>::elem E;
+    const long long f = cf / in.n_ch;
+    const int ch = (int)(cf - f * in.n_ch);
+    const E *src = (const E *)in.base + f * in.frame_stride + ch * in.ch_stride;
+    if constexpr (FAST) {
+        /* int16, unit stride, 16-byte aligned rows: 8 samples per lane and load */
+        const int4 *s4 = (const int4 *)(src + first);
+        int4 *d4 = (int4 *)dst;
+        for (int i = lane; i < count / 8; i += 64)
+            d4[i] = s4[i];
+    } else {
+        for (int i = lane; i < count; i += 64)
+            dst[i] = src[(long long)(first + i) * in.samp_stride];
+    }
+}
+
+/* ------------------------------------------------------------------ long */
+template <int DT, bool FAST>
+__global__ __launch_bounds__(64) void k_mdct_long(PacxTables T, PacxPcmView in,
+                                                 const uint8_t *__restrict__ flags, long long n_cf,
+                                                 int skip_cur, int prewin, double *__restrict__ lines,
+                                                 int32_t *__restrict__ scale_out, int scale_stride)
+{
+    typedef typename PcmStage<DT>::elem E;
+    __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
+    __shared__ __attribute__((aligned(16))) E raw[PACX_N_LONG];
+    const int lane = threadIdx.x;
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf)
+        return;
+    const unsigned fl = flags ? flags[cf / in.n_ch] : 0u;
+    if (skip_cur && (fl & 2u))
+        return;
+    const double *__restrict__ w = prewin ? T.ones : T.win_long + pacx_window_kind(fl) * PACX_N_LONG;
+
+    stage_samples<DT, FAST>(raw, in, cf, 0, PACX_N_LONG, lane);
+    __syncthreads();
+
+    const int Q = PACX_N_LONG / 4, M = PACX_M_LONG;
+    cplx v[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = lane + 64 * n1;
+        double re, im;
+        if (n1 < 4) {            /* n < Q/2 */
+            const int i0 = 3 * Q - 1 - 2 * n, i1 = 3 * Q + 2 * n, i2 = Q - 1 - 2 * n, i3 = Q + 2 * n;
+            re = -(w[i0] * PcmStage<DT>::get(raw, i0)) - w[i1] * PcmStage<DT>::get(raw, i1);
+            im = w[i2] * PcmStage<DT>::get(raw, i2) - w[i3] * PcmStage<DT>::get(raw, i3);
+        } else {
+            const int m = 2 * n - Q;
+            const int i0 = m, i1 = M - 1 - m, i2 = 2 * Q + m, i3 = 4 * Q - 1 - m;
+            re = w[i0] * PcmStage<DT>::get(raw, i0) - w[i1] * PcmStage<DT>::get(raw, i1);
+            im = -(w[i2] * PcmStage<DT>::get(raw, i2)) - w[i3] * PcmStage<DT>::get(raw, i3);
+        }
+        v[n1] = c_mul(make_double2(re, im), T.tw_long[n]);
+    }
+
+    fft512(v, tile, T.w512, lane);
+
+    const double s = 2.0 / PACX_N_LONG;      /* 2^-10, exact */
+    double *__restrict__ out = lines + cf * PACX_M_LONG;
+    double mx = 0.0;
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) {
+        const int k = fft512_out_index(lane, k3);
+        const cplx y = c_mul(v[k3], T.tw_long[k]);
+        const double a = y.x * s, b = -(y.y * s);
+        out[2 * k] = a;
+        out[M - 1 - 2 * k] = b;
+        mx = fmax(mx, fmax(fabs(a), fabs(b)));
+    }
+    if (scale_out) {
+        mx = wave_max(mx);
+        if (lane == 0)
+            scale_out[cf * scale_stride] = pacx_scale_factor(mx, T.n_scale_bits, 5);
+    }
+}
+
+/* ----------------------------------------------------------------- short */
+/* 8 sub-blocks of 256 samples at n = 448 + 128 g (coder/pacfile.py:526-527),
+ * sine window, 128 lines each: lane = 8 g + r works on sub-block g. */
+template <int DT, bool FAST>
+__global__ __launch_bounds__(64) void k_mdct_short(PacxTables T, PacxPcmView in,
+                                                  const uint8_t *__restrict__ flags, long long n_cf,
+                                                  int only_cur, int prewin, double *__restrict__ lines,
+                                                  int32_t *__restrict__ scale_out,
+                                                  uint32_t *__restrict__ status)
+{
+    typedef typename PcmStage<DT>::elem E;
+    const int SPAN = PACX_N_SHORT + (PACX_SUB - 1) * PACX_M_SHORT;     /* 1152 samples */
+    __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
+    __shared__ __attribute__((aligned(16))) E raw[SPAN];
+    const int lane = threadIdx.x;
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf)
+        return;
+    const unsigned fl = flags ? flags[cf / in.n_ch] : 2u;
+    if (only_cur && !(fl & 2u))
+        return;
+    const double *__restrict__ w = prewin ? T.ones : T.win_short;
+
+    stage_samples<DT, FAST>(raw, in, cf, PACX_SHORT_FIRST, SPAN, lane);
+    __syncthreads();
+
+    const int g = lane >> 3, r = lane & 7;
+    const E *sub = raw + g * PACX_M_SHORT;
+    const int Q = PACX_N_SHORT / 4, M = PACX_M_SHORT;
+
+    /* coder/pacfile.py:530-533: an all-zero sub-block makes the writer drop the hop */
+    if (status) {
+        bool nz = false;
+        for (int i = r; i < PACX_N_SHORT; i += 8)
+            nz = nz || (PcmStage<DT>::get(sub, i) != 0.0);
+        const unsigned long long any = __ballot(nz);
+        bool dropped = false;
+        for (int q = 0; q < PACX_SUB; ++q)
+            dropped = dropped || (((any >> (8 * q)) & 0xFFull) == 0);
+        if (lane == 0)
+            status[cf] = 1u | (dropped ? 2u : 0u);
+    }
+
+    cplx v[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = r + 8 * n1;
+        double re, im;
+        if (n1 < 4) {
+            const int i0 = 3 * Q - 1 - 2 * n, i1 = 3 * Q + 2 * n, i2 = Q - 1 - 2 * n, i3 = Q + 2 * n;
+            re = -(w[i0] * PcmStage<DT>::get(sub, i0)) - w[i1] * PcmStage<DT>::get(sub, i1);
+            im = w[i2] * PcmStage<DT>::get(sub, i2) - w[i3] * PcmStage<DT>::get(sub, i3);
+        } else {
+            const int m = 2 * n - Q;
+            const int i0 = m, i1 = M - 1 - m, i2 = 2 * Q + m, i3 = 4 * Q - 1 - m;
+            re = w[i0] * PcmStage<DT>::get(sub, i0) - w[i1] * PcmStage<DT>::get(sub, i1);
+            im = -(w[i2] * PcmStage<DT>::get(sub, i2)) - w[i3] * PcmStage<DT>::get(sub, i3);
+        }
+        v[n1] = c_mul(make_double2(re, im), T.tw_short[n]);
+    }
+
+    fft64x8(v, tile, T.w512, lane);
+
+    const double s = 2.0 / PACX_N_SHORT;     /* 2^-7 */
+    double *__restrict__ out = lines + cf * PACX_M_LONG + g * PACX_M_SHORT;
+    double mx = 0.0;
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) {
+        const int k = fft64_out_index(lane, k3);
+        const cplx y = c_mul(v[k3], T.tw_short[k]);
+        const double a = y.x * s, b = -(y.y * s);
+        out[2 * k] = a;
+        out[M - 1 - 2 * k] = b;
+        mx = fmax(mx, fmax(fabs(a), fabs(b)));
+    }
+    if (scale_out) {
+        mx = fmax(mx, __shfl_xor(mx, 1, 64));
+        mx = fmax(mx, __shfl_xor(mx, 2, 64));
+        mx = fmax(mx, __shfl_xor(mx, 4, 64));
+        if (r == 0)
+            scale_out[cf * PACX_SUB + g] = pacx_scale_factor(mx, T.n_scale_bits, 5);
+    }
+}
+
+/* ------------------------------------------------------------- launchers */
+template <int DT, bool FAST>
+static void launch_mdct(const PacxTables &T, const PacxPcmView &in, const uint8_t *flags,
+                        long long n_cf, int short_blocks, int mixed, int prewin, double *lines,
+                        int32_t *scale_out, int scale_stride, uint32_t *status, hipStream_t st)
+{
+    const dim3 grid((unsigned)n_cf), block(64);
+    if (!short_blocks || mixed)
+        hipLaunchKernelGGL((k_mdct_long<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed,
+                           prewin, lines, scale_out, scale_stride);
+    if (short_blocks || mixed)
+        hipLaunchKernelGGL((k_mdct_short<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed,
+                           prewin, lines, scale_out, status);
+}
+
+/* mixed = 1: long kernel skips CUR frames, short kernel takes only CUR frames
+ * (scale_out is then [n_cf][8]); otherwise short_blocks selects one of them. */
+void pacx_launch_mdct(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
+                      const uint8_t *flags, long long n_cf, int short_blocks, int mixed, int prewin,
+                      double *lines, int32_t *scale_out, int scale_stride, uint32_t *status,
+                      hipStream_t st)
+{
+    if (n_cf <= 0)
+        return;
+    if (dtype == 0 && fast)
+        launch_mdct<0, true>(T, in, flags, n_cf, short_blocks, mixed, prewin, lines, scale_out, scale_stride, status, st);
+    else if (dtype == 0)
+        launch_mdct<0, false>(T, in, flags, n_cf, short_blocks, mixed, prewin, lines, scale_out, scale_stride, status, st);
+    else
+        launch_mdct<1, false>(T, in, flags, n_cf, short_blocks, mixed, prewin, lines, scale_out, scale_stride, status, st);
+}

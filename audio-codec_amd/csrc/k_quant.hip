@@ -1,0 +1,353 @@
+/*
+ * k_quant.hip -- bit allocation, scale factors + mantissas, bit packing.
+ *
+ *   k_bitalloc : BitAlloc (coder/bitalloc.py:62-121) with the budget rule of
+ *                coder/codec.py:288-299; one lane per (sub-)block -- the loop
+ *                is serial, data dependent and tiny (<= 25 bands)
+ *   k_quantize : per band ScaleFactor + vMantissa (coder/codec.py:362-377,
+ *                coder/quantize.py:99-125, 229-250); one wave per (sub-)block
+ *   k_pack     : MSB-first payload of one channel-block
+ *                (coder/pacfile.py:404-447, 552-577; coder/bitpack.py:37-102)
+ *   k_scan_x, k_copy_body : "<L nBytes" + payload of every cf back to back
+ *                (coder/pacfile.py:566-568, 608)
+ *
+ * All arithmetic that decides an integer code goes through pacx_exact.h and is
+ * compiled with -ffp-contract=off.
+ */
+#include "pacx_dev.h"
+#include "wave_fft.h"   /* wave_max */
+
+/* ---------------------------------------------------------------- bitalloc */
+__global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
+                                                long long n_cf, int short_blocks, int mixed,
+                                                const double *__restrict__ smr,
+                                                int32_t *__restrict__ bit_alloc,
+                                                uint32_t *__restrict__ status)
+{
+    const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long cf = tid / PACX_SUB;
+    const int sb = (int)(tid % PACX_SUB);
+    if (cf >= n_cf)
+        return;
+    const unsigned fl = flags ? flags[cf / n_ch] : 0u;
+    const bool is_short = mixed ? ((fl & 2u) != 0) : (short_blocks != 0);
+    if (!is_short && sb != 0)
+        return;
+    const int nb = is_short ? T.nb_short : T.nb_long;
+    const int32_t *n_lines = is_short ? T.band_lines_short : T.band_lines_long;
+    const double budget = pacx_bit_budget(T.target_bps, is_short ? PACX_M_SHORT : PACX_M_LONG,
+                                          is_short ? 1 : 0, (fl & 5u) != 0, T.n_scale_bits,
+                                          T.n_mant_size_bits, nb);
+    int max_mant = 1 << T.n_mant_size_bits;
+    if (max_mant > 16)
+        max_mant = 16;
+    const long long off = cf * T.band_stride + (is_short ? sb * nb : 0);
+    double s[PACX_MAX_BANDS];
+    int32_t nl[PACX_MAX_BANDS], bits[PACX_MAX_BANDS];
+    for (int b = 0; b < nb; ++b) {
+        s[b] = smr[off + b];
+        nl[b] = n_lines[b];
+    }
+    int cap = 0;
+    pacx_bit_alloc(budget, max_mant, nb, nl, s, bits, &cap);
+    for (int b = 0; b < nb; ++b)
+        bit_alloc[off + b] = bits[b];
+    if (cap && status)
+        atomicOr(&status[cf], 4u);
+}
+
+/* ---------------------------------------------------------------- quantize */
+template <int M>
+__global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
+                                                long long n_units, int mixed,
+                                                const double *__restrict__ lines,
+                                                const int32_t *__restrict__ overall, int overall_stride,
+                                                const int32_t *__restrict__ bit_alloc,
+                                                int32_t *__restrict__ scale_factor,
+                                                int32_t *__restrict__ mantissa)
+{
+    constexpr bool SHORT = (M == PACX_M_SHORT);
+    constexpr int PER = M / 64;
+    __shared__ double mag[M];
+    __shared__ int sfs[PACX_MAX_BANDS];
+    const int lane = threadIdx.x;
+    const long long unit = blockIdx.x;
+    if (unit >= n_units)
+        return;
+    const long long cf = SHORT ? unit / PACX_SUB : unit;
+    const int sb = SHORT ? (int)(unit % PACX_SUB) : 0;
+    if (mixed) {
+        const unsigned fl = flags ? flags[cf / n_ch] : 0u;
+        if (SHORT != ((fl & 2u) != 0))
+            return;
+    }
+    const int nb = SHORT ? T.nb_short : T.nb_long;
+    const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
+    const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
+    const uint8_t *__restrict__ band_of = SHORT ? T.line_band_short : T.line_band_long;
+    const long long boff = cf * T.band_stride + sb * T.nb_short;
+    const long long loff = cf * PACX_M_LONG + sb * PACX_M_SHORT;
+    const int ov = overall[SHORT ? (cf * overall_stride + (overall_stride == 1 ? 0 : sb)) : cf * overall_stride];
+    const double up = (double)(1 << ov);            /* mdctLines *= (1 << overallScale) */
+
+    double x[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int k = lane + 64 * j;
+        x[j] = lines[loff + k] * up;
+        mag[k] = fabs(x[j]);
+    }
+    __syncthreads();
+    for (int b = 0; b < nb; ++b) {
+        const int lo = lower[b], hi = lo + count[b];
+        double m = 0.0;
+        for (int k = lo + lane; k < hi; k += 64)
+            m = fmax(m, mag[k]);
+        m = wave_max(m);
+        if (lane == 0) {
+            const int sf = pacx_scale_factor(m, T.n_scale_bits, bit_alloc[boff + b]);
+            sfs[b] = sf;
+            scale_factor[boff + b] = sf;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int k = lane + 64 * j;
+        const int b = band_of[k];
+        const int ba = bit_alloc[boff + b];
+        mantissa[loff + k] = ba ? pacx_mantissa(x[j], sfs[b], T.n_scale_bits, ba) : 0;
+    }
+}
+
+/* -------------------------------------------------------------------- pack */
+#define PACX_PACK_WORDS 548            /* 2192 bytes >= 3 + 8*(4+8*16) + 1024*16 bits */
+
+__device__ __forceinline__ void put_bits(unsigned *words, int pos, unsigned val, int width)
+{
+    /* stream bit p lives in word p>>5 at bit 31-(p&31) (MSB first) */
+    if (width <= 0)
+        return;
+    val &= (width >= 32) ? 0xFFFFFFFFu : ((1u << width) - 1u);
+    const int w = pos >> 5, o = pos & 31;
+    const int room = 32 - o;
+    if (width <= room) {
+        atomicOr(&words[w], val << (room - width));
+    } else {
+        atomicOr(&words[w], val >> (width - room));
+        atomicOr(&words[w + 1], val << (32 - (width - room)));
+    }
+}
+
+/* one (sub-)block body starting at stream bit `pos`; returns its bit length */
+template <int M>
+__device__ __forceinline__ int pack_body(const PacxTables &T, unsigned *words, int *offs, int pos,
+                                         int ov, const int32_t *__restrict__ ba,
+                                         const int32_t *__restrict__ sf,
+                                         const int32_t *__restrict__ mant, int lane)
+{
+    constexpr bool SHORT = (M == PACX_M_SHORT);
+    const int nb = SHORT ? T.nb_short : T.nb_long;
+    const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
+    const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
+    const uint8_t *__restrict__ band_of = SHORT ? T.line_band_short : T.line_band_long;
+    if (lane == 0) {
+        int p = pos + T.n_scale_bits;
+        for (int b = 0; b < nb; ++b) {
+            offs[b] = p;
+            p += T.n_mant_size_bits + T.n_scale_bits + ba[b] * count[b];
+        }
+        offs[nb] = p;
+        put_bits(words, pos, (unsigned)ov, T.n_scale_bits);
+    }
+    __syncthreads();
+    if (lane < nb) {
+        const int a = ba[lane];
+        put_bits(words, offs[lane], (unsigned)(a ? a - 1 : 0), T.n_mant_size_bits);
+        put_bits(words, offs[lane] + T.n_mant_size_bits, (unsigned)sf[lane], T.n_scale_bits);
+    }
+    for (int k = lane; k < M; k += 64) {
+        const int b = band_of[k];
+        const int a = ba[b];
+        if (a)
+            put_bits(words, offs[b] + T.n_mant_size_bits + T.n_scale_bits + (k - lower[b]) * a,
+                     (unsigned)mant[k], a);
+    }
+    const int end = offs[nb];
+    __syncthreads();
+    return end - pos;
+}
+
+__global__ __launch_bounds__(64) void k_pack(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
+                                            long long n_cf, const int32_t *__restrict__ overall,
+                                            const int32_t *__restrict__ scale_factor,
+                                            const int32_t *__restrict__ bit_alloc,
+                                            const int32_t *__restrict__ mantissa,
+                                            const uint32_t *__restrict__ status,
+                                            uint8_t *__restrict__ payload, int payload_stride,
+                                            int32_t *__restrict__ n_bytes)
+{
+    __shared__ unsigned words[PACX_PACK_WORDS];
+    __shared__ int offs[PACX_MAX_BANDS + 1];
+    const int lane = threadIdx.x;
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf)
+        return;
+    const long long f = cf / n_ch;
+    const unsigned fl = flags ? flags[f] : 0u;
+    const bool is_short = (fl & 2u) != 0;
+    /* the reference drops the hop for every channel when any channel holds an
+       all-zero short sub-block (coder/pacfile.py:530-533) */
+    unsigned st = 0;
+    if (status)
+        for (int c = 0; c < n_ch; ++c)
+            st |= status[f * n_ch + c];
+    if (is_short && (st & 2u)) {
+        if (lane == 0)
+            n_bytes[cf] = 0;
+        return;
+    }
+    for (int i = lane; i < PACX_PACK_WORDS; i += 64)
+        words[i] = 0u;
+    __syncthreads();
+    if (lane == 0) {
+        put_bits(words, 0, fl & 1u, 1);
+        put_bits(words, 1, (fl >> 1) & 1u, 1);
+        put_bits(words, 2, (fl >> 2) & 1u, 1);
+    }
+    int pos = 3;
+    const int32_t *ba = bit_alloc + cf * T.band_stride;
+    const int32_t *sf = scale_factor + cf * T.band_stride;
+    const int32_t *mant = mantissa + cf * PACX_M_LONG;
+    const int32_t *ov = overall + cf * PACX_SUB;
+    if (!is_short) {
+        pos += pack_body<PACX_M_LONG>(T, words, offs, pos, ov[0], ba, sf, mant, lane);
+    } else {
+        for (int sb = 0; sb < PACX_SUB; ++sb)
+            pos += pack_body<PACX_M_SHORT>(T, words, offs, pos, ov[sb], ba + sb * T.nb_short,
+                                           sf + sb * T.nb_short, mant + sb * PACX_M_SHORT, lane);
+    }
+    /* size rule of coder/pacfile.py:552-565: body bits + 4, rounded up */
+    const int bits = (pos - 3) + 4;
+    const int nbytes = (bits + 7) >> 3;
+    unsigned *dst = (unsigned *)(payload + cf * (long long)payload_stride);
+    for (int i = lane; i < (nbytes + 3) / 4; i += 64)
+        dst[i] = __builtin_bswap32(words[i]);
+    if (lane == 0)
+        n_bytes[cf] = nbytes;
+}
+
+/* ----------------------------------------------------------- body gather */
+#define SCAN_CHUNK 1024
+
+__device__ __forceinline__ long long rec_len(int nb) { return nb > 0 ? (long long)nb + 4 : 0; }
+
+__global__ __launch_bounds__(256) void k_scan_partial(const int32_t *__restrict__ n_bytes, long long n,
+                                                     long long *__restrict__ chunk_sum)
+{
+    __shared__ long long red[256];
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
+    long long s = 0;
+    for (int i = threadIdx.x; i < SCAN_CHUNK; i += 256)
+        if (base + i < n)
+            s += rec_len(n_bytes[base + i]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        chunk_sum[blockIdx.x] = red[0];
+}
+
+__global__ void k_scan_chunks(long long *chunk_sum, long long n_chunks, long long *total)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        long long run = 0;
+        for (long long i = 0; i < n_chunks; ++i) {
+            const long long v = chunk_sum[i];
+            chunk_sum[i] = run;
+            run += v;
+        }
+        if (total)
+            *total = run;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_copy_body(const int32_t *__restrict__ n_bytes, long long n,
+                                                 const long long *__restrict__ chunk_off,
+                                                 const uint8_t *__restrict__ payload, int payload_stride,
+                                                 uint8_t *__restrict__ body, long long capacity)
+{
+    /* one wave per chunk of SCAN_CHUNK records: serial offsets inside the chunk
+       are cheap (records are ~350 bytes each) and keep the kernel simple */
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
+    long long off = chunk_off[blockIdx.x];
+    for (int i = 0; i < SCAN_CHUNK && base + i < n; ++i) {
+        const int nb = n_bytes[base + i];
+        if (nb <= 0)
+            continue;
+        if (off + nb + 4 <= capacity) {
+            const uint8_t *src = payload + (base + i) * (long long)payload_stride;
+            if (threadIdx.x < 4)
+                body[off + threadIdx.x] = (uint8_t)((unsigned)nb >> (8 * threadIdx.x));
+            for (int j = threadIdx.x; j < nb; j += 64)
+                body[off + 4 + j] = src[j];
+        }
+        off += nb + 4;
+    }
+}
+
+/* ------------------------------------------------------------- launchers */
+void pacx_launch_bitalloc(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
+                          int short_blocks, int mixed, const double *smr, int32_t *bit_alloc,
+                          uint32_t *status, hipStream_t st)
+{
+    if (n_cf <= 0)
+        return;
+    const long long threads = n_cf * PACX_SUB;
+    hipLaunchKernelGGL(k_bitalloc, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, T, flags, n_ch,
+                       n_cf, short_blocks, mixed, smr, bit_alloc, status);
+}
+
+void pacx_launch_quantize(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
+                          int short_blocks, int mixed, const double *lines, const int32_t *overall,
+                          int overall_stride, const int32_t *bit_alloc, int32_t *scale_factor,
+                          int32_t *mantissa, hipStream_t st)
+{
+    if (n_cf <= 0)
+        return;
+    if (!short_blocks || mixed)
+        hipLaunchKernelGGL((k_quantize<PACX_M_LONG>), dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch,
+                           n_cf, mixed, lines, overall, overall_stride, bit_alloc, scale_factor, mantissa);
+    if (short_blocks || mixed)
+        hipLaunchKernelGGL((k_quantize<PACX_M_SHORT>), dim3((unsigned)(n_cf * PACX_SUB)), dim3(64), 0, st, T,
+                           flags, n_ch, n_cf * PACX_SUB, mixed, lines, overall, overall_stride, bit_alloc,
+                           scale_factor, mantissa);
+}
+
+void pacx_launch_pack(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
+                      const int32_t *overall, const int32_t *scale_factor, const int32_t *bit_alloc,
+                      const int32_t *mantissa, const uint32_t *status, uint8_t *payload,
+                      int payload_stride, int32_t *n_bytes, hipStream_t st)
+{
+    if (n_cf <= 0)
+        return;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch, n_cf, overall,
+                       scale_factor, bit_alloc, mantissa, status, payload, payload_stride, n_bytes);
+}
+
+void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stride,
+                        const int32_t *n_bytes, long long *chunk_buf, uint8_t *body,
+                        long long capacity, long long *total, hipStream_t st)
+{
+    if (n_cf <= 0)
+        return;
+    const long long n_chunks = (n_cf + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)n_chunks), dim3(256), 0, st, n_bytes, n_cf, chunk_buf);
+    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(64), 0, st, chunk_buf, n_chunks, total);
+    hipLaunchKernelGGL(k_copy_body, dim3((unsigned)n_chunks), dim3(64), 0, st, n_bytes, n_cf, chunk_buf,
+                       payload, payload_stride, body, capacity);
+}

@@ -1,0 +1,577 @@
+/*
+ * pacx_api.hip -- the C ABI of include/pacx.h: handle, resident tables,
+ * grow-only workspace, argument checking, kernel sequencing on a HIP stream.
+ */
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pacx.h"
+#include "pacx_dev.h"
+
+/* kernels (k_mdct.hip, k_psy.hip, k_quant.hip) */
+void pacx_launch_mdct(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
+                      const uint8_t *flags, long long n_cf, int short_blocks, int mixed, int prewin,
+                      double *lines, int32_t *scale_out, int scale_stride, uint32_t *status,
+                      hipStream_t st);
+void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
+                      const uint8_t *flags, long long n_cf, int short_blocks, int mixed,
+                      PacxPeak *peaks, int32_t *n_peaks, hipStream_t st);
+void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
+                      int short_blocks, int mixed, const PacxPeak *peaks, const int32_t *n_peaks,
+                      const double *lines, double *smr, double *thr_out, hipStream_t st);
+void pacx_launch_bitalloc(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
+                          int short_blocks, int mixed, const double *smr, int32_t *bit_alloc,
+                          uint32_t *status, hipStream_t st);
+void pacx_launch_quantize(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
+                          int short_blocks, int mixed, const double *lines, const int32_t *overall,
+                          int overall_stride, const int32_t *bit_alloc, int32_t *scale_factor,
+                          int32_t *mantissa, hipStream_t st);
+void pacx_launch_pack(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
+                      const int32_t *overall, const int32_t *scale_factor, const int32_t *bit_alloc,
+                      const int32_t *mantissa, const uint32_t *status, uint8_t *payload,
+                      int payload_stride, int32_t *n_bytes, hipStream_t st);
+void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stride,
+                        const int32_t *n_bytes, long long *chunk_buf, uint8_t *body,
+                        long long capacity, long long *total, hipStream_t st);
+
+void pacx_launch_window(const double *win, long long n_rows, int len, const double *x, double *y,
+                        hipStream_t st);
+void pacx_launch_quant_elem(int op, long long n, const double *x, int scale, int a, int b, int64_t *out,
+                            hipStream_t st);
+void pacx_launch_bitalloc_generic(long long n, int nb, const int32_t *n_lines, const double *budget,
+                                  int max_mant, const double *smr, int32_t *bits, hipStream_t st);
+
+#define PACX_PAYLOAD_STRIDE 2192
+
+struct pacx_handle {
+    int device;
+    PacxTables T;
+    std::vector<void *> owned;        /* table allocations                      */
+    /* workspace (device), sized for ws_cf channel-frames */
+    long long ws_cf;
+    double *ws_lines;                 /* [ws_cf][1024]                          */
+    double *ws_smr;                   /* [ws_cf][band_stride]                   */
+    PacxPeak *ws_peaks;               /* [ws_cf][512]                           */
+    int32_t *ws_npeaks;               /* [ws_cf][8]                             */
+    int32_t *ws_overall;              /* [ws_cf][8]                             */
+    long long *ws_chunks;             /* [ws_cf/1024 + 1]                       */
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(pacx_handle *h, int code, const std::string &msg)
+{
+    if (h)
+        h->err = msg;
+    else
+        g_create_err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                               \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(h, PACX_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename Tp>
+static int upload(pacx_handle *h, const Tp *host, size_t n, const Tp **dev)
+{
+    void *p = nullptr;
+    HIP_TRY(h, hipMalloc(&p, n * sizeof(Tp)));
+    h->owned.push_back(p);
+    HIP_TRY(h, hipMemcpy(p, host, n * sizeof(Tp), hipMemcpyHostToDevice));
+    *dev = (const Tp *)p;
+    return PACX_OK;
+}
+
+static std::vector<double2> unit_circle(int count, long double num_mul, long double num_add, long double den)
+{
+    /* exp(-j*pi*(num_mul*i + num_add)/den), evaluated in long double */
+    std::vector<double2> t(count);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int i = 0; i < count; ++i) {
+        const long double a = pi * (num_mul * i + num_add) / den;
+        t[i].x = (double)cosl(a);
+        t[i].y = (double)(-sinl(a));
+    }
+    return t;
+}
+
+static std::vector<double> sine_window_c(int n)
+{
+    std::vector<double> w(n);
+    for (int i = 0; i < n; ++i)
+        w[i] = sin(M_PI * (i + 0.5) / n);
+    return w;
+}
+
+extern "C" int pacx_abi_version(void) { return PACX_ABI_VERSION; }
+
+extern "C" const char *pacx_last_error(const pacx_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int pacx_band_stride(const pacx_handle *h) { return h ? h->T.band_stride : PACX_E_ARG; }
+
+extern "C" int pacx_payload_stride(const pacx_handle *h) { return h ? PACX_PAYLOAD_STRIDE : PACX_E_ARG; }
+
+static int build_bands(pacx_handle *h, const int32_t *lines, int nb, int total,
+                       const int32_t **d_lower, const int32_t **d_lines, const uint8_t **d_map)
+{
+    std::vector<int32_t> lower(nb), cnt(lines, lines + nb);
+    std::vector<uint8_t> map(total);
+    int at = 0;
+    for (int b = 0; b < nb; ++b) {
+        lower[b] = at;
+        if (cnt[b] <= 0)
+            return fail(h, PACX_E_ARG, "band with no lines");
+        for (int k = 0; k < cnt[b] && at + k < total; ++k)
+            map[at + k] = (uint8_t)b;
+        at += cnt[b];
+    }
+    if (at != total)
+        return fail(h, PACX_E_ARG, "band line counts do not add up to the number of MDCT lines");
+    int rc;
+    if ((rc = upload(h, lower.data(), nb, d_lower))) return rc;
+    if ((rc = upload(h, cnt.data(), nb, d_lines))) return rc;
+    return upload(h, map.data(), total, d_map);
+}
+
+extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
+{
+    if (!cfg || !out)
+        return fail(nullptr, PACX_E_ARG, "pacx_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != PACX_ABI_VERSION)
+        return fail(nullptr, PACX_E_ARG, "pacx_create: abi_version mismatch");
+    if (cfg->n_lines_long != PACX_M_LONG || cfg->n_lines_short != PACX_M_SHORT)
+        return fail(nullptr, PACX_E_UNSUPPORTED,
+                    "pacx_create: kernels are built for nMDCTLines 1024 (long) / 128 (short)");
+    if (cfg->n_bands_long < 1 || cfg->n_bands_long > PACX_MAX_BANDS || cfg->n_bands_short < 1 ||
+        cfg->n_bands_short > 8 || !cfg->band_lines_long || !cfg->band_lines_short)
+        return fail(nullptr, PACX_E_ARG, "pacx_create: band tables missing or too large");
+    if (cfg->n_scale_bits < 1 || cfg->n_scale_bits > 4 || cfg->n_mant_size_bits < 1 ||
+        cfg->n_mant_size_bits > 16 || cfg->sample_rate <= 0)
+        return fail(nullptr, PACX_E_UNSUPPORTED, "pacx_create: nScaleBits must be 1..4, nMantSizeBits 1..16");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(nullptr, PACX_E_HIP, "pacx_create: no HIP device visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= n_dev)
+        return fail(nullptr, PACX_E_ARG, "pacx_create: device ordinal out of range");
+
+    pacx_handle *h = new pacx_handle();
+    h->device = cfg->device;
+    h->ws_cf = 0;
+    h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
+    h->ws_overall = nullptr; h->ws_chunks = nullptr;
+    memset(&h->T, 0, sizeof(h->T));
+    int rc = PACX_OK;
+#define TRY(x) do { rc = (x); if (rc) { g_create_err = h->err; pacx_destroy(h); return rc; } } while (0)
+    {
+        hipError_t e = hipSetDevice(cfg->device);
+        if (e != hipSuccess) {
+            g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+            delete h;
+            return PACX_E_HIP;
+        }
+    }
+    PacxTables &T = h->T;
+    const int NL = PACX_N_LONG, NS = PACX_N_SHORT, ML = PACX_M_LONG, MS = PACX_M_SHORT;
+    const double sr = cfg->sample_rate;
+
+    /* windows */
+    std::vector<double> wl(4 * NL), ws(NS), hl(NL), hs(NS);
+    if (cfg->win_long) {
+        memcpy(wl.data(), cfg->win_long, sizeof(double) * 4 * NL);
+    } else {
+        const std::vector<double> sl = sine_window_c(NL), ss = sine_window_c(NS);
+        const int pad = NL / 4 - NS / 4;
+        for (int i = 0; i < NL; ++i) {
+            wl[i] = sl[i];
+            double st;                                    /* start window, coder/window.py:67-69 */
+            if (i < NL / 2) st = sl[i];
+            else if (i < NL / 2 + pad) st = 1.0;
+            else if (i < NL / 2 + pad + NS / 2) st = ss[NS / 2 + (i - NL / 2 - pad)];
+            else st = 0.0;
+            wl[NL + i] = st;
+            double ssw;                                   /* start-stop, coder/window.py:88-90 */
+            if (i < pad) ssw = 0.0;
+            else if (i < pad + NS / 2) ssw = ss[i - pad];
+            else if (i < pad + NS / 2 + 2 * pad) ssw = 1.0;
+            else if (i < pad + NS + 2 * pad) ssw = ss[NS / 2 + (i - pad - NS / 2 - 2 * pad)];
+            else ssw = 0.0;
+            wl[3 * NL + i] = ssw;
+        }
+        for (int i = 0; i < NL; ++i)
+            wl[2 * NL + i] = wl[NL + (NL - 1 - i)];       /* stop = flipped start */
+    }
+    if (cfg->win_short) memcpy(ws.data(), cfg->win_short, sizeof(double) * NS);
+    else ws = sine_window_c(NS);
+    for (int i = 0; i < NL; ++i)
+        hl[i] = cfg->hann_long ? cfg->hann_long[i] : 0.5 * (1 - cos(2 * M_PI * (i + 0.5) / NL));
+    for (int i = 0; i < NS; ++i)
+        hs[i] = cfg->hann_short ? cfg->hann_short[i] : 0.5 * (1 - cos(2 * M_PI * (i + 0.5) / NS));
+    TRY(upload(h, wl.data(), wl.size(), &T.win_long));
+    TRY(upload(h, ws.data(), ws.size(), &T.win_short));
+    TRY(upload(h, hl.data(), hl.size(), &T.hann_long));
+    TRY(upload(h, hs.data(), hs.size(), &T.hann_short));
+    {
+        std::vector<double> ones(NL, 1.0);
+        TRY(upload(h, ones.data(), ones.size(), &T.ones));
+    }
+
+    /* twiddles */
+    {
+        std::vector<double2> t;
+        t = unit_circle(512, 8, 1, 8192);  TRY(upload(h, t.data(), t.size(), &T.tw_long));
+        t = unit_circle(64, 8, 1, 1024);   TRY(upload(h, t.data(), t.size(), &T.tw_short));
+        t = unit_circle(512, 2, 0, 512);   TRY(upload(h, t.data(), t.size(), &T.w512));
+        t = unit_circle(512, 2, 0, 1024);  TRY(upload(h, t.data(), t.size(), &T.w1024));
+        t = unit_circle(1025, 2, 0, 2048); TRY(upload(h, t.data(), t.size(), &T.w2048));
+        t = unit_circle(64, 2, 0, 128);    TRY(upload(h, t.data(), t.size(), &T.w128));
+        t = unit_circle(129, 2, 0, 256);   TRY(upload(h, t.data(), t.size(), &T.w256));
+    }
+
+    /* psychoacoustic tables at the MDCT line frequencies (coder/psychoac.py:183-184) */
+    {
+        std::vector<double> bl(ML), tl(ML), bs(MS), ts(MS);
+        for (int k = 0; k < ML; ++k) {
+            const double f = (sr / (2 * ML)) * (k + 0.5);
+            bl[k] = cfg->bark_long ? cfg->bark_long[k] : pacx_bark(f);
+            tl[k] = cfg->thresh_long ? cfg->thresh_long[k] : pacx_thresh_quiet(f);
+        }
+        for (int k = 0; k < MS; ++k) {
+            const double f = (sr / (2 * MS)) * (k + 0.5);
+            bs[k] = cfg->bark_short ? cfg->bark_short[k] : pacx_bark(f);
+            ts[k] = cfg->thresh_short ? cfg->thresh_short[k] : pacx_thresh_quiet(f);
+        }
+        TRY(upload(h, bl.data(), bl.size(), &T.bark_long));
+        TRY(upload(h, tl.data(), tl.size(), &T.thresh_long));
+        TRY(upload(h, bs.data(), bs.size(), &T.bark_short));
+        TRY(upload(h, ts.data(), ts.size(), &T.thresh_short));
+    }
+    /* FFT power normalisation 4/(N^2 mean(np.hanning(N)^2)) and rfftfreq step */
+    auto hanning_norm = [](int n) {
+        long double acc = 0;
+        for (int i = 0; i < n; ++i) {
+            const long double w = 0.5L - 0.5L * cosl(2.0L * 3.14159265358979323846264338327950288L * i / (n - 1));
+            acc += w * w;
+        }
+        return (double)(4.0L / ((long double)n * n * (acc / n)));
+    };
+    T.norm_long = cfg->fft_norm_long != 0.0 ? cfg->fft_norm_long : hanning_norm(NL);
+    T.norm_short = cfg->fft_norm_short != 0.0 ? cfg->fft_norm_short : hanning_norm(NS);
+    T.fstep_long = cfg->fft_freq_step_long != 0.0 ? cfg->fft_freq_step_long : 1.0 / (NL * (1.0 / sr));
+    T.fstep_short = cfg->fft_freq_step_short != 0.0 ? cfg->fft_freq_step_short : 1.0 / (NS * (1.0 / sr));
+
+    T.nb_long = cfg->n_bands_long;
+    T.nb_short = cfg->n_bands_short;
+    TRY(build_bands(h, cfg->band_lines_long, T.nb_long, ML, &T.band_lower_long, &T.band_lines_long,
+                    &T.line_band_long));
+    TRY(build_bands(h, cfg->band_lines_short, T.nb_short, MS, &T.band_lower_short, &T.band_lines_short,
+                    &T.line_band_short));
+    T.band_stride = T.nb_long > PACX_SUB * T.nb_short ? T.nb_long : PACX_SUB * T.nb_short;
+    T.n_scale_bits = cfg->n_scale_bits;
+    T.n_mant_size_bits = cfg->n_mant_size_bits;
+    T.target_bps = cfg->target_bits_per_sample;
+#undef TRY
+    *out = h;
+    return PACX_OK;
+}
+
+static void free_ws(pacx_handle *h)
+{
+    void *p[] = {h->ws_lines, h->ws_smr, h->ws_peaks, h->ws_npeaks, h->ws_overall, h->ws_chunks};
+    for (void *q : p)
+        if (q)
+            (void)hipFree(q);
+    h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
+    h->ws_overall = nullptr; h->ws_chunks = nullptr;
+    h->ws_cf = 0;
+}
+
+extern "C" void pacx_destroy(pacx_handle *h)
+{
+    if (!h)
+        return;
+    (void)hipSetDevice(h->device);
+    free_ws(h);
+    for (void *p : h->owned)
+        (void)hipFree(p);
+    delete h;
+}
+
+extern "C" int pacx_reserve(pacx_handle *h, int64_t n_cf)
+{
+    if (!h || n_cf < 0)
+        return fail(h, PACX_E_ARG, "pacx_reserve: bad argument");
+    if (n_cf <= h->ws_cf)
+        return PACX_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    free_ws(h);
+    const size_t n = (size_t)n_cf;
+    HIP_TRY(h, hipMalloc((void **)&h->ws_lines, n * PACX_M_LONG * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_smr, n * h->T.band_stride * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_peaks, n * PACX_MAX_PEAKS * sizeof(PacxPeak)));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_npeaks, n * PACX_SUB * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_overall, n * PACX_SUB * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_chunks, (n / 1024 + 2) * sizeof(long long)));
+    h->ws_cf = n_cf;
+    return PACX_OK;
+}
+
+/* validate a pcm view; fills the device-side view and the fast-path flag */
+static int check_pcm(pacx_handle *h, const pacx_pcm *in, PacxPcmView *v, int *fast, long long *n_cf)
+{
+    if (!in || !in->data)
+        return fail(h, PACX_E_ARG, "pcm view or data pointer is null");
+    if (in->dtype != PACX_PCM_I16 && in->dtype != PACX_PCM_F64)
+        return fail(h, PACX_E_ARG, "pcm dtype must be PACX_PCM_I16 or PACX_PCM_F64");
+    if (in->n_channels < 1 || in->n_frames < 0 || in->sample_stride < 1 || in->frame_stride < 0 ||
+        in->channel_stride < 0)
+        return fail(h, PACX_E_ARG, "pcm view: bad channel count, frame count or stride");
+    if (in->n_frames * in->n_channels > 0x7fffffffLL / PACX_SUB)
+        return fail(h, PACX_E_ARG, "pcm view: too many channel-frames for one call");
+    v->base = in->data;
+    v->frame_stride = in->frame_stride;
+    v->ch_stride = in->channel_stride;
+    v->samp_stride = in->sample_stride;
+    v->n_ch = in->n_channels;
+    *fast = (in->dtype == PACX_PCM_I16 && in->sample_stride == 1 && ((uintptr_t)in->data % 16) == 0 &&
+             in->frame_stride % 8 == 0 && in->channel_stride % 8 == 0);
+    *n_cf = in->n_frames * in->n_channels;
+    return PACX_OK;
+}
+
+static int post_launch(pacx_handle *h, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(h, PACX_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return PACX_OK;
+}
+
+extern "C" int pacx_mdct_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
+                               int mode, double *lines, int32_t *max_scale, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    PacxPcmView v;
+    int fast;
+    long long n_cf;
+    int rc = check_pcm(h, in, &v, &fast, &n_cf);
+    if (rc)
+        return rc;
+    if (!lines)
+        return fail(h, PACX_E_ARG, "pacx_mdct_batch: lines is null");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int short_blocks = (mode & PACX_MDCT_SHORT) ? 1 : 0;
+    pacx_launch_mdct(h->T, v, in->dtype, fast, frame_flags, n_cf, short_blocks, 0,
+                     (mode & PACX_MDCT_PREWINDOWED) ? 1 : 0, lines, max_scale,
+                     short_blocks ? PACX_SUB : 1, nullptr, (hipStream_t)stream);
+    return post_launch(h, "pacx_mdct_batch");
+}
+
+extern "C" int pacx_smr_batch(pacx_handle *h, const pacx_pcm *in, const double *lines, int short_blocks,
+                              double *smr, double *threshold, int32_t *n_peaks, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    PacxPcmView v;
+    int fast;
+    long long n_cf;
+    int rc = check_pcm(h, in, &v, &fast, &n_cf);
+    if (rc)
+        return rc;
+    if (!lines || !smr)
+        return fail(h, PACX_E_ARG, "pacx_smr_batch: lines or smr is null");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((rc = pacx_reserve(h, n_cf)))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int sb = short_blocks ? 1 : 0;
+    pacx_launch_side(h->T, v, in->dtype, fast, nullptr, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, st);
+    pacx_launch_mask(h->T, nullptr, in->n_channels, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, lines, smr,
+                     threshold, st);
+    if (n_peaks) {
+        if (sb)
+            HIP_TRY(h, hipMemcpyAsync(n_peaks, h->ws_npeaks, (size_t)n_cf * PACX_SUB * sizeof(int32_t),
+                                      hipMemcpyDeviceToDevice, st));
+        else
+            HIP_TRY(h, hipMemcpy2DAsync(n_peaks, sizeof(int32_t), h->ws_npeaks, PACX_SUB * sizeof(int32_t),
+                                        sizeof(int32_t), (size_t)n_cf, hipMemcpyDeviceToDevice, st));
+    }
+    return post_launch(h, "pacx_smr_batch");
+}
+
+extern "C" int pacx_bitalloc_batch(pacx_handle *h, int64_t n_cf, int n_channels, const uint8_t *frame_flags,
+                                   int short_blocks, const double *smr, int32_t *bit_alloc,
+                                   uint32_t *status, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_cf < 0 || n_channels < 1 || !smr || !bit_alloc)
+        return fail(h, PACX_E_ARG, "pacx_bitalloc_batch: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_bitalloc(h->T, frame_flags, n_channels, n_cf, short_blocks ? 1 : 0, 0, smr, bit_alloc, status,
+                         (hipStream_t)stream);
+    return post_launch(h, "pacx_bitalloc_batch");
+}
+
+extern "C" int pacx_quantize_batch(pacx_handle *h, int64_t n_cf, const double *lines,
+                                   const int32_t *overall_scale, const int32_t *bit_alloc, int short_blocks,
+                                   int32_t *scale_factor, int32_t *mantissa, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_cf < 0 || !lines || !overall_scale || !bit_alloc || !scale_factor || !mantissa)
+        return fail(h, PACX_E_ARG, "pacx_quantize_batch: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_quantize(h->T, nullptr, 1, n_cf, short_blocks ? 1 : 0, 0, lines, overall_scale,
+                         short_blocks ? PACX_SUB : 1, bit_alloc, scale_factor, mantissa, (hipStream_t)stream);
+    return post_launch(h, "pacx_quantize_batch");
+}
+
+extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
+                                 int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,
+                                 int32_t *mantissa, uint32_t *status, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    PacxPcmView v;
+    int fast;
+    long long n_cf;
+    int rc = check_pcm(h, in, &v, &fast, &n_cf);
+    if (rc)
+        return rc;
+    if (!overall_scale || !scale_factor || !bit_alloc || !mantissa || !status)
+        return fail(h, PACX_E_ARG, "pacx_encode_batch: null output pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((rc = pacx_reserve(h, n_cf)))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const PacxTables &T = h->T;
+    const int mixed = frame_flags ? 1 : 0;     /* without flags every frame is a long sine block */
+    const int n_ch = in->n_channels;
+    HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
+    HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
+    pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
+                     PACX_SUB, status, st);
+    pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, st);
+    pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_lines, h->ws_smr,
+                     nullptr, st);
+    pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_smr, bit_alloc, status, st);
+    pacx_launch_quantize(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_lines, overall_scale, PACX_SUB, bit_alloc,
+                         scale_factor, mantissa, st);
+    return post_launch(h, "pacx_encode_batch");
+}
+
+extern "C" int pacx_pack_batch(pacx_handle *h, int64_t n_cf, int n_channels, const uint8_t *frame_flags,
+                               const int32_t *overall_scale, const int32_t *scale_factor,
+                               const int32_t *bit_alloc, const int32_t *mantissa, const uint32_t *status,
+                               uint8_t *payload, int32_t *n_bytes, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_cf < 0 || n_channels < 1 || !overall_scale || !scale_factor || !bit_alloc || !mantissa || !payload ||
+        !n_bytes)
+        return fail(h, PACX_E_ARG, "pacx_pack_batch: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_pack(h->T, frame_flags, n_channels, n_cf, overall_scale, scale_factor, bit_alloc, mantissa,
+                     status, payload, PACX_PAYLOAD_STRIDE, n_bytes, (hipStream_t)stream);
+    return post_launch(h, "pacx_pack_batch");
+}
+
+extern "C" int pacx_gather_body(pacx_handle *h, int64_t n_cf, const uint8_t *payload, const int32_t *n_bytes,
+                                uint8_t *body, int64_t body_capacity, int64_t *total_bytes, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_cf < 0 || !payload || !n_bytes || !body || body_capacity < 0)
+        return fail(h, PACX_E_ARG, "pacx_gather_body: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = pacx_reserve(h, n_cf);
+    if (rc)
+        return rc;
+    pacx_launch_gather(n_cf, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_chunks, body, body_capacity,
+                       (long long *)total_bytes, (hipStream_t)stream);
+    return post_launch(h, "pacx_gather_body");
+}
+
+/* ---- function-level entry points (k_misc.hip) --------------------------- */
+extern "C" int pacx_window_batch(pacx_handle *h, int window, int64_t n_rows, const double *x, double *y,
+                                 void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_rows < 0 || !x || !y)
+        return fail(h, PACX_E_ARG, "pacx_window_batch: bad argument");
+    const double *w;
+    int len;
+    switch (window) {
+    case PACX_WIN_SINE: case PACX_WIN_START: case PACX_WIN_STOP: case PACX_WIN_STARTSTOP:
+        w = h->T.win_long + window * PACX_N_LONG; len = PACX_N_LONG; break;
+    case PACX_WIN_SINE_SHORT: w = h->T.win_short; len = PACX_N_SHORT; break;
+    case PACX_WIN_HANN: w = h->T.hann_long; len = PACX_N_LONG; break;
+    case PACX_WIN_HANN_SHORT: w = h->T.hann_short; len = PACX_N_SHORT; break;
+    default: return fail(h, PACX_E_ARG, "pacx_window_batch: unknown window");
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_window(w, n_rows, len, x, y, (hipStream_t)stream);
+    return post_launch(h, "pacx_window_batch");
+}
+
+static int quant_elem(pacx_handle *h, int op, int64_t n, const double *x, int scale, int a, int b,
+                      int64_t *out, void *stream, const char *what)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n < 0 || !x || !out)
+        return fail(h, PACX_E_ARG, std::string(what) + ": bad argument");
+    const int r_bits = (op == 0) ? a : ((1 << a) - 1 + b);
+    if (a < 1 || b < 0 || r_bits < 1 || r_bits > 62 || (op == 2 && b < 1))
+        return fail(h, PACX_E_UNSUPPORTED, std::string(what) + ": bit widths out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_quant_elem(op, n, x, scale, a, b, out, (hipStream_t)stream);
+    return post_launch(h, what);
+}
+
+extern "C" int pacx_quantize_uniform(pacx_handle *h, int64_t n, const double *x, int n_bits, int64_t *codes,
+                                     void *stream)
+{
+    return quant_elem(h, 0, n, x, 0, n_bits, 0, codes, stream, "pacx_quantize_uniform");
+}
+
+extern "C" int pacx_scale_factor(pacx_handle *h, int64_t n, const double *x, int n_scale_bits,
+                                 int n_mant_bits, int64_t *scale, void *stream)
+{
+    return quant_elem(h, 1, n, x, 0, n_scale_bits, n_mant_bits, scale, stream, "pacx_scale_factor");
+}
+
+extern "C" int pacx_mantissa(pacx_handle *h, int64_t n, const double *x, int scale, int n_scale_bits,
+                             int n_mant_bits, int64_t *mantissa, void *stream)
+{
+    return quant_elem(h, 2, n, x, scale, n_scale_bits, n_mant_bits, mantissa, stream, "pacx_mantissa");
+}
+
+extern "C" int pacx_bitalloc_generic(pacx_handle *h, int64_t n, int n_bands, const int32_t *band_lines,
+                                     const double *budget, int max_mant_bits, const double *smr,
+                                     int32_t *bit_alloc, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n < 0 || n_bands < 1 || n_bands > PACX_MAX_BANDS || !band_lines || !budget || !smr || !bit_alloc)
+        return fail(h, PACX_E_ARG, "pacx_bitalloc_generic: bad argument (at most 32 bands)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_bitalloc_generic(n, n_bands, band_lines, budget, max_mant_bits, smr, bit_alloc,
+                                 (hipStream_t)stream);
+    return post_launch(h, "pacx_bitalloc_generic");
+}

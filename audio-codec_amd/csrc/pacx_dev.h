@@ -1,0 +1,61 @@
+/*
+ * pacx_dev.h -- device-side views shared by the kernels and the C-ABI layer.
+ */
+#ifndef PACX_DEV_H
+#define PACX_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pacx_exact.h"
+
+#define PACX_N_LONG 2048      /* window length of a long block               */
+#define PACX_M_LONG 1024      /* MDCT lines of a long block (nMDCTLines)      */
+#define PACX_N_SHORT 256
+#define PACX_M_SHORT 128
+#define PACX_SUB 8            /* short sub-blocks per frame                   */
+#define PACX_SHORT_FIRST 448  /* first sub-block starts here (long/2-short/2) */
+#define PACX_MAX_PEAKS 512    /* strict local maxima of 1025 bins             */
+
+/* Tables resident in HBM for the life of a handle (all float64 / complex128). */
+struct PacxTables {
+    const double *win_long;     /* [4][2048]                                  */
+    const double *win_short;    /* [256]                                      */
+    const double *hann_long;    /* [2048]                                     */
+    const double *hann_short;   /* [256]                                      */
+    const double *ones;         /* [2048] of 1.0: MDCT of pre-windowed data     */
+    const double2 *tw_long;     /* exp(-j pi (8n+1)/8192), n < 512            */
+    const double2 *tw_short;    /* exp(-j pi (8n+1)/1024), n < 64             */
+    const double2 *w512;        /* exp(-2 pi j m/512),  m < 512               */
+    const double2 *w1024;       /* exp(-2 pi j k/1024), k < 512               */
+    const double2 *w2048;       /* exp(-2 pi j k/2048), k <= 1024             */
+    const double2 *w128;        /* exp(-2 pi j k/128),  k < 64                */
+    const double2 *w256;        /* exp(-2 pi j k/256),  k <= 128              */
+    const double *bark_long, *thresh_long;      /* [1024]                     */
+    const double *bark_short, *thresh_short;    /* [128]                      */
+    const int32_t *band_lower_long, *band_lines_long;     /* [nb_long]        */
+    const int32_t *band_lower_short, *band_lines_short;   /* [nb_short]       */
+    const uint8_t *line_band_long;   /* [1024] band of each line              */
+    const uint8_t *line_band_short;  /* [128]                                 */
+    double norm_long, norm_short;    /* 4/(N^2 mean(hanning^2))               */
+    double fstep_long, fstep_short;  /* rfftfreq step                         */
+    double target_bps;
+    int nb_long, nb_short;
+    int n_scale_bits, n_mant_size_bits;
+    int band_stride;
+};
+
+struct PacxPcmView {
+    const void *base;
+    long long frame_stride, ch_stride, samp_stride;
+    int n_ch;
+};
+
+/* one peak (tonal masker) as the mask kernel consumes it */
+struct __attribute__((aligned(8))) PacxPeak {
+    double z;       /* Bark of the energy-weighted frequency                  */
+    double spl;     /* SPL of the two-bin energy                              */
+    double slope;   /* -27 + 0.367*max(spl-40,0): upper-side slope, dB/Bark   */
+};
+
+#endif

@@ -1,0 +1,138 @@
+/*
+ * wave_fft.h -- FP64 complex FFTs held in the registers of ONE wave64.
+ *
+ * Built for the gfx950 execution model: 64 lanes x 8 complex values per lane,
+ * radix-8 butterflies done in registers, data moved between lanes through a
+ * per-wave LDS tile (one b128 write + one b128 read per value and exchange).
+ * tools/proto_wave_fft.py is the lane-level NumPy model of exactly this
+ * index math.
+ *
+ *   fft64x8 : eight independent 64-point FFTs, one per 8-lane group
+ *             (short blocks: one sub-block per group)
+ *   fft512  : one 512-point FFT = radix-8 pass + cross-lane exchange + fft64x8
+ *
+ * LDS tile: 8 rows x 72 complex (rows padded by 8 so that the column gather of
+ * exchange 1 is bank-conflict free for ds_read_b128; exchange 2 stays inside an
+ * 8-lane group and uses an XOR swizzle inside the row).
+ *
+ * Compiled with -ffp-contract=off: fused multiply-adds are written out.
+ */
+#ifndef PACX_WAVE_FFT_H
+#define PACX_WAVE_FFT_H
+
+#include <hip/hip_runtime.h>
+
+#define WFFT_ROW 72                 /* complex values per padded row          */
+#define WFFT_TILE (8 * WFFT_ROW)    /* complex values per wave tile (9216 B)  */
+
+typedef double2 cplx;
+
+__device__ __forceinline__ cplx c_add(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx c_sub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+/* a * b with two FMAs */
+__device__ __forceinline__ cplx c_mul(cplx a, cplx b)
+{
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+/* a * (-j) */
+__device__ __forceinline__ cplx c_mul_mj(cplx a) { return make_double2(a.y, -a.x); }
+
+/* LDS ordering inside one wave: DS instructions of a wave execute in order, so
+ * only the compiler has to be kept from moving a lane's read above the store
+ * that another lane's value comes from. */
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* forward 8-point DFT in place: v[k] = sum_n v[n] exp(-2 pi i n k / 8) */
+__device__ __forceinline__ void dft8(cplx v[8])
+{
+    const double h = 0.70710678118654752440;   /* sqrt(1/2) */
+    cplx b0 = c_add(v[0], v[4]), c0 = c_sub(v[0], v[4]);
+    cplx b1 = c_add(v[1], v[5]), c1 = c_sub(v[1], v[5]);
+    cplx b2 = c_add(v[2], v[6]), c2 = c_sub(v[2], v[6]);
+    cplx b3 = c_add(v[3], v[7]), c3 = c_sub(v[3], v[7]);
+    /* odd half: c_n * W8^n */
+    c1 = make_double2((c1.x + c1.y) * h, (c1.y - c1.x) * h);
+    c2 = c_mul_mj(c2);
+    c3 = make_double2((c3.y - c3.x) * h, -((c3.x + c3.y) * h));
+    /* 4-point DFTs */
+    cplx e0 = c_add(b0, b2), e1 = c_sub(b0, b2);
+    cplx f0 = c_add(b1, b3), f1 = c_mul_mj(c_sub(b1, b3));
+    v[0] = c_add(e0, f0);
+    v[2] = c_add(e1, f1);
+    v[4] = c_sub(e0, f0);
+    v[6] = c_sub(e1, f1);
+    cplx g0 = c_add(c0, c2), g1 = c_sub(c0, c2);
+    cplx h0 = c_add(c1, c3), h1 = c_mul_mj(c_sub(c1, c3));
+    v[1] = c_add(g0, h0);
+    v[3] = c_add(g1, h1);
+    v[5] = c_sub(g0, h0);
+    v[7] = c_sub(g1, h1);
+}
+
+/*
+ * Eight 64-point FFTs.  lane = 8*g + r.
+ *   in : v[j]  = x_g[r + 8 j]
+ *   out: v[k3] = X_g[r + 8 k3]
+ * w512: table exp(-2 pi i m / 512), m < 512 (W64^q = w512[8 q]).
+ */
+__device__ __forceinline__ void fft64x8(cplx v[8], cplx *tile, const cplx *__restrict__ w512, int lane)
+{
+    const int g = lane >> 3, r = lane & 7;
+    dft8(v);
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2)
+        v[k2] = c_mul(v[k2], w512[8 * r * k2]);
+    cplx *row = tile + g * WFFT_ROW;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2)
+        row[8 * k2 + (r ^ k2)] = v[k2];
+    wave_lds_fence();
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3)
+        v[n3] = row[8 * r + (n3 ^ r)];
+    wave_lds_fence();
+    dft8(v);
+}
+
+/*
+ * One 512-point FFT.
+ *   in : v[n1] = x[lane + 64 n1]
+ *   out: v[k3] = X[g + 8 r + 64 k3]   with g = lane>>3, r = lane&7
+ */
+__device__ __forceinline__ void fft512(cplx v[8], cplx *tile, const cplx *__restrict__ w512, int lane)
+{
+    dft8(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1)
+        v[k1] = c_mul(v[k1], w512[lane * k1]);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1)
+        tile[k1 * WFFT_ROW + lane] = v[k1];
+    wave_lds_fence();
+    const int g = lane >> 3, r = lane & 7;
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2)
+        v[n2] = tile[g * WFFT_ROW + 8 * n2 + r];
+    wave_lds_fence();
+    fft64x8(v, tile, w512, lane);
+}
+
+/* index of the value held in register k3 after fft512 */
+__device__ __forceinline__ int fft512_out_index(int lane, int k3) { return (lane >> 3) + 8 * (lane & 7) + 64 * k3; }
+/* index (inside the group) of the value held in register k3 after fft64x8 */
+__device__ __forceinline__ int fft64_out_index(int lane, int k3) { return (lane & 7) + 8 * k3; }
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+#endif

@@ -1,0 +1,290 @@
+"""Batched encode engine: owns one pacx handle (HIP library, include/pacx.h) and
+runs the per-frame hot path of codec.Encode for thousands of channel-frames per
+launch.  PyTorch is used for device memory and streams only.
+
+Reference path replaced: coder/codec.py:225-380 (Encode/EncodeSingleChannel)
+and the window/mdct/psychoac/bitalloc/quantize functions it calls.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, tables
+from .psychoac import ScaleFactorBands, AssignMDCTLinesFromFreqLimits
+
+N_LONG, N_SHORT = 1024, 128          # MDCT lines of long / short blocks
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class PcmView:
+    """Strided view of PCM on the device (see pacx_pcm in include/pacx.h)."""
+
+    def __init__(self, tensor, n_channels, n_frames, frame_stride, channel_stride,
+                 sample_stride=1):
+        if tensor.dtype == torch.int16:
+            dt = _lib.PCM_I16
+        elif tensor.dtype == torch.float64:
+            dt = _lib.PCM_F64
+        else:
+            raise TypeError("PCM must be int16 codes or float64 signed fractions")
+        if not tensor.is_cuda:
+            raise ValueError("PCM tensor must live on the GPU")
+        self.tensor = tensor                      # keeps the memory alive
+        self.n_channels, self.n_frames = int(n_channels), int(n_frames)
+        self.c = _lib.PacxPcm(tensor.data_ptr(), dt, self.n_channels, self.n_frames,
+                              int(frame_stride), int(channel_stride), int(sample_stride))
+
+    @property
+    def n_cf(self):
+        return self.n_channels * self.n_frames
+
+    @staticmethod
+    def stream(planar, hop=N_LONG):
+        """planar: [n_ch, (n_hops+1)*hop] -- hop 0 is the prior block (zeros at
+        the start of a file); frame f spans hops f, f+1 (coder/pacfile.py:460-464)."""
+        n_ch, n = planar.shape
+        assert planar.is_contiguous() and n % hop == 0 and n >= 2 * hop
+        return PcmView(planar, n_ch, n // hop - 1, hop, n, 1)
+
+    @staticmethod
+    def frames(blocks):
+        """blocks: [n_frames, n_ch, 2*hop] independent full blocks."""
+        n_f, n_ch, n = blocks.shape
+        assert blocks.is_contiguous()
+        return PcmView(blocks, n_ch, n_f, n_ch * n, n, 1)
+
+
+class Encoder:
+    """One handle = one (sampleRate, bit rate, band layout) on one GPU."""
+
+    def __init__(self, sample_rate, target_bits_per_sample, n_scale_bits=4, n_mant_size_bits=12,
+                 sf_bands=None, sf_bands_short=None, device=None, n_mdct_lines=N_LONG):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.PacxError("no GPU visible: the encode path has no CPU implementation")
+        if n_mdct_lines != N_LONG:
+            raise _lib.PacxError("kernels are built for nMDCTLines = 1024")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.sample_rate = int(sample_rate)
+        self.target_bits_per_sample = float(target_bits_per_sample)
+        self.n_scale_bits, self.n_mant_size_bits = int(n_scale_bits), int(n_mant_size_bits)
+        self.sfBands = sf_bands or ScaleFactorBands(
+            AssignMDCTLinesFromFreqLimits(N_LONG, self.sample_rate))
+        self.sfBandsShort = sf_bands_short or ScaleFactorBands(
+            AssignMDCTLinesFromFreqLimits(N_SHORT, self.sample_rate))
+
+        keep = self._host = {}
+        def f64(name, arr):
+            keep[name] = np.ascontiguousarray(arr, dtype=np.float64)
+            return keep[name].ctypes.data_as(_lib.c_double_p)
+        def i32(name, arr):
+            keep[name] = np.ascontiguousarray(arr, dtype=np.int32)
+            return keep[name].ctypes.data_as(_lib.c_int32_p)
+        sr = self.sample_rate
+        cfg = _lib.PacxConfig()
+        cfg.abi_version = _lib.PACX_ABI_VERSION
+        cfg.device = self.device.index
+        cfg.sample_rate = sr
+        cfg.n_lines_long, cfg.n_lines_short = N_LONG, N_SHORT
+        cfg.n_scale_bits, cfg.n_mant_size_bits = self.n_scale_bits, self.n_mant_size_bits
+        cfg.n_bands_long, cfg.n_bands_short = self.sfBands.nBands, self.sfBandsShort.nBands
+        cfg.target_bits_per_sample = self.target_bits_per_sample
+        cfg.band_lines_long = i32("bl", self.sfBands.nLines)
+        cfg.band_lines_short = i32("bs", self.sfBandsShort.nLines)
+        cfg.win_long = f64("wl", tables.long_windows(2 * N_LONG))
+        cfg.win_short = f64("ws", tables.sine(2 * N_SHORT))
+        cfg.hann_long = f64("hl", tables.hann(2 * N_LONG))
+        cfg.hann_short = f64("hs", tables.hann(2 * N_SHORT))
+        cfg.bark_long = f64("zl", tables.bark(tables.line_freqs(N_LONG, sr)))
+        cfg.thresh_long = f64("tl", tables.thresh(tables.line_freqs(N_LONG, sr)))
+        cfg.bark_short = f64("zs", tables.bark(tables.line_freqs(N_SHORT, sr)))
+        cfg.thresh_short = f64("ts", tables.thresh(tables.line_freqs(N_SHORT, sr)))
+        cfg.fft_norm_long = tables.fft_norm(2 * N_LONG)
+        cfg.fft_norm_short = tables.fft_norm(2 * N_SHORT)
+        cfg.fft_freq_step_long = tables.fft_freq_step(2 * N_LONG, sr)
+        cfg.fft_freq_step_short = tables.fft_freq_step(2 * N_SHORT, sr)
+        h = ctypes.c_void_p()
+        rc = self.lib.pacx_create(ctypes.byref(cfg), ctypes.byref(h))
+        _lib.check(self.lib, None, rc, "pacx_create")
+        self.h = h
+        self.band_stride = self.lib.pacx_band_stride(h)
+        self.payload_stride = self.lib.pacx_payload_stride(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pacx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ----------------------------------------------------------------- helpers
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(self.h, *args)
+        _lib.check(self.lib, self.h, rc, name)
+
+    def reserve(self, n_cf):
+        self._call("pacx_reserve", ctypes.c_int64(int(n_cf)))
+
+    def flags_tensor(self, flags, n_frames):
+        """flags: None, or per-frame iterable of (last, cur, next) / packed uint8."""
+        if flags is None:
+            return None
+        if isinstance(flags, torch.Tensor):
+            t = flags.to(device=self.device, dtype=torch.uint8)
+        else:
+            a = np.asarray(flags)
+            if a.ndim == 2:
+                a = (a[:, 0] != 0) * 1 + (a[:, 1] != 0) * 2 + (a[:, 2] != 0) * 4
+            t = torch.as_tensor(a.astype(np.uint8), device=self.device)
+        assert t.numel() == n_frames
+        return t.contiguous()
+
+    # ------------------------------------------------------------------ stages
+    def mdct(self, pcm, flags=None, short=False, want_scale=False, prewindowed=False):
+        """window + MDCT (+ overall scale factor).  lines: [n_cf, 1024] float64
+        (short: [n_cf, 8, 128])."""
+        fl = self.flags_tensor(flags, pcm.n_frames)
+        lines = self._empty((pcm.n_cf, N_LONG), torch.float64)
+        scale = self._empty((pcm.n_cf, _lib.SUB) if short else (pcm.n_cf,), torch.int32) \
+            if want_scale else None
+        mode = (_lib.MDCT_SHORT if short else 0) | (_lib.MDCT_PREWINDOWED if prewindowed else 0)
+        self._call("pacx_mdct_batch", ctypes.byref(pcm.c), _ptr(fl), mode, _ptr(lines),
+                   _ptr(scale), self._stream())
+        if short:
+            lines = lines.view(pcm.n_cf, _lib.SUB, N_SHORT)
+        return (lines, scale) if want_scale else lines
+
+    def smr(self, pcm, lines, short=False, want_threshold=False, want_peaks=False):
+        """CalcSMRs.  lines are the unscaled MDCT lines.  smr: [n_cf, band_stride]."""
+        lines = lines.contiguous().view(pcm.n_cf, N_LONG)
+        smr = torch.zeros((pcm.n_cf, self.band_stride), dtype=torch.float64, device=self.device)
+        thr = self._empty((pcm.n_cf, N_LONG), torch.float64) if want_threshold else None
+        npk = self._empty((pcm.n_cf, _lib.SUB) if short else (pcm.n_cf,), torch.int32) \
+            if want_peaks else None
+        self._call("pacx_smr_batch", ctypes.byref(pcm.c), _ptr(lines), int(bool(short)), _ptr(smr),
+                   _ptr(thr), _ptr(npk), self._stream())
+        out = [smr]
+        if want_threshold:
+            out.append(thr)
+        if want_peaks:
+            out.append(npk)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def bit_alloc(self, smr, n_channels=1, flags=None, short=False):
+        smr = smr.contiguous()
+        n_cf = smr.shape[0]
+        fl = self.flags_tensor(flags, n_cf // n_channels)
+        ba = torch.zeros((n_cf, self.band_stride), dtype=torch.int32, device=self.device)
+        status = torch.zeros((n_cf,), dtype=torch.int32, device=self.device)
+        self._call("pacx_bitalloc_batch", ctypes.c_int64(n_cf), int(n_channels), _ptr(fl),
+                   int(bool(short)), _ptr(smr), _ptr(ba), _ptr(status), self._stream())
+        return ba, status
+
+    def quantize(self, lines, overall_scale, bit_alloc, short=False):
+        n_cf = bit_alloc.shape[0]
+        lines = lines.contiguous().view(n_cf, N_LONG)
+        sf = torch.zeros((n_cf, self.band_stride), dtype=torch.int32, device=self.device)
+        mant = self._empty((n_cf, N_LONG), torch.int32)
+        self._call("pacx_quantize_batch", ctypes.c_int64(n_cf), _ptr(lines),
+                   _ptr(overall_scale.contiguous()), _ptr(bit_alloc.contiguous()), int(bool(short)),
+                   _ptr(sf), _ptr(mant), self._stream())
+        return sf, mant
+
+    # -------------------------------------------------------------- whole path
+    def encode(self, pcm, flags=None, out=None):
+        """codec.Encode for every channel of every frame of `pcm`.
+        Returns dict of device tensors: overall [n_cf,8], scale_factor / bit_alloc
+        [n_cf, band_stride], mantissa [n_cf,1024] (line-indexed), status [n_cf]."""
+        n_cf = pcm.n_cf
+        fl = self.flags_tensor(flags, pcm.n_frames)
+        if out is None:
+            out = self.alloc_outputs(n_cf)
+        self._call("pacx_encode_batch", ctypes.byref(pcm.c), _ptr(fl), _ptr(out["overall"]),
+                   _ptr(out["scale_factor"]), _ptr(out["bit_alloc"]), _ptr(out["mantissa"]),
+                   _ptr(out["status"]), self._stream())
+        out["flags"] = fl
+        return out
+
+    def alloc_outputs(self, n_cf, with_payload=False):
+        o = {
+            "overall": self._empty((n_cf, _lib.SUB), torch.int32),
+            "scale_factor": torch.zeros((n_cf, self.band_stride), dtype=torch.int32, device=self.device),
+            "bit_alloc": torch.zeros((n_cf, self.band_stride), dtype=torch.int32, device=self.device),
+            "mantissa": self._empty((n_cf, N_LONG), torch.int32),
+            "status": self._empty((n_cf,), torch.int32),
+        }
+        if with_payload:
+            o["payload"] = self._empty((n_cf, self.payload_stride), torch.uint8)
+            o["n_bytes"] = self._empty((n_cf,), torch.int32)
+        return o
+
+    def pack(self, enc, n_channels, out=None):
+        """.pac payload of every cf: payload [n_cf, payload_stride] uint8, n_bytes [n_cf]."""
+        n_cf = enc["bit_alloc"].shape[0]
+        payload = out["payload"] if out else self._empty((n_cf, self.payload_stride), torch.uint8)
+        n_bytes = out["n_bytes"] if out else self._empty((n_cf,), torch.int32)
+        self._call("pacx_pack_batch", ctypes.c_int64(n_cf), int(n_channels), _ptr(enc.get("flags")),
+                   _ptr(enc["overall"]), _ptr(enc["scale_factor"]), _ptr(enc["bit_alloc"]),
+                   _ptr(enc["mantissa"]), _ptr(enc["status"]), _ptr(payload), _ptr(n_bytes),
+                   self._stream())
+        return payload, n_bytes
+
+    def gather_body(self, payload, n_bytes, capacity=None):
+        """'<L nBytes' + payload of every cf, back to back (the .pac body)."""
+        n_cf = n_bytes.shape[0]
+        if capacity is None:
+            capacity = n_cf * (self.payload_stride + 4)
+        body = self._empty((capacity,), torch.uint8)
+        total = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        self._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(payload), _ptr(n_bytes), _ptr(body),
+                   ctypes.c_int64(capacity), _ptr(total), self._stream())
+        return body, total
+
+    # ------------------------------------------- function-level entry points
+    def window(self, kind, x):
+        """window * x for rows of x ([n, 2048] or [n, 256] float64 on the GPU)."""
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        self._call("pacx_window_batch", int(kind), ctypes.c_int64(x.shape[0]), _ptr(x), _ptr(y),
+                   self._stream())
+        return y
+
+    def _elem(self, name, x, *ints):
+        x = x.contiguous()
+        out = self._empty(x.shape, torch.int64)
+        self._call(name, ctypes.c_int64(x.numel()), _ptr(x), *[int(i) for i in ints], _ptr(out),
+                   self._stream())
+        return out
+
+    def quantize_uniform(self, x, n_bits):
+        return self._elem("pacx_quantize_uniform", x, n_bits)
+
+    def scale_factor(self, x, n_scale_bits, n_mant_bits):
+        return self._elem("pacx_scale_factor", x, n_scale_bits, n_mant_bits)
+
+    def mantissa(self, x, scale, n_scale_bits, n_mant_bits):
+        return self._elem("pacx_mantissa", x, scale, n_scale_bits, n_mant_bits)
+
+    def bit_alloc_generic(self, budget, max_mant_bits, n_lines, smr):
+        """BitAlloc for rows of smr [n, nBands] with per-row budgets [n]."""
+        smr = smr.contiguous()
+        n, nb = smr.shape
+        nl = torch.as_tensor(np.asarray(n_lines, dtype=np.int32), device=self.device)
+        bits = self._empty((n, nb), torch.int32)
+        self._call("pacx_bitalloc_generic", ctypes.c_int64(n), int(nb), _ptr(nl), _ptr(budget.contiguous()),
+                   int(max_mant_bits), _ptr(smr), _ptr(bits), self._stream())
+        return bits

@@ -1,0 +1,140 @@
+"""pacfile.py mirror (coder/pacfile.py): the .pac block API in front of the GPU
+path, scalar-mantissa coder (useVQ False, useSBR False).
+
+  PACFile.WriteFileHeader / WriteDataBlock / Close / Encode keep the
+  reference's signatures and write the same bytes (one GPU call per block:
+  drop-in, not fast);
+  encode_stream() is the batched path: every hop of a stream in one
+  pacx_encode_batch + pacx_pack_batch + pacx_gather_body.
+"""
+from struct import pack
+
+import numpy as np
+
+from . import codec, context
+from .audiofile import AudioFile
+from .detect_transients import hop_transients
+from .engine import PcmView
+from .pcmfile import codes_to_fraction
+from .psychoac import AssignMDCTLinesFromFreqLimits, ScaleFactorBands
+
+BYTESIZE = 8
+
+
+def omitted_bands(sfBands, factor=2):
+    """coder/sbr.py:6-9 (only recorded in codingParams; SBR itself is not accelerated)."""
+    return np.where(sfBands.lowerLine >= sfBands.upperLine[-1] // factor)[0]
+
+
+def header_bytes(cp):
+    """coder/pacfile.py:306-333 (mutates cp.numSamples exactly as the reference does)."""
+    if not cp.numSamples % cp.nMDCTLines:
+        cp.numSamples += cp.nMDCTLines - cp.numSamples % cp.nMDCTLines
+    cp.numSamples += cp.nMDCTLines
+    out = b"PAC " + pack("<LHLLHHHH", cp.sampleRate, cp.nChannels, cp.numSamples, cp.nMDCTLines,
+                         cp.nScaleBits, cp.nMantSizeBits, int(cp.useSBR), int(cp.useVQ))
+    cp.sfBands = ScaleFactorBands(AssignMDCTLinesFromFreqLimits(cp.nMDCTLines, cp.sampleRate))
+    cp.sfBandsShort = ScaleFactorBands(AssignMDCTLinesFromFreqLimits(128, cp.sampleRate))
+    cp.omittedBands = omitted_bands(cp.sfBands) if cp.useSBR else []
+    out += pack("<L", cp.sfBands.nBands)
+    out += pack("<" + str(cp.sfBands.nBands) + "H", *(cp.sfBands.nLines.tolist()))
+    return out
+
+
+class PACFile(AudioFile):
+    tag = b"PAC "
+
+    def WriteFileHeader(self, codingParams):
+        if getattr(codingParams, "useVQ", False) or getattr(codingParams, "useSBR", False):
+            raise NotImplementedError("the GPU path writes scalar-mantissa .pac files (useVQ/useSBR False)")
+        self.fp.write(header_bytes(codingParams))
+        codingParams.priorBlock = [np.zeros(codingParams.nMDCTLines, dtype=np.float64)
+                                   for _ in range(codingParams.nChannels)]
+
+    def WriteDataBlock(self, data, codingParams, lastTrans=False, curTrans=False, nextTrans=False):
+        """coder/pacfile.py:449-610: prior || data per channel, encode, pack, write."""
+        import torch
+        cp = codingParams
+        enc = context.encoder_for_params(cp)
+        blk = np.stack([np.concatenate((cp.priorBlock[ch], data[ch])) for ch in range(cp.nChannels)])
+        cp.priorBlock = data
+        pcm = PcmView.frames(torch.as_tensor(blk[None], device=enc.device))
+        flags = [(bool(lastTrans), bool(curTrans), bool(nextTrans))]
+        out = enc.encode(pcm, flags)
+        payload, n_bytes = enc.pack(out, cp.nChannels)
+        n_bytes = n_bytes.cpu().numpy()
+        if not n_bytes.any():
+            return                                  # hop dropped (coder/pacfile.py:530-533)
+        payload = payload.cpu().numpy()
+        for ch in range(cp.nChannels):
+            self.fp.write(pack("<L", int(n_bytes[ch])))
+            self.fp.write(payload[ch, :n_bytes[ch]].tobytes())
+
+    def Close(self, codingParams):
+        """coder/pacfile.py:612-625: one block of zeros flushes the last hop."""
+        if self.fp.mode == "wb":
+            self.WriteDataBlock([np.zeros(codingParams.nMDCTLines) for _ in range(codingParams.nChannels)],
+                                codingParams)
+        self.fp.close()
+
+    def Encode(self, data, codingParams, lastTrans=False, curTrans=False, nextTrans=False):
+        """coder/pacfile.py:627-643."""
+        return codec.Encode(data, codingParams, lastTrans, curTrans, nextTrans)
+
+
+def stream_flags(pcm, block_switching, hop=1024):
+    """(last, cur, next) for every written hop of the driver loop
+    (coder/pacfile.py:717-741) plus the Close block.  pcm: int16 [n_hops*hop, nCh]."""
+    n_hops = len(pcm) // hop
+    if block_switching:
+        frac = np.stack([codes_to_fraction(pcm[:, ch]) for ch in range(pcm.shape[1])])
+        t = hop_transients(frac.reshape(pcm.shape[1], n_hops, hop).transpose(1, 0, 2))
+    else:
+        t = np.zeros(n_hops, dtype=bool)
+    t = np.concatenate((t, [False]))                      # EOF pass: next = False
+    flags = np.zeros((n_hops + 2, 3), dtype=np.uint8)
+    for f in range(n_hops + 1):
+        flags[f] = (t[f - 2] if f >= 2 else 0, t[f - 1] if f >= 1 else 0, t[f])
+    return flags                                          # last row (Close) stays 0,0,0
+
+
+def device_stream(enc, pcm, hop=1024):
+    """Planar int16 device buffer [nCh, (n_hops+3)*hop]: zeros, the hops, the
+    last hop again (the driver writes it twice), zeros (Close)."""
+    import torch
+    n, n_ch = pcm.shape
+    n_hops = n // hop
+    buf = np.zeros((n_ch, (n_hops + 3) * hop), dtype=np.int16)
+    buf[:, hop:hop + n] = pcm.T
+    if n_hops:
+        buf[:, hop + n:2 * hop + n] = pcm[n - hop:].T
+    return torch.as_tensor(buf, device=enc.device)
+
+
+def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, header_samples=None,
+                  n_scale_bits=4, n_mant_size_bits=12):
+    """Whole-stream batched encode -> .pac bytes identical to what the
+    reference's driver (coder/pacfile.py:674-757, scalar path) writes for the
+    same PCM.  pcm: int16 [n, nCh], n a multiple of 1024 (see
+    pcmfile.wav_effective_stream for real WAV files)."""
+    from .audiofile import CodingParams
+    pcm = np.ascontiguousarray(pcm)
+    hop = 1024
+    assert pcm.ndim == 2 and len(pcm) % hop == 0
+    cp = CodingParams()
+    cp.sampleRate, cp.nChannels = int(sample_rate), pcm.shape[1]
+    cp.numSamples = len(pcm) if header_samples is None else int(header_samples)
+    cp.nMDCTLines = cp.nSamplesPerBlock = hop
+    cp.nScaleBits, cp.nMantSizeBits = n_scale_bits, n_mant_size_bits
+    cp.targetBitsPerSample = kbps_per_channel / (cp.sampleRate / 1000)
+    cp.useSBR = cp.useVQ = False
+    head = header_bytes(cp)
+    enc = context.encoder_for_params(cp)
+    flags = stream_flags(pcm, block_switching, hop)
+    view = PcmView.stream(device_stream(enc, pcm, hop), hop)
+    assert view.n_frames == len(flags)
+    out = enc.encode(view, flags)
+    payload, n_bytes = enc.pack(out, cp.nChannels)
+    body, total = enc.gather_body(payload, n_bytes)
+    n = int(total.item())
+    return head + body[:n].cpu().numpy().tobytes()

@@ -1,0 +1,87 @@
+"""Static float64 tables of the encode path, evaluated on the host with the same
+NumPy expressions the reference uses, so that what is uploaded to HBM is
+bit-identical to what the reference multiplies by.  (Host set-up code: runs once
+per handle, not per frame.)
+
+Reference: coder/window.py:14-92, coder/psychoac.py:35-48, 100-160, 171-184.
+"""
+import numpy as np
+
+SHORT_WINDOW = 256            # coder/codec.py:27
+SHORT_LINES = 128             # coder/pacfile.py:490
+
+# Zwicker critical-band upper edges, coder/psychoac.py:100-103
+cbFreqLimits = np.array([
+    100, 200, 300, 400, 510, 630, 770, 920, 1080, 1270, 1480, 1720, 2000, 2320,
+    2700, 3150, 3700, 4400, 5300, 6400, 7700, 9500, 12000, 15500, 24000
+])
+
+
+def sine(n):
+    return np.sin(np.pi * (np.arange(n) + 0.5) / n)
+
+
+def hann(n):
+    return 0.5 * (1 - np.cos(2 * np.pi * (np.arange(n) + 0.5) / n))
+
+
+def start(n_long, n_short):
+    pad = n_long // 4 - n_short // 4
+    return np.concatenate((sine(n_long)[:n_long // 2], np.ones(pad),
+                           sine(n_short)[n_short // 2:], np.zeros(pad)))
+
+
+def stop(n_long, n_short):
+    return np.flip(start(n_long, n_short))
+
+
+def start_stop(n_long, n_short):
+    pad = n_long // 4 - n_short // 4
+    s = sine(n_short)
+    return np.concatenate((np.zeros(pad), s[:n_short // 2], np.ones(2 * pad),
+                           s[n_short // 2:], np.zeros(pad)))
+
+
+def long_windows(n_long):
+    """[4][n_long] in PACX_WIN_* order: sine, start, stop, start-stop."""
+    return np.ascontiguousarray(np.stack([
+        sine(n_long), start(n_long, SHORT_WINDOW), stop(n_long, SHORT_WINDOW),
+        start_stop(n_long, SHORT_WINDOW)]))
+
+
+def line_freqs(n_lines, sample_rate):
+    return sample_rate / (2 * n_lines) * (np.arange(n_lines) + 0.5)
+
+
+def bark(f):
+    return 13.0 * np.arctan(0.76 * f / 1000.0) + 3.5 * np.arctan((f / 7500.0) ** 2)
+
+
+def thresh(f):
+    f = np.array(f, dtype=np.float64)
+    f[f < 10] = 10
+    return 3.64 * (f / 1000) ** (-0.8) - 6.5 * np.exp(-0.6 * (f / 1000 - 3.3) ** 2) \
+        + 10 ** (-3) * (f / 1000) ** 4
+
+
+def fft_norm(n):
+    """coder/psychoac.py:172-173 (np.hanning: the symmetric Hann)."""
+    return 4 / (n ** 2 * np.mean(np.hanning(n) ** 2))
+
+
+def fft_freq_step(n, sample_rate):
+    """Step of np.fft.rfftfreq(n, d=1/sample_rate)."""
+    return 1.0 / (n * (1 / sample_rate))
+
+
+def band_line_counts(n_lines, sample_rate, flimit=cbFreqLimits):
+    """coder/psychoac.py:106-124."""
+    width = sample_rate / (2 * n_lines)
+    centers = np.floor(flimit / width - 0.5)
+    counts = centers - np.concatenate([[-1], centers[:-1]])
+    for i in range(len(counts)):
+        if flimit[i] > sample_rate / 2:
+            counts[i] = n_lines - np.sum(counts[0:i])
+            counts[i + 1:] = 0
+            break
+    return counts

@@ -1,0 +1,53 @@
+"""window.py mirror (coder/window.py): same names, window * data evaluated on
+the GPU (pacx_window_batch).  On the encode hot path the window multiply is
+fused into the MDCT kernel instead (csrc/k_mdct.hip)."""
+import numpy as np
+
+from . import _lib, context
+
+
+def _apply(kind, data, expect):
+    import torch
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    if data.shape[-1] != expect:
+        raise NotImplementedError(f"GPU window tables exist for {expect}-sample blocks here")
+    enc = context.any_encoder()
+    y = enc.window(kind, torch.as_tensor(data, device=enc.device).view(-1, expect))
+    return y.cpu().numpy().reshape(data.shape)
+
+
+def SineWindow(dataSampleArray):
+    """coder/window.py:14-25 (2048- or 256-sample blocks)."""
+    n = np.shape(dataSampleArray)[-1]
+    return _apply(_lib.WIN_SINE if n == 2048 else _lib.WIN_SINE_SHORT, dataSampleArray,
+                  2048 if n == 2048 else 256)
+
+
+def HanningWindow(dataSampleArray):
+    """coder/window.py:29-41."""
+    n = np.shape(dataSampleArray)[-1]
+    return _apply(_lib.WIN_HANN if n == 2048 else _lib.WIN_HANN_SHORT, dataSampleArray,
+                  2048 if n == 2048 else 256)
+
+
+def _check(N_long, N_short):
+    if (N_long, N_short) != (2048, 256):
+        raise NotImplementedError("transition windows are resident for N_long=2048, N_short=256")
+
+
+def StartWindow(dataSampleArray, N_long, N_short):
+    """coder/window.py:61-71."""
+    _check(N_long, N_short)
+    return _apply(_lib.WIN_START, dataSampleArray, 2048)
+
+
+def StopWindow(dataSampleArray, N_long, N_short):
+    """coder/window.py:73-80."""
+    _check(N_long, N_short)
+    return _apply(_lib.WIN_STOP, dataSampleArray, 2048)
+
+
+def StartStopWindow(dataSampleArray, N_long, N_short):
+    """coder/window.py:82-92."""
+    _check(N_long, N_short)
+    return _apply(_lib.WIN_STARTSTOP, dataSampleArray, 2048)

@@ -59,6 +59,14 @@ extern "C" {
 #define PACX_WIN_START 1
 #define PACX_WIN_STOP 2
 #define PACX_WIN_STARTSTOP 3
+/* further tables addressable through pacx_window_batch */
+#define PACX_WIN_SINE_SHORT 4  /* SineWindow on a 256-sample short block      */
+#define PACX_WIN_HANN 5        /* HanningWindow, 2048 (coder/window.py:29-41) */
+#define PACX_WIN_HANN_SHORT 6  /* HanningWindow, 256                          */
+
+/* mode bits of pacx_mdct_batch */
+#define PACX_MDCT_SHORT 1        /* 8 short sub-blocks per frame              */
+#define PACX_MDCT_PREWINDOWED 2  /* input already windowed: plain mdct.MDCT   */
 
 /* per-cf status word bits written by pacx_encode_batch */
 #define PACX_ST_SHORT        1u   /* coded as 8 short sub-blocks               */
@@ -149,9 +157,11 @@ int  pacx_reserve(pacx_handle *h, int64_t n_cf);
  * window.py + mdct.py: MDCT(window(data), halfN, halfN)[:halfN]
  * (coder/codec.py:303-305; window choice coder/codec.py:30-44; int16 input is
  * first mapped as coder/pcmfile.py:89-99 does).
- *   short_blocks = 0: every frame is one long block; the window kind comes
+ *   mode 0: every frame is one long block; the window kind comes
  *       from frame_flags (NULL = all sine).  lines: [n_cf][n_lines_long].
- *   short_blocks = 1: every frame is cut into 8 short sub-blocks at
+ *   mode & PACX_MDCT_PREWINDOWED: no window is applied (mdct.MDCT alone,
+ *       coder/mdct.py:43-69 with a = b = halfN).
+ *   mode & PACX_MDCT_SHORT: every frame is cut into 8 short sub-blocks at
  *       n = 448 + 128 j (coder/pacfile.py:526-527), sine-windowed.
  *       lines: [n_cf][8][n_lines_short].
  * frame_flags: device uint8 [n_frames] of PACX_FLAG_* or NULL.
@@ -160,7 +170,7 @@ int  pacx_reserve(pacx_handle *h, int64_t n_cf);
  * The lines written are NOT multiplied by 2^scale.
  */
 int pacx_mdct_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
-                    int short_blocks, double *lines, int32_t *max_scale, void *stream);
+                    int mode, double *lines, int32_t *max_scale, void *stream);
 
 /*
  * psychoac.py: CalcSMRs(data, mdctLines*2^scale, scale, sampleRate, sfBands)
@@ -239,6 +249,31 @@ int pacx_pack_batch(pacx_handle *h, int64_t n_cf, int n_channels,
 int pacx_gather_body(pacx_handle *h, int64_t n_cf, const uint8_t *payload,
                      const int32_t *n_bytes, uint8_t *body, int64_t body_capacity,
                      int64_t *total_bytes, void *stream);
+
+/* ---- function-level entry points --------------------------------------
+ * One per remaining public function of the replaced modules, so that each has
+ * a GPU implementation behind the reference's signature.  The batched path
+ * above does not call these. */
+
+/* window.py: y = window * x for n_rows rows (SineWindow / StartWindow /
+ * StopWindow / StartStopWindow / HanningWindow; coder/window.py:14-92).
+ * `window` is a PACX_WIN_* id; rows are 2048 (256 for *_SHORT) float64. */
+int pacx_window_batch(pacx_handle *h, int window, int64_t n_rows, const double *x, double *y,
+                      void *stream);
+/* quantize.py: vQuantizeUniform(x, n_bits) (coder/quantize.py:61-78) */
+int pacx_quantize_uniform(pacx_handle *h, int64_t n, const double *x, int n_bits, int64_t *codes,
+                          void *stream);
+/* quantize.py: ScaleFactor(x[i], n_scale_bits, n_mant_bits) (coder/quantize.py:99-125) */
+int pacx_scale_factor(pacx_handle *h, int64_t n, const double *x, int n_scale_bits, int n_mant_bits,
+                      int64_t *scale, void *stream);
+/* quantize.py: vMantissa(x, scale, n_scale_bits, n_mant_bits) (coder/quantize.py:229-250) */
+int pacx_mantissa(pacx_handle *h, int64_t n, const double *x, int scale, int n_scale_bits,
+                  int n_mant_bits, int64_t *mantissa, void *stream);
+/* bitalloc.py: BitAlloc(budget[i], max_mant_bits, n_bands, band_lines, smr[i])
+ * for n independent problems (coder/bitalloc.py:62-121); all pointers device. */
+int pacx_bitalloc_generic(pacx_handle *h, int64_t n, int n_bands, const int32_t *band_lines,
+                          const double *budget, int max_mant_bits, const double *smr,
+                          int32_t *bit_alloc, void *stream);
 
 #ifdef __cplusplus
 }
