@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X encode path (BASELINE.json metric: audio channel-frames/s
+encode, 48 kHz, 1024-line long blocks, 128 kb/s/ch; MDCT HBM GB/s vs roofline).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the whole hot path over one device-resident batch of
+BASELINE configs[1]: 4096 synthetic 48 kHz stereo frames (8192 channel-frames) per
+GPU -> window, MDCT, psychoacoustic SMR, bit allocation, scale factors +
+mantissas, .pac bit packing and body assembly; with N > 1 the packed bitstream
+of every rank is then gathered to rank 0 over RCCL.  Weak scaling: every rank
+encodes its own 4096-frame shard.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES_PER_GPU = 4096          # stereo frames per step and GPU (configs[1])
+N_CH = 2
+SAMPLE_RATE = 48000
+KBPS = 128
+MDCT_BYTES_PER_CF = 1024 * 2 + 1024 * 8      # int16 hop in + float64 lines out
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(n_frames=96):
+    """The oracle (NumPy restatement of the reference, kind 'port') on the first
+    n_frames stereo frames of the same workload, one host core."""
+    from oracle import pac_oracle as po
+    import audio_codec_amd as A
+    pcm = A.synth.stream(n_frames, N_CH)
+    halo = np.concatenate((np.zeros((1024, N_CH), np.int16), pcm))
+    p = po.make_params(SAMPLE_RATE, N_CH, KBPS)
+    t0 = time.perf_counter()
+    for f in range(n_frames):
+        for ch in range(N_CH):
+            po.encode_channel(po.pcm16_to_fraction(halo[f * 1024:f * 1024 + 2048, ch]), p)
+    dt = time.perf_counter() - t0
+    return {"value": n_frames * N_CH / dt, "unit": "channel-frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_frames} stereo frames ({n_frames * N_CH} cf) of the same synthetic stream, "
+                      f"oracle/pac_oracle.py encode_channel, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="stereo frames per GPU and step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mdct-launches", type=int, default=50)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import audio_codec_amd as A
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    # ---- workload: device-resident before any timing
+    n_frames = args.frames
+    pcm = A.synth.stream(n_frames, N_CH, seed=A.synth.SEED + rank)
+    enc = A.engine.Encoder(SAMPLE_RATE, KBPS / (SAMPLE_RATE / 1000))
+    planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=dev)
+    view = A.engine.PcmView.stream(planar)
+    n_cf = view.n_cf
+    enc.reserve(n_cf)
+    out = enc.alloc_outputs(n_cf, with_payload=True)
+    cap = n_cf * 512
+    body = torch.empty(cap, dtype=torch.uint8, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    import ctypes
+    from audio_codec_amd.engine import _ptr
+
+    def step():
+        enc.encode(view, None, out)
+        enc.pack(out, N_CH, out)
+        enc._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(out["payload"]), _ptr(out["n_bytes"]),
+                  _ptr(body), ctypes.c_int64(cap), _ptr(total), enc._stream())
+        if world > 1:
+            A.dist.gather_bitstream(body, total.item())
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- MDCT kernel alone: HIP events on the stream the kernel runs on
+    lines = torch.empty((n_cf, 1024), dtype=torch.float64, device=dev)
+    scale = torch.empty((n_cf,), dtype=torch.int32, device=dev)
+
+    def mdct_once():
+        enc._call("pacx_mdct_batch", ctypes.byref(view.c), None, 0, _ptr(lines), _ptr(scale), enc._stream())
+    for _ in range(5):
+        mdct_once()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.mdct_launches)]
+    for a, b in ev:
+        a.record()
+        mdct_once()
+        b.record()
+    torch.cuda.synchronize()
+    mdct_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    mdct_gbs = n_cf * MDCT_BYTES_PER_CF / (mdct_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        res = {
+            "metric": "audio channel-frames/s encode (48 kHz, 1024-line long blocks, 128 kb/s/ch)",
+            "value": world * n_cf * args.steps / dt,
+            "unit": "channel-frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{n_frames} synthetic 48 kHz stereo frames per GPU ({n_cf} channel-frames), "
+                                   "N=1024 long blocks, 128 kb/s/ch, int16 PCM resident in HBM; step = encode + "
+                                   ".pac bit packing + body assembly" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                       "stereo_frames_per_s": world * n_frames * args.steps / dt,
+                       "sharding": f"{world} x frame-range shards, no data-path collective"},
+            "roofline": {"kernel": "k_mdct_long (window + MDCT, int16 in, float64 lines out)",
+                         "bound": "hbm", "achieved": mdct_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": mdct_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": mdct_ms, "bytes_per_cf": MDCT_BYTES_PER_CF, "cf_per_launch": n_cf,
+                         "mdct_cf_per_s": n_cf / (mdct_ms * 1e-3)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

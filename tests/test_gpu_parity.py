@@ -20,8 +20,11 @@ DB_TOL = 1e-9
 # rather than by the signal: a constant (DC) block has MDCT lines and FFT bins
 # that are mathematically ~0 above the first few, so which noise bins are
 # "peaks" and the sign bit of zero-magnitude mantissas depend on the FFT
-# implementation.  They are compared with test_rounding_noise_frame instead.
-NOISE_DECIDED = {"dc"}
+# implementation.  A lone impulse is the other textbook case: its spectrum is
+# exactly flat, so EVERY strict-local-maximum decision of the peak picker
+# (coder/psychoac.py:312-317) is a coin toss on the last bit of the FFT.
+# They are compared with test_rounding_noise_frame instead.
+NOISE_DECIDED = {"dc", "impulse", "nyquist"}   # nyquist: +-A alternating, one non-zero bin
 
 
 def strict(stages, kind, idx):
@@ -231,6 +234,15 @@ def test_rounding_noise_frame(A, torch, stages):
     assert np.array_equal(mant & (sign - 1), want & (sign - 1))
     differ = mant != want
     assert not ((mant & (sign - 1))[differ]).any()
+    # lone impulse: flat spectrum, the masker set itself is noise-decided; what
+    # the signal decides (MDCT lines, overall scale) is covered by
+    # test_mdct_long_golden, and the encode still has to be well formed
+    j = [str(t) for t in stages["long_tag"]].index("impulse")
+    out = enc.encode(frames_view(A, torch, enc, stages["long_x_i16"][j:j + 1]), stages["long_flags"][j:j + 1])
+    host = {k: v.cpu().numpy() for k, v in out.items() if v is not None}
+    sf, ba, mant, ov = A.codec.unpack_long(enc, host, 0)
+    assert ov == int(stages["long_overall"][j])
+    assert int(ba @ enc.sfBands.nLines) <= 2044 and ((ba == 0) | (ba >= 2)).all()
 
 
 def test_encode_synthetic_vs_oracle(A, torch):
