@@ -90,10 +90,15 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
                                                  int32_t *__restrict__ n_peaks)
 {
     typedef typename PcmStage<DT>::elem E;
-    __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
+    /* LDS lifetimes: raw (until the FFT inputs are in registers) then inten share
+       one region; the FFT exchange tile then the packed spectrum Z share another */
+    constexpr int RAW_BYTES = (int)sizeof(E) * PACX_N_LONG;
+    constexpr int B_BYTES = RAW_BYTES > 1032 * 8 ? RAW_BYTES : 1032 * 8;
     __shared__ __attribute__((aligned(16))) cplx Z[1024];
-    __shared__ __attribute__((aligned(16))) double inten[1032];
-    __shared__ __attribute__((aligned(16))) E raw[PACX_N_LONG];
+    __shared__ __attribute__((aligned(16))) char regB[B_BYTES];
+    cplx *tile = Z;
+    double *inten = (double *)regB;
+    E *raw = (E *)regB;
     const int lane = threadIdx.x;
     const long long cf = blockIdx.x;
     if (cf >= n_cf)
@@ -113,8 +118,10 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
         ev[n1] = make_double2(hw[i] * PcmStage<DT>::get(raw, i), hw[i + 1] * PcmStage<DT>::get(raw, i + 1));
         od[n1] = make_double2(hw[i + 2] * PcmStage<DT>::get(raw, i + 2), hw[i + 3] * PcmStage<DT>::get(raw, i + 3));
     }
+    __syncthreads();                  /* raw fully consumed before anything reuses LDS */
     fft512(ev, tile, T.w512, lane);
     fft512(od, tile, T.w512, lane);
+    __syncthreads();                  /* tile dead: Z takes its place */
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) {
         const int k = fft512_out_index(lane, k3);
@@ -223,7 +230,18 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 
 /* ------------------------------------------------------ mask + per-band SMR */
 /* One wave per unit: a long cf (M = 1024, 16 lines per lane) or one short
- * sub-block (M = 128, 2 lines per lane; unit = 8*cf + sub-block). */
+ * sub-block (M = 128, 2 lines per lane; unit = 8*cf + sub-block).
+ *
+ * Lines are walked in chunks of 64 consecutive lines (one per lane), i.e. one
+ * contiguous Bark interval [zlo, zhi] per chunk.  For every chunk the maskers
+ * are first screened 64 at a time (one masker per lane): a masker whose curve
+ * cannot rise above (min threshold-in-quiet of the chunk - 0.01 dB) anywhere in
+ * [zlo, zhi] cannot change max(quiet, SPL(Intensity(.))) there and is skipped;
+ * the survivors (ballot mask) are evaluated for all 64 lines with exactly the
+ * reference's operation order.  The screen is exact: spreading curves fall
+ * monotonically away from the masker, and the SPL/Intensity round trip adds at
+ * most 1.2e-5 dB at levels >= the lowest threshold in quiet (-5 dB).
+ */
 template <int M>
 __global__ __launch_bounds__(64) void k_mask(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
                                             long long n_units, int mixed,
@@ -234,7 +252,9 @@ __global__ __launch_bounds__(64) void k_mask(PacxTables T, const uint8_t *__rest
 {
     constexpr bool SHORT = (M == PACX_M_SHORT);
     constexpr int PER = M / 64;
-    __shared__ double dif[M];
+    constexpr int MAXP = SHORT ? 64 : PACX_MAX_PEAKS;
+    constexpr int LDS_DOUBLES = (3 * MAXP > M) ? 3 * MAXP : M;
+    __shared__ __attribute__((aligned(16))) double lds[LDS_DOUBLES];   /* maskers, later the SMR terms */
     const int lane = threadIdx.x;
     const long long unit = blockIdx.x;
     if (unit >= n_units)
@@ -251,40 +271,63 @@ __global__ __launch_bounds__(64) void k_mask(PacxTables T, const uint8_t *__rest
     const PacxPeak *__restrict__ pk = peaks + cf * PACX_MAX_PEAKS + sb * 64;
     const int np = n_peaks[cf * PACX_SUB + sb];
     const double *__restrict__ x = lines + cf * PACX_M_LONG + sb * PACX_M_SHORT;
+    PacxPeak *pks = (PacxPeak *)lds;
+    for (int p = lane; p < np; p += 64)
+        pks[p] = pk[p];
+    __syncthreads();
 
-    double z[PER], best[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        z[j] = bark[lane + 64 * j];
-        best[j] = -INFINITY;
-    }
-    for (int p = 0; p < np; ++p) {
-        const double pz = pk[p].z, ps = pk[p].spl, pu = pk[p].slope;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const double dz = z[j] - pz;
-            const double a = fabs(dz) - 0.5;
-            double gain = 0.0;
-            if (dz < -0.5)
-                gain = -27.0 * a;
-            else if (dz > 0.5)
-                gain = pu * a;
-            best[j] = fmax(best[j], (ps + gain) - 16.0);
-        }
-    }
+    double dif[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int k = lane + 64 * j;
-        double thr = quiet[k];
-        if (np > 0) {
-            const double inten = pow(10.0, (best[j] - 96.0) / 10.0);
+        const double zk = bark[k], qk = quiet[k];
+        const double zlo = bark[64 * j], zhi = bark[64 * j + 63];
+        double qmin = qk;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            qmin = fmin(qmin, __shfl_xor(qmin, off, 64));
+        qmin -= 0.01;
+        double best = -INFINITY;
+        for (int pb = 0; pb < np; pb += 64) {
+            bool live = false;
+            if (pb + lane < np) {
+                const PacxPeak q = pks[pb + lane];
+                double ub = 0.0;                       /* best case of the spreading gain on [zlo, zhi] */
+                if (q.z < zlo - 0.5)
+                    ub = q.slope * ((zlo - q.z) - 0.5);
+                else if (q.z > zhi + 0.5)
+                    ub = -27.0 * ((q.z - zhi) - 0.5);
+                live = (q.slope > 0.0) || ((q.spl - 16.0) + ub > qmin);
+            }
+            unsigned long long todo = __ballot(live);
+            while (todo) {
+                const int b = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const PacxPeak q = pks[pb + b];        /* wave-uniform address: LDS broadcast */
+                const double dz = zk - q.z;
+                const double a = fabs(dz) - 0.5;
+                double gain = 0.0;
+                if (dz < -0.5)
+                    gain = -27.0 * a;
+                else if (dz > 0.5)
+                    gain = q.slope * a;
+                best = fmax(best, (q.spl + gain) - 16.0);
+            }
+        }
+        double thr = qk;
+        if (best > -INFINITY) {
+            const double inten = pow(10.0, (best - 96.0) / 10.0);
             thr = fmax(thr, pacx_spl_array(inten));
         }
         if (thr_out)
             thr_out[cf * PACX_M_LONG + sb * PACX_M_SHORT + k] = thr;
         const double v = x[k];
-        dif[k] = pacx_spl_array((v * v) * 4.0) - thr;
+        dif[j] = pacx_spl_array((v * v) * 4.0) - thr;
     }
+    __syncthreads();                                   /* maskers no longer needed */
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        lds[lane + 64 * j] = dif[j];
     __syncthreads();
     const int nb = SHORT ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
@@ -294,7 +337,7 @@ __global__ __launch_bounds__(64) void k_mask(PacxTables T, const uint8_t *__rest
         const int lo = lower[b], hi = lo + count[b];
         double m = -INFINITY;
         for (int k = lo + lane; k < hi; k += 64)
-            m = fmax(m, dif[k]);
+            m = fmax(m, lds[k]);
         m = wave_max(m);
         if (lane == 0)
             out[b] = m;

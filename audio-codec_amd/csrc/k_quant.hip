@@ -25,8 +25,10 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
                                                 uint32_t *__restrict__ status)
 {
     const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
-    const long long cf = tid / PACX_SUB;
-    const int sb = (int)(tid % PACX_SUB);
+    /* one lane per (cf, sub-block) when short blocks can occur, else one per cf */
+    const bool dense = !short_blocks && !(mixed && flags);
+    const long long cf = dense ? tid : tid / PACX_SUB;
+    const int sb = dense ? 0 : (int)(tid % PACX_SUB);
     if (cf >= n_cf)
         return;
     const unsigned fl = flags ? flags[cf / n_ch] : 0u;
@@ -238,20 +240,17 @@ __global__ __launch_bounds__(64) void k_pack(PacxTables T, const uint8_t *__rest
 }
 
 /* ----------------------------------------------------------- body gather */
-#define SCAN_CHUNK 1024
+#define SCAN_CHUNK 256
 
 __device__ __forceinline__ long long rec_len(int nb) { return nb > 0 ? (long long)nb + 4 : 0; }
 
+/* per-chunk byte totals */
 __global__ __launch_bounds__(256) void k_scan_partial(const int32_t *__restrict__ n_bytes, long long n,
                                                      long long *__restrict__ chunk_sum)
 {
     __shared__ long long red[256];
-    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
-    long long s = 0;
-    for (int i = threadIdx.x; i < SCAN_CHUNK; i += 256)
-        if (base + i < n)
-            s += rec_len(n_bytes[base + i]);
-    red[threadIdx.x] = s;
+    const long long i = (long long)blockIdx.x * SCAN_CHUNK + threadIdx.x;
+    red[threadIdx.x] = (i < n) ? rec_len(n_bytes[i]) : 0;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w)
@@ -262,42 +261,82 @@ __global__ __launch_bounds__(256) void k_scan_partial(const int32_t *__restrict_
         chunk_sum[blockIdx.x] = red[0];
 }
 
-__global__ void k_scan_chunks(long long *chunk_sum, long long n_chunks, long long *total)
+/* exclusive scan of the chunk totals (one wave; chunks are few: n_cf/256) */
+__global__ __launch_bounds__(64) void k_scan_chunks(long long *chunk_sum, long long n_chunks, long long *total)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        long long run = 0;
-        for (long long i = 0; i < n_chunks; ++i) {
-            const long long v = chunk_sum[i];
-            chunk_sum[i] = run;
-            run += v;
+    const int lane = threadIdx.x;
+    long long run = 0;
+    for (long long base = 0; base < n_chunks; base += 64) {
+        const long long i = base + lane;
+        const long long v = (i < n_chunks) ? chunk_sum[i] : 0;
+        long long inc = v;                       /* inclusive scan across the wave */
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long t = __shfl_up(inc, off, 64);
+            if (lane >= off)
+                inc += t;
         }
-        if (total)
-            *total = run;
+        if (i < n_chunks)
+            chunk_sum[i] = run + inc - v;
+        run += __shfl(inc, 63, 64);
     }
+    if (total && lane == 0)
+        *total = run;
 }
 
+/* byte offset of every record */
+__global__ __launch_bounds__(256) void k_scan_offsets(const int32_t *__restrict__ n_bytes, long long n,
+                                                     const long long *__restrict__ chunk_off,
+                                                     long long *__restrict__ offs)
+{
+    __shared__ long long buf[256];
+    const int t = threadIdx.x;
+    const long long i = (long long)blockIdx.x * SCAN_CHUNK + t;
+    const long long v = (i < n) ? rec_len(n_bytes[i]) : 0;
+    buf[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const long long add = (t >= off) ? buf[t - off] : 0;
+        __syncthreads();
+        buf[t] += add;
+        __syncthreads();
+    }
+    if (i < n)
+        offs[i] = chunk_off[blockIdx.x] + buf[t] - v;
+}
+
+/* one wave per record: "<L nBytes" then the payload bytes */
 __global__ __launch_bounds__(64) void k_copy_body(const int32_t *__restrict__ n_bytes, long long n,
-                                                 const long long *__restrict__ chunk_off,
+                                                 const long long *__restrict__ offs,
                                                  const uint8_t *__restrict__ payload, int payload_stride,
                                                  uint8_t *__restrict__ body, long long capacity)
 {
-    /* one wave per chunk of SCAN_CHUNK records: serial offsets inside the chunk
-       are cheap (records are ~350 bytes each) and keep the kernel simple */
-    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
-    long long off = chunk_off[blockIdx.x];
-    for (int i = 0; i < SCAN_CHUNK && base + i < n; ++i) {
-        const int nb = n_bytes[base + i];
-        if (nb <= 0)
-            continue;
-        if (off + nb + 4 <= capacity) {
-            const uint8_t *src = payload + (base + i) * (long long)payload_stride;
-            if (threadIdx.x < 4)
-                body[off + threadIdx.x] = (uint8_t)((unsigned)nb >> (8 * threadIdx.x));
-            for (int j = threadIdx.x; j < nb; j += 64)
-                body[off + 4 + j] = src[j];
-        }
-        off += nb + 4;
+    const long long i = blockIdx.x;
+    if (i >= n)
+        return;
+    const int nb = n_bytes[i];
+    if (nb <= 0)
+        return;
+    const long long off = offs[i];
+    if (off + nb + 4 > capacity)
+        return;
+    const uint8_t *src = payload + i * (long long)payload_stride;
+    const int lane = threadIdx.x;
+    if (lane < 4)
+        body[off + lane] = (uint8_t)((unsigned)nb >> (8 * lane));
+    uint8_t *dst = body + off + 4;
+    /* head bytes up to 4-byte alignment of dst, then dwords (src slots are 16-byte aligned), then tail */
+    const int head = (int)((4 - ((uintptr_t)dst & 3)) & 3);
+    if (lane < head && lane < nb)
+        dst[lane] = src[lane];
+    const int n_words = (nb - head) > 0 ? (nb - head) >> 2 : 0;
+    for (int w = lane; w < n_words; w += 64) {
+        const uint8_t *s = src + head + 4 * w;
+        const unsigned v = (unsigned)s[0] | ((unsigned)s[1] << 8) | ((unsigned)s[2] << 16) | ((unsigned)s[3] << 24);
+        *(unsigned *)(dst + head + 4 * w) = v;
     }
+    const int done = head + 4 * n_words;
+    if (done + lane < nb && lane < 4)
+        dst[done + lane] = src[done + lane];
 }
 
 /* ------------------------------------------------------------- launchers */
@@ -307,7 +346,8 @@ void pacx_launch_bitalloc(const PacxTables &T, const uint8_t *flags, int n_ch, l
 {
     if (n_cf <= 0)
         return;
-    const long long threads = n_cf * PACX_SUB;
+    const bool dense = !short_blocks && !(mixed && flags);
+    const long long threads = dense ? n_cf : n_cf * PACX_SUB;
     hipLaunchKernelGGL(k_bitalloc, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, T, flags, n_ch,
                        n_cf, short_blocks, mixed, smr, bit_alloc, status);
 }
@@ -340,7 +380,7 @@ void pacx_launch_pack(const PacxTables &T, const uint8_t *flags, int n_ch, long 
 }
 
 void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stride,
-                        const int32_t *n_bytes, long long *chunk_buf, uint8_t *body,
+                        const int32_t *n_bytes, long long *chunk_buf, long long *offs_buf, uint8_t *body,
                         long long capacity, long long *total, hipStream_t st)
 {
     if (n_cf <= 0)
@@ -348,6 +388,8 @@ void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stri
     const long long n_chunks = (n_cf + SCAN_CHUNK - 1) / SCAN_CHUNK;
     hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)n_chunks), dim3(256), 0, st, n_bytes, n_cf, chunk_buf);
     hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(64), 0, st, chunk_buf, n_chunks, total);
-    hipLaunchKernelGGL(k_copy_body, dim3((unsigned)n_chunks), dim3(64), 0, st, n_bytes, n_cf, chunk_buf,
-                       payload, payload_stride, body, capacity);
+    hipLaunchKernelGGL(k_scan_offsets, dim3((unsigned)n_chunks), dim3(256), 0, st, n_bytes, n_cf, chunk_buf,
+                       offs_buf);
+    hipLaunchKernelGGL(k_copy_body, dim3((unsigned)n_cf), dim3(64), 0, st, n_bytes, n_cf, offs_buf, payload,
+                       payload_stride, body, capacity);
 }

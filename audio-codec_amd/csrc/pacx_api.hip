@@ -37,7 +37,7 @@ void pacx_launch_pack(const PacxTables &T, const uint8_t *flags, int n_ch, long 
                       const int32_t *mantissa, const uint32_t *status, uint8_t *payload,
                       int payload_stride, int32_t *n_bytes, hipStream_t st);
 void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stride,
-                        const int32_t *n_bytes, long long *chunk_buf, uint8_t *body,
+                        const int32_t *n_bytes, long long *chunk_buf, long long *offs_buf, uint8_t *body,
                         long long capacity, long long *total, hipStream_t st);
 
 void pacx_launch_window(const double *win, long long n_rows, int len, const double *x, double *y,
@@ -60,7 +60,8 @@ struct pacx_handle {
     PacxPeak *ws_peaks;               /* [ws_cf][512]                           */
     int32_t *ws_npeaks;               /* [ws_cf][8]                             */
     int32_t *ws_overall;              /* [ws_cf][8]                             */
-    long long *ws_chunks;             /* [ws_cf/1024 + 1]                       */
+    long long *ws_chunks;             /* [ws_cf/256 + 2]                        */
+    long long *ws_offs;               /* [ws_cf]                                */
     std::string err;
 };
 
@@ -170,7 +171,7 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->device = cfg->device;
     h->ws_cf = 0;
     h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
-    h->ws_overall = nullptr; h->ws_chunks = nullptr;
+    h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr;
     memset(&h->T, 0, sizeof(h->T));
     int rc = PACX_OK;
 #define TRY(x) do { rc = (x); if (rc) { g_create_err = h->err; pacx_destroy(h); return rc; } } while (0)
@@ -288,12 +289,12 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
 
 static void free_ws(pacx_handle *h)
 {
-    void *p[] = {h->ws_lines, h->ws_smr, h->ws_peaks, h->ws_npeaks, h->ws_overall, h->ws_chunks};
+    void *p[] = {h->ws_lines, h->ws_smr, h->ws_peaks, h->ws_npeaks, h->ws_overall, h->ws_chunks, h->ws_offs};
     for (void *q : p)
         if (q)
             (void)hipFree(q);
     h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
-    h->ws_overall = nullptr; h->ws_chunks = nullptr;
+    h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr;
     h->ws_cf = 0;
 }
 
@@ -323,7 +324,8 @@ extern "C" int pacx_reserve(pacx_handle *h, int64_t n_cf)
     HIP_TRY(h, hipMalloc((void **)&h->ws_peaks, n * PACX_MAX_PEAKS * sizeof(PacxPeak)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_npeaks, n * PACX_SUB * sizeof(int32_t)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_overall, n * PACX_SUB * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc((void **)&h->ws_chunks, (n / 1024 + 2) * sizeof(long long)));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_chunks, (n / 256 + 2) * sizeof(long long)));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_offs, (n + 1) * sizeof(long long)));
     h->ws_cf = n_cf;
     return PACX_OK;
 }
@@ -501,7 +503,7 @@ extern "C" int pacx_gather_body(pacx_handle *h, int64_t n_cf, const uint8_t *pay
     int rc = pacx_reserve(h, n_cf);
     if (rc)
         return rc;
-    pacx_launch_gather(n_cf, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_chunks, body, body_capacity,
+    pacx_launch_gather(n_cf, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_chunks, h->ws_offs, body, body_capacity,
                        (long long *)total_bytes, (hipStream_t)stream);
     return post_launch(h, "pacx_gather_body");
 }
