@@ -67,8 +67,10 @@ __global__ __launch_bounds__(64) void k_mdct_long(PacxTables T, PacxPcmView in,
     if (cf >= n_cf)
         return;
     const unsigned fl = flags ? flags[cf / in.n_ch] : 0u;
-    if (skip_cur && (fl & 2u))
+    if ((skip_cur & 1) && (fl & 2u))
         return;
+    if ((skip_cur & 2) && pacx_window_kind(fl) == 0)
+        return;                              /* sine frames were done by k_mdct_long_v2 */
     const double *__restrict__ w = prewin ? T.ones : T.win_long + pacx_window_kind(fl) * PACX_N_LONG;
 
     stage_samples<DT, FAST>(raw, in, cf, 0, PACX_N_LONG, lane);
@@ -205,11 +207,22 @@ static void launch_mdct(const PacxTables &T, const PacxPcmView &in, const uint8_
                         int32_t *scale_out, int scale_stride, uint32_t *status, hipStream_t st)
 {
     const dim3 grid((unsigned)n_cf), block(64);
+    /* mixed = 2 / 3: the sine-window long frames were done by k_mdct_long_v2;
+       here the long kernel only takes transition-window frames (3: and skips
+       CUR frames), the short kernel only CUR frames (3) */
+    if (mixed == 2 || mixed == 3) {
+        hipLaunchKernelGGL((k_mdct_long<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf,
+                           mixed == 3 ? 3 : 2, prewin, lines, scale_out, scale_stride);
+        if (mixed == 3)
+            hipLaunchKernelGGL((k_mdct_short<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, 1,
+                               prewin, lines, scale_out, status);
+        return;
+    }
     if (!short_blocks || mixed)
         hipLaunchKernelGGL((k_mdct_long<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed,
                            prewin, lines, scale_out, scale_stride);
     if (short_blocks || mixed)
-        hipLaunchKernelGGL((k_mdct_short<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed,
+        hipLaunchKernelGGL((k_mdct_short<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed ? 1 : 0,
                            prewin, lines, scale_out, status);
 }
 

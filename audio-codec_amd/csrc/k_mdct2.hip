@@ -1,0 +1,145 @@
+/*
+ * k_mdct2.hip -- the roofline kernel: window + MDCT of long blocks, int16 PCM in
+ * (unit stride, 16-byte aligned rows), float64 lines out.  Same math as
+ * k_mdct.hip (reference: coder/window.py:14-25, coder/mdct.py:43-69 at
+ * coder/codec.py:303-311) laid out for throughput:
+ *
+ *   - persistent workgroups of 8 waves, one channel-frame per wave at a time,
+ *     grid-stride over frames; twiddle table d[n] and the sine window live in
+ *     LDS once per workgroup, the per-lane FFT twiddles in registers;
+ *   - the next frame's 4 KB of PCM is prefetched into registers (4 x 16-byte
+ *     coalesced loads per lane) while the current frame is transformed;
+ *   - natural-order 512-point FFT (wave_fft.h fft512n) on an 8 KB swizzled tile
+ *     that also stages the raw int16 samples, so LDS is 8 KB per wave;
+ *   - lane L ends up holding y[L + 64 j]; X[2k] = Re y[k] and
+ *     X[2k+1] = -Im y[511-k] sit in mirrored lanes, one 64-lane reversal
+ *     (ds_bpermute) pairs them so every store is a contiguous 16 bytes per lane
+ *     (1 KB per wave instruction).
+ *
+ * HBM traffic per channel-frame: 2 KB of new PCM (the other half of the window
+ * was read by the previous frame and is an L2 hit) + 8 KB of lines = 10 240 B.
+ */
+#include "pacx_dev.h"
+#include "wave_fft.h"
+
+#define MDCT2_WAVES 6      /* 6 x 8 KB tiles + 17 KB tables = 65 KB: two workgroups per CU */
+
+__global__ __launch_bounds__(64 * MDCT2_WAVES, 3) void k_mdct_long_v2(
+    PacxTables T, PacxPcmView in, const uint8_t *__restrict__ flags, long long n_cf, int skip_cur,
+    double *__restrict__ lines, int32_t *__restrict__ scale_out, int scale_stride)
+{
+    __shared__ __attribute__((aligned(16))) cplx tiles[MDCT2_WAVES][WFFT_TILE_N];
+    __shared__ __attribute__((aligned(16))) cplx twl[512];
+    __shared__ __attribute__((aligned(16))) double wsin[1024];
+    __shared__ __attribute__((aligned(16))) cplx w64[7][8];        /* W64^(r k2), k2 = 1..7 */
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 512; i += 64 * MDCT2_WAVES)
+        twl[i] = T.tw_long[i];
+    for (int i = tid; i < 1024; i += 64 * MDCT2_WAVES)
+        wsin[i] = T.win_long[i];
+    if (tid < 56)
+        w64[tid >> 3][tid & 7] = T.w512[8 * (tid & 7) * ((tid >> 3) + 1)];
+    __syncthreads();
+
+    cplx w1[7];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        w1[k - 1] = T.w512[lane * k];
+    const cplx *w2 = &w64[0][lane & 7];                            /* w2[8 (k2-1)] */
+    cplx *tile = tiles[wv];
+    short *raw = (short *)tile;
+    const unsigned n_ch = (unsigned)in.n_ch;
+    const unsigned stride = gridDim.x * MDCT2_WAVES;
+    const unsigned total = (unsigned)n_cf;
+    const short *base = (const short *)in.base;
+
+    /* PCM goes HBM -> LDS without touching VGPRs (global_load_lds_dwordx4:
+       wave-uniform LDS base + lane*16, per-lane global address) */
+    auto stage = [&](unsigned c) {
+        const unsigned f = c / n_ch, ch = c - f * n_ch;
+        const int4 *src = (const int4 *)(base + (long long)f * in.frame_stride + (long long)ch * in.ch_stride);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane + 64 * j),
+                                             (__attribute__((address_space(3))) void *)((char *)tile + 1024 * j),
+                                             16, 0, 0);
+    };
+    unsigned cf = blockIdx.x * MDCT2_WAVES + wv;
+    if (cf < total)
+        stage(cf);
+    for (; cf < total; cf += stride) {
+        const unsigned fl = flags ? flags[cf / n_ch] : 0u;
+        /* frames this kernel leaves to others: short-coded (CUR) ones when asked
+           to, and long frames with a transition window (k_mdct_long takes them) */
+        const bool mine = !(skip_cur && (fl & 2u)) && pacx_window_kind(fl) == 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* this frame's PCM has landed in LDS */
+        wave_lds_fence();
+        const int Q = PACX_N_LONG / 4, M = PACX_M_LONG;
+        cplx v[8];
+        /* sine window: w[2047-i] = w[i], so two table values serve each n */
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int n = lane + 64 * n1;
+            double re, im;
+            if (n1 < 4) {
+                const int i0 = 3 * Q - 1 - 2 * n, i1 = 3 * Q + 2 * n, i2 = Q - 1 - 2 * n, i3 = Q + 2 * n;
+                const double wa = wsin[i3], wb = wsin[i2];       /* = w[i0], w[i1] */
+                re = -(wa * pacx_pcm16_to_f64(raw[i0])) - wb * pacx_pcm16_to_f64(raw[i1]);
+                im = wb * pacx_pcm16_to_f64(raw[i2]) - wa * pacx_pcm16_to_f64(raw[i3]);
+            } else {
+                const int m = 2 * n - Q;
+                const int i0 = m, i1 = M - 1 - m, i2 = 2 * Q + m, i3 = 4 * Q - 1 - m;
+                const double wa = wsin[i0], wb = wsin[i1];       /* = w[i3], w[i2] */
+                re = wa * pacx_pcm16_to_f64(raw[i0]) - wb * pacx_pcm16_to_f64(raw[i1]);
+                im = -(wb * pacx_pcm16_to_f64(raw[i2])) - wa * pacx_pcm16_to_f64(raw[i3]);
+            }
+            v[n1] = c_mul(make_double2(re, im), twl[n]);
+        }
+        wave_lds_fence();                 /* raw samples consumed: the tile may be overwritten */
+        fft512n(v, tile, w1, w2, 8, lane);
+
+        /* the tile is free again: start the next frame's PCM on its way now, it
+           lands during the epilogue and the other waves' work */
+        if (cf + stride < total)
+            stage(cf + stride);
+        if (!mine)
+            continue;
+
+        const double s = 2.0 / PACX_N_LONG;
+        double a[8], b[8];
+        double mx = 0.0;
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) {
+            const cplx y = c_mul(v[k3], twl[lane + 64 * k3]);
+            a[k3] = y.x * s;                 /* X[2k],        k = lane + 64 k3 */
+            b[k3] = -(y.y * s);              /* X[1023 - 2k]                   */
+            mx = fmax(mx, fmax(fabs(a[k3]), fabs(b[k3])));
+        }
+        double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) {
+            /* X[2k+1] = X[1023 - 2(511-k)] is held by lane 63-lane, register 7-k3 */
+            const double odd = __shfl(b[7 - k3], 63 - lane, 64);
+            out[lane + 64 * k3] = make_double2(a[k3], odd);
+        }
+        if (scale_out) {
+            mx = wave_max(mx);
+            if (lane == 0)
+                scale_out[(long long)cf * scale_stride] = pacx_scale_factor(mx, T.n_scale_bits, 5);
+        }
+    }
+}
+
+void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8_t *flags, long long n_cf,
+                         int skip_cur, double *lines, int32_t *scale_out, int scale_stride, int n_cu,
+                         hipStream_t st)
+{
+    if (n_cf <= 0)
+        return;
+    long long blocks = (n_cf + MDCT2_WAVES - 1) / MDCT2_WAVES;
+    const long long cap = (long long)n_cu * 2;            /* 2 workgroups per CU (LDS) */
+    if (blocks > cap)
+        blocks = cap;
+    hipLaunchKernelGGL(k_mdct_long_v2, dim3((unsigned)blocks), dim3(64 * MDCT2_WAVES), 0, st, T, in, flags,
+                       n_cf, skip_cur, lines, scale_out, scale_stride);
+}

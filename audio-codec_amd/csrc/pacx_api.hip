@@ -19,6 +19,9 @@ void pacx_launch_mdct(const PacxTables &T, const PacxPcmView &in, int dtype, int
                       const uint8_t *flags, long long n_cf, int short_blocks, int mixed, int prewin,
                       double *lines, int32_t *scale_out, int scale_stride, uint32_t *status,
                       hipStream_t st);
+void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8_t *flags, long long n_cf,
+                         int skip_cur, double *lines, int32_t *scale_out, int scale_stride, int n_cu,
+                         hipStream_t st);
 void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
                       const uint8_t *flags, long long n_cf, int short_blocks, int mixed,
                       PacxPeak *peaks, int32_t *n_peaks, hipStream_t st);
@@ -51,6 +54,7 @@ void pacx_launch_bitalloc_generic(long long n, int nb, const int32_t *n_lines, c
 
 struct pacx_handle {
     int device;
+    int n_cu;                         /* compute units (persistent-kernel grid sizing) */
     PacxTables T;
     std::vector<void *> owned;        /* table allocations                      */
     /* workspace (device), sized for ws_cf channel-frames */
@@ -182,6 +186,11 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
             delete h;
             return PACX_E_HIP;
         }
+    }
+    {
+        hipDeviceProp_t prop;
+        h->n_cu = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
     }
     PacxTables &T = h->T;
     const int NL = PACX_N_LONG, NS = PACX_N_SHORT, ML = PACX_M_LONG, MS = PACX_M_SHORT;
@@ -376,6 +385,13 @@ extern "C" int pacx_mdct_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t
         return fail(h, PACX_E_ARG, "pacx_mdct_batch: lines is null");
     HIP_TRY(h, hipSetDevice(h->device));
     const int short_blocks = (mode & PACX_MDCT_SHORT) ? 1 : 0;
+    if (fast && !short_blocks && !(mode & PACX_MDCT_PREWINDOWED)) {
+        pacx_launch_mdct_v2(h->T, v, frame_flags, n_cf, 0, lines, max_scale, 1, h->n_cu, (hipStream_t)stream);
+        if (frame_flags)       /* frames with a start/stop/start-stop window */
+            pacx_launch_mdct(h->T, v, in->dtype, fast, frame_flags, n_cf, 0, 2, 0, lines, max_scale, 1, nullptr,
+                             (hipStream_t)stream);
+        return post_launch(h, "pacx_mdct_batch");
+    }
     pacx_launch_mdct(h->T, v, in->dtype, fast, frame_flags, n_cf, short_blocks, 0,
                      (mode & PACX_MDCT_PREWINDOWED) ? 1 : 0, lines, max_scale,
                      short_blocks ? PACX_SUB : 1, nullptr, (hipStream_t)stream);
@@ -465,8 +481,16 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
     const int n_ch = in->n_channels;
     HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
     HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
-    pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
-                     PACX_SUB, status, st);
+    if (fast) {
+        /* long frames: persistent roofline kernel; short (CUR) frames: k_mdct_short */
+        pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, h->n_cu, st);
+        if (mixed)
+            pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 3, 0, h->ws_lines, overall_scale,
+                             PACX_SUB, status, st);
+    } else {
+        pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
+                         PACX_SUB, status, st);
+    }
     pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, st);
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_lines, h->ws_smr,
                      nullptr, st);

@@ -122,6 +122,49 @@ __device__ __forceinline__ void fft512(cplx v[8], cplx *tile, const cplx *__rest
     fft64x8(v, tile, w512, lane);
 }
 
+/*
+ * 512-point FFT, natural order in AND out, on an unpadded 512-complex tile:
+ *   in : v[n1] = x[lane + 64 n1]        out: v[k3] = X[lane + 64 k3]
+ * Both exchanges are bank-conflict free through XOR swizzles (found by
+ * exhaustive search over the ds_write_b128 / ds_read_b128 lane groups of
+ * gfx950, tools/proto_wave_fft.py:fft512n is the model):
+ *   X1 write  row k1, col lane ^ 8 k1        X1 read  row g, col 8 (n2 ^ g) + r
+ *   X2 write  row g,  col 8 k2 + (r ^ g)     X2 read  row lane&7, col 8 (lane>>3) + (n3 ^ (lane&7))
+ * w1[k-1] = W512^(lane k): per-lane constants the caller keeps in registers
+ * across frames; w2[(k-1) w2_stride] = W64^((lane&7) k), k = 1..7 (LDS table).
+ */
+#define WFFT_TILE_N 512
+__device__ __forceinline__ void fft512n(cplx v[8], cplx *tile, const cplx w1[7], const cplx *w2, int w2_stride,
+                                        int lane)
+{
+    const int g = lane >> 3, r = lane & 7;
+    dft8(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1)
+        v[k1] = c_mul(v[k1], w1[k1 - 1]);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1)
+        tile[64 * k1 + (lane ^ (8 * k1))] = v[k1];
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2)
+        v[n2] = tile[64 * g + 8 * (n2 ^ g) + r];
+    wave_lds_fence();
+    dft8(v);
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2)
+        v[k2] = c_mul(v[k2], w2[(k2 - 1) * w2_stride]);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2)
+        tile[64 * g + 8 * k2 + (r ^ g)] = v[k2];
+    wave_lds_fence();
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3)
+        v[n3] = tile[64 * r + 8 * g + (n3 ^ r)];
+    wave_lds_fence();
+    dft8(v);
+}
+
 /* index of the value held in register k3 after fft512 */
 __device__ __forceinline__ int fft512_out_index(int lane, int k3) { return (lane >> 3) + 8 * (lane & 7) + 64 * k3; }
 /* index (inside the group) of the value held in register k3 after fft64x8 */

@@ -180,3 +180,64 @@ if __name__ == "__main__":
     print("rfft2048 err", np.max(np.abs(rfft2048(xh) - np.fft.rfft(xh))))
     xh8 = rng.standard_normal((8, 256))
     print("rfft256x8 err", np.max(np.abs(rfft256x8(xh8) - np.fft.rfft(xh8, axis=1))))
+
+
+# ---------------------------------------------------------------------------
+# v2: 512-point FFT with NATURAL-order output (lane L, reg k3 holds X[L + 64 k3])
+# on an unpadded 512-complex tile; both exchanges conflict-free via XOR swizzles
+# (searched exhaustively against the ds_read_b128 / ds_write_b128 lane groups).
+def fft512n(v):
+    A = dft8(v)
+    k1 = np.arange(8)
+    A = A * np.exp(-2j * np.pi * np.outer(L, k1) / 512)
+    lds = np.zeros(512, dtype=complex)
+    for kk in range(8):
+        lds[64 * kk + (L ^ (8 * kk))] = A[:, kk]                  # X1 write
+    g, r = L >> 3, L & 7
+    b = np.zeros((64, 8), dtype=complex)
+    for n2 in range(8):
+        b[:, n2] = lds[64 * g + 8 * (n2 ^ g) + r]                  # X1 read
+    B = dft8(b)
+    k2 = np.arange(8)
+    B = B * np.exp(-2j * np.pi * np.outer(r, k2) / 64)
+    lds = np.zeros(512, dtype=complex)
+    for kk in range(8):
+        lds[64 * g + 8 * kk + (r ^ g)] = B[:, kk]                  # X2 write
+    c = np.zeros((64, 8), dtype=complex)
+    for n3 in range(8):
+        c[:, n3] = lds[64 * (L & 7) + 8 * (L >> 3) + (n3 ^ (L & 7))]   # X2 read, natural lanes
+    return dft8(c)
+
+
+def mdct_long_v2(xw):
+    """MDCT with fft512n: pre- and post-twiddle use the same per-lane table
+    entries d[L + 64 j]; out[2k+1] comes from the mirrored lane / register."""
+    N, M, Q = 2048, 1024, 512
+    n = L[:, None] + 64 * np.arange(8)[None, :]
+    lo = n < Q // 2
+    m = 2 * n - Q
+    re = np.where(lo, -xw[np.where(lo, 3 * Q - 1 - 2 * n, 0)] - xw[np.where(lo, 3 * Q + 2 * n, 0)],
+                  xw[np.where(lo, 0, m)] - xw[np.where(lo, 0, M - 1 - m)])
+    im = np.where(lo, xw[np.where(lo, Q - 1 - 2 * n, 0)] - xw[np.where(lo, Q + 2 * n, 0)],
+                  -xw[np.where(lo, 0, 2 * Q + m)] - xw[np.where(lo, 0, 4 * Q - 1 - m)])
+    d = np.exp(-1j * np.pi * (8 * n + 1) / 8192)
+    y = fft512n((re + 1j * im) * d) * d * (2.0 / N)
+    a = y.real                      # -> out[2k]
+    bb = -y.imag                    # -> out[M-1-2k]
+    partner = bb[63 - L][:, ::-1]   # lane 63-L, register 7-k3
+    out = np.zeros(M)
+    out[2 * n] = a
+    out[2 * n + 1] = partner
+    return out
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(512) + 1j * rng.standard_normal(512)
+    v = x[L[:, None] + 64 * np.arange(8)[None, :]]
+    X = np.zeros(512, dtype=complex)
+    X[L[:, None] + 64 * np.arange(8)[None, :]] = fft512n(v)
+    print("fft512n err", np.max(np.abs(X - np.fft.fft(x))))
+    xw = po.sine_window(2048) * rng.standard_normal(2048)
+    ref = po.mdct_forward(xw, 1024, 1024)
+    print("mdct v2 rel err", np.max(np.abs(mdct_long_v2(xw) - ref)) / np.max(np.abs(ref)))
