@@ -22,9 +22,13 @@
 #include "pacx_dev.h"
 #include "wave_fft.h"
 
-#define MDCT2_WAVES 6      /* 6 x 8 KB tiles + 17 KB tables = 65 KB: two workgroups per CU */
+#include <stdlib.h>
 
-__global__ __launch_bounds__(64 * MDCT2_WAVES, 3) void k_mdct_long_v2(
+
+/* WAVES waves per workgroup (8 KB tile each + 17 KB of tables), MINW = waves per
+   SIMD the register allocator has to leave room for */
+template <int MDCT2_WAVES, int MINW>
+__global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
     PacxTables T, PacxPcmView in, const uint8_t *__restrict__ flags, long long n_cf, int skip_cur,
     double *__restrict__ lines, int32_t *__restrict__ scale_out, int scale_stride)
 {
@@ -32,19 +36,26 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 3) void k_mdct_long_v2(
     __shared__ __attribute__((aligned(16))) cplx twl[512];
     __shared__ __attribute__((aligned(16))) double wsin[1024];
     __shared__ __attribute__((aligned(16))) cplx w64[7][8];        /* W64^(r k2), k2 = 1..7 */
+    __shared__ __attribute__((aligned(16))) cplx w1s[7][64];       /* W512^(lane k1), k1 = 1..7 */
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < 512; i += 64 * MDCT2_WAVES)
         twl[i] = T.tw_long[i];
+    /* window table with the PCM scale 2/65535 (coder/pcmfile.py:89-99 mapping)
+       and the MDCT's 2/N = 2^-10 folded in: the transform is linear, so the
+       int16 codes go through it as exact integers and each product w'[i]*c
+       carries one rounding.  Against the reference's order (round x = 2c/65535
+       first, then window) this moves a line by ~1e-16 of the block maximum,
+       three orders below the 2e-13 that separates the two FFT algorithms. */
+    const double kscale = (2.0 / 65535.0) * (2.0 / PACX_N_LONG);
     for (int i = tid; i < 1024; i += 64 * MDCT2_WAVES)
-        wsin[i] = T.win_long[i];
+        wsin[i] = T.win_long[i] * kscale;
     if (tid < 56)
         w64[tid >> 3][tid & 7] = T.w512[8 * (tid & 7) * ((tid >> 3) + 1)];
+    for (int i = tid; i < 7 * 64; i += 64 * MDCT2_WAVES)
+        w1s[i >> 6][i & 63] = T.w512[(i & 63) * ((i >> 6) + 1)];
     __syncthreads();
 
-    cplx w1[7];
-#pragma unroll
-    for (int k = 1; k < 8; ++k)
-        w1[k - 1] = T.w512[lane * k];
+    const cplx *w1 = &w1s[0][lane];                                /* w1[64 (k1-1)] */
     const cplx *w2 = &w64[0][lane & 7];                            /* w2[8 (k2-1)] */
     cplx *tile = tiles[wv];
     short *raw = (short *)tile;
@@ -76,7 +87,12 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 3) void k_mdct_long_v2(
         wave_lds_fence();
         const int Q = PACX_N_LONG / 4, M = PACX_M_LONG;
         cplx v[8];
-        /* sine window: w[2047-i] = w[i], so two table values serve each n */
+        /* sine window: w[2047-i] = w[i], so two table values serve each n.
+           code(): int16 -> double, with -32768 -> 0 as the reference maps it */
+        auto code = [&](int i) -> double {
+            const int c = raw[i];
+            return (double)(c == -32768 ? 0 : c);
+        };
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
             const int n = lane + 64 * n1;
@@ -84,19 +100,19 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 3) void k_mdct_long_v2(
             if (n1 < 4) {
                 const int i0 = 3 * Q - 1 - 2 * n, i1 = 3 * Q + 2 * n, i2 = Q - 1 - 2 * n, i3 = Q + 2 * n;
                 const double wa = wsin[i3], wb = wsin[i2];       /* = w[i0], w[i1] */
-                re = -(wa * pacx_pcm16_to_f64(raw[i0])) - wb * pacx_pcm16_to_f64(raw[i1]);
-                im = wb * pacx_pcm16_to_f64(raw[i2]) - wa * pacx_pcm16_to_f64(raw[i3]);
+                re = -fma(wb, code(i1), wa * code(i0));
+                im = fma(wb, code(i2), -(wa * code(i3)));
             } else {
                 const int m = 2 * n - Q;
                 const int i0 = m, i1 = M - 1 - m, i2 = 2 * Q + m, i3 = 4 * Q - 1 - m;
                 const double wa = wsin[i0], wb = wsin[i1];       /* = w[i3], w[i2] */
-                re = wa * pacx_pcm16_to_f64(raw[i0]) - wb * pacx_pcm16_to_f64(raw[i1]);
-                im = -(wb * pacx_pcm16_to_f64(raw[i2])) - wa * pacx_pcm16_to_f64(raw[i3]);
+                re = fma(wa, code(i0), -(wb * code(i1)));
+                im = -fma(wb, code(i2), wa * code(i3));
             }
             v[n1] = c_mul(make_double2(re, im), twl[n]);
         }
         wave_lds_fence();                 /* raw samples consumed: the tile may be overwritten */
-        fft512n(v, tile, w1, w2, 8, lane);
+        fft512n(v, tile, w1, 64, w2, 8, lane);
 
         /* the tile is free again: start the next frame's PCM on its way now, it
            lands during the epilogue and the other waves' work */
@@ -105,14 +121,13 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 3) void k_mdct_long_v2(
         if (!mine)
             continue;
 
-        const double s = 2.0 / PACX_N_LONG;
         double a[8], b[8];
         double mx = 0.0;
 #pragma unroll
         for (int k3 = 0; k3 < 8; ++k3) {
-            const cplx y = c_mul(v[k3], twl[lane + 64 * k3]);
-            a[k3] = y.x * s;                 /* X[2k],        k = lane + 64 k3 */
-            b[k3] = -(y.y * s);              /* X[1023 - 2k]                   */
+            const cplx d = twl[lane + 64 * k3];
+            a[k3] = fma(v[k3].x, d.x, -(v[k3].y * d.y));      /* Re y = X[2k], k = lane + 64 k3 */
+            b[k3] = -fma(v[k3].x, d.y, v[k3].y * d.x);        /* -Im y = X[1023 - 2k]           */
             mx = fmax(mx, fmax(fabs(a[k3]), fabs(b[k3])));
         }
         double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);
@@ -136,10 +151,27 @@ void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8
 {
     if (n_cf <= 0)
         return;
-    long long blocks = (n_cf + MDCT2_WAVES - 1) / MDCT2_WAVES;
-    const long long cap = (long long)n_cu * 2;            /* 2 workgroups per CU (LDS) */
-    if (blocks > cap)
-        blocks = cap;
-    hipLaunchKernelGGL(k_mdct_long_v2, dim3((unsigned)blocks), dim3(64 * MDCT2_WAVES), 0, st, T, in, flags,
-                       n_cf, skip_cur, lines, scale_out, scale_stride);
+    /* geometry variants (PACX_MDCT_VARIANT, for experiments; default 0) */
+    static int variant = -1;
+    if (variant < 0) {
+        const char *e = getenv("PACX_MDCT_VARIANT");
+        variant = e ? atoi(e) : 0;
+    }
+#define LAUNCH(W, MW, PER_CU)                                                                         \
+    do {                                                                                              \
+        long long blocks = (n_cf + (W) - 1) / (W);                                                    \
+        const long long cap = (long long)n_cu * (PER_CU);                                             \
+        if (blocks > cap)                                                                             \
+            blocks = cap;                                                                             \
+        hipLaunchKernelGGL((k_mdct_long_v2<W, MW>), dim3((unsigned)blocks), dim3(64 * (W)), 0, st, T, \
+                           in, flags, n_cf, skip_cur, lines, scale_out, scale_stride);                \
+    } while (0)
+    switch (variant) {
+    case 1: LAUNCH(8, 2, 1); break;      /* 8 waves/CU, 256 VGPRs            */
+    case 2: LAUNCH(4, 2, 2); break;      /* 8 waves/CU in two workgroups     */
+    case 3: LAUNCH(4, 3, 3); break;      /* 12 waves/CU in three workgroups  */
+    case 4: LAUNCH(8, 4, 2); break;      /* 16 waves/CU, 128 VGPRs (LDS 81920 B x 2) */
+    default: LAUNCH(6, 3, 2); break;     /* 12 waves/CU, 168 VGPRs           */
+    }
+#undef LAUNCH
 }

@@ -130,18 +130,18 @@ __device__ __forceinline__ void fft512(cplx v[8], cplx *tile, const cplx *__rest
  * gfx950, tools/proto_wave_fft.py:fft512n is the model):
  *   X1 write  row k1, col lane ^ 8 k1        X1 read  row g, col 8 (n2 ^ g) + r
  *   X2 write  row g,  col 8 k2 + (r ^ g)     X2 read  row lane&7, col 8 (lane>>3) + (n3 ^ (lane&7))
- * w1[k-1] = W512^(lane k): per-lane constants the caller keeps in registers
- * across frames; w2[(k-1) w2_stride] = W64^((lane&7) k), k = 1..7 (LDS table).
+ * w1[(k-1) w1_stride] = W512^(lane k), w2[(k-1) w2_stride] = W64^((lane&7) k),
+ * k = 1..7: per-lane twiddles, normally LDS tables shared by the workgroup.
  */
 #define WFFT_TILE_N 512
-__device__ __forceinline__ void fft512n(cplx v[8], cplx *tile, const cplx w1[7], const cplx *w2, int w2_stride,
-                                        int lane)
+__device__ __forceinline__ void fft512n(cplx v[8], cplx *tile, const cplx *w1, int w1_stride, const cplx *w2,
+                                        int w2_stride, int lane)
 {
     const int g = lane >> 3, r = lane & 7;
     dft8(v);
 #pragma unroll
     for (int k1 = 1; k1 < 8; ++k1)
-        v[k1] = c_mul(v[k1], w1[k1 - 1]);
+        v[k1] = c_mul(v[k1], w1[(k1 - 1) * w1_stride]);
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1)
         tile[64 * k1 + (lane ^ (8 * k1))] = v[k1];
