@@ -27,17 +27,40 @@
 
 /* WAVES waves per workgroup (8 KB tile each + 17 KB of tables), MINW = waves per
    SIMD the register allocator has to leave room for */
-template <int MDCT2_WAVES, int MINW>
+template <int MDCT2_WAVES, int MINW, bool DBUF>
 __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
     PacxTables T, PacxPcmView in, const uint8_t *__restrict__ flags, long long n_cf, int skip_cur,
     double *__restrict__ lines, int32_t *__restrict__ scale_out, int scale_stride)
 {
     __shared__ __attribute__((aligned(16))) cplx tiles[MDCT2_WAVES][WFFT_TILE_N];
+    /* DBUF: PCM has a landing buffer of its own, so the next frame's DMA starts
+       right after the fold and has the whole FFT + epilogue to arrive */
+    __shared__ __attribute__((aligned(16))) short rawbuf[DBUF ? MDCT2_WAVES : 1][DBUF ? PACX_N_LONG : 8];
     __shared__ __attribute__((aligned(16))) cplx twl[512];
     __shared__ __attribute__((aligned(16))) double wsin[1024];
     __shared__ __attribute__((aligned(16))) cplx w64[7][8];        /* W64^(r k2), k2 = 1..7 */
     __shared__ __attribute__((aligned(16))) cplx w1s[7][64];       /* W512^(lane k1), k1 = 1..7 */
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    cplx *tile = tiles[wv];
+    short *raw = DBUF ? rawbuf[wv] : (short *)tile;
+    const unsigned n_ch = (unsigned)in.n_ch;
+    const unsigned stride = gridDim.x * MDCT2_WAVES;
+    const unsigned total = (unsigned)n_cf;
+    const short *base = (const short *)in.base;
+    /* PCM goes HBM -> LDS without touching VGPRs (global_load_lds_dwordx4:
+       wave-uniform LDS base + lane*16, per-lane global address) */
+    auto stage = [&](unsigned c) {
+        const unsigned f = c / n_ch, ch = c - f * n_ch;
+        const int4 *src = (const int4 *)(base + (long long)f * in.frame_stride + (long long)ch * in.ch_stride);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane + 64 * j),
+                                             (__attribute__((address_space(3))) void *)((char *)raw + 1024 * j),
+                                             16, 0, 0);
+    };
+    unsigned cf = blockIdx.x * MDCT2_WAVES + wv;
+    if (cf < total)
+        stage(cf);                    /* first frame's PCM flies while the tables load */
     for (int i = tid; i < 512; i += 64 * MDCT2_WAVES)
         twl[i] = T.tw_long[i];
     /* window table with the PCM scale 2/65535 (coder/pcmfile.py:89-99 mapping)
@@ -57,69 +80,83 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
 
     const cplx *w1 = &w1s[0][lane];                                /* w1[64 (k1-1)] */
     const cplx *w2 = &w64[0][lane & 7];                            /* w2[8 (k2-1)] */
-    cplx *tile = tiles[wv];
-    short *raw = (short *)tile;
-    const unsigned n_ch = (unsigned)in.n_ch;
-    const unsigned stride = gridDim.x * MDCT2_WAVES;
-    const unsigned total = (unsigned)n_cf;
-    const short *base = (const short *)in.base;
-
-    /* PCM goes HBM -> LDS without touching VGPRs (global_load_lds_dwordx4:
-       wave-uniform LDS base + lane*16, per-lane global address) */
-    auto stage = [&](unsigned c) {
-        const unsigned f = c / n_ch, ch = c - f * n_ch;
-        const int4 *src = (const int4 *)(base + (long long)f * in.frame_stride + (long long)ch * in.ch_stride);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane + 64 * j),
-                                             (__attribute__((address_space(3))) void *)((char *)tile + 1024 * j),
-                                             16, 0, 0);
-    };
-    unsigned cf = blockIdx.x * MDCT2_WAVES + wv;
-    if (cf < total)
-        stage(cf);
+    int younger = -1;                /* vector-memory ops issued after the DMA being waited for */
     for (; cf < total; cf += stride) {
         const unsigned fl = flags ? flags[cf / n_ch] : 0u;
         /* frames this kernel leaves to others: short-coded (CUR) ones when asked
            to, and long frames with a transition window (k_mdct_long takes them) */
         const bool mine = !(skip_cur && (fl & 2u)) && pacx_window_kind(fl) == 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* this frame's PCM has landed in LDS */
+        /* this frame's PCM must have landed in LDS.  vmcnt counts loads, stores and
+           LDS-DMA together in issue order: with DBUF the DMA is older than the
+           previous frame's 8 (+1) line stores, so only they may stay in flight */
+        if (DBUF && younger == 9)
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (DBUF && younger == 8)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_fence();
         const int Q = PACX_N_LONG / 4, M = PACX_M_LONG;
         cplx v[8];
         /* sine window: w[2047-i] = w[i], so two table values serve each n.
-           code(): int16 -> double, with -32768 -> 0 as the reference maps it */
-        auto code = [&](int i) -> double {
-            const int c = raw[i];
-            return (double)(c == -32768 ? 0 : c);
-        };
+           The codes enter as integers (scale folded into wsin).  The reference
+           maps the code -32768 to 0 (coder/pcmfile.py:93-97 masks the magnitude
+           with 32767): rather than test every sample, track the minimum and,
+           only for a frame that has one, rewrite them in LDS and fold again. */
+        for (int pass = 0;; ++pass) {
+            int lowest = 0;
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) {
-            const int n = lane + 64 * n1;
-            double re, im;
-            if (n1 < 4) {
-                const int i0 = 3 * Q - 1 - 2 * n, i1 = 3 * Q + 2 * n, i2 = Q - 1 - 2 * n, i3 = Q + 2 * n;
-                const double wa = wsin[i3], wb = wsin[i2];       /* = w[i0], w[i1] */
-                re = -fma(wb, code(i1), wa * code(i0));
-                im = fma(wb, code(i2), -(wa * code(i3)));
-            } else {
-                const int m = 2 * n - Q;
-                const int i0 = m, i1 = M - 1 - m, i2 = 2 * Q + m, i3 = 4 * Q - 1 - m;
-                const double wa = wsin[i0], wb = wsin[i1];       /* = w[i3], w[i2] */
-                re = fma(wa, code(i0), -(wb * code(i1)));
-                im = -fma(wb, code(i2), wa * code(i3));
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const int n = lane + 64 * n1;
+                auto code = [&](int i) -> double {
+                    const int c = raw[i];
+                    lowest = min(lowest, c);
+                    return (double)c;
+                };
+                double re, im;
+                if (n1 < 4) {
+                    const int i0 = 3 * Q - 1 - 2 * n, i1 = 3 * Q + 2 * n, i2 = Q - 1 - 2 * n, i3 = Q + 2 * n;
+                    const double wa = wsin[i3], wb = wsin[i2];       /* = w[i0], w[i1] */
+                    re = -fma(wb, code(i1), wa * code(i0));
+                    im = fma(wb, code(i2), -(wa * code(i3)));
+                } else {
+                    const int m = 2 * n - Q;
+                    const int i0 = m, i1 = M - 1 - m, i2 = 2 * Q + m, i3 = 4 * Q - 1 - m;
+                    const double wa = wsin[i0], wb = wsin[i1];       /* = w[i3], w[i2] */
+                    re = fma(wa, code(i0), -(wb * code(i1)));
+                    im = -fma(wb, code(i2), wa * code(i3));
+                }
+                v[n1] = c_mul(make_double2(re, im), twl[n]);
             }
-            v[n1] = c_mul(make_double2(re, im), twl[n]);
+            if (pass || !__ballot(lowest == -32768))
+                break;
+            /* rare: rewrite the -32768 codes of this frame to 0 in LDS and fold again */
+            wave_lds_fence();
+            unsigned *rw = (unsigned *)raw;
+            for (int j = 0; j < 16; ++j) {
+                unsigned x = rw[lane + 64 * j];
+                if ((x & 0xFFFFu) == 0x8000u) x &= 0xFFFF0000u;
+                if ((x >> 16) == 0x8000u) x &= 0x0000FFFFu;
+                rw[lane + 64 * j] = x;
+            }
+            wave_lds_fence();
         }
-        wave_lds_fence();                 /* raw samples consumed: the tile may be overwritten */
+        wave_lds_fence();                 /* raw samples consumed: their LDS may be overwritten */
+        if (DBUF) {
+            if (cf + stride < total)
+                stage(cf + stride);
+            younger = 0;
+        }
         fft512n(v, tile, w1, 64, w2, 8, lane);
-
-        /* the tile is free again: start the next frame's PCM on its way now, it
-           lands during the epilogue and the other waves' work */
-        if (cf + stride < total)
-            stage(cf + stride);
+        if (!DBUF) {
+            /* the tile is free again: start the next frame's PCM on its way now, it
+               lands during the epilogue and the other waves' work */
+            if (cf + stride < total)
+                stage(cf + stride);
+        }
         if (!mine)
             continue;
+        younger = scale_out ? 9 : 8;
 
         double a[8], b[8];
         double mx = 0.0;
@@ -157,21 +194,23 @@ void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8
         const char *e = getenv("PACX_MDCT_VARIANT");
         variant = e ? atoi(e) : 0;
     }
-#define LAUNCH(W, MW, PER_CU)                                                                         \
+#define LAUNCH(W, MW, PER_CU, DB)                                                                        \
     do {                                                                                              \
         long long blocks = (n_cf + (W) - 1) / (W);                                                    \
         const long long cap = (long long)n_cu * (PER_CU);                                             \
         if (blocks > cap)                                                                             \
             blocks = cap;                                                                             \
-        hipLaunchKernelGGL((k_mdct_long_v2<W, MW>), dim3((unsigned)blocks), dim3(64 * (W)), 0, st, T, \
+        hipLaunchKernelGGL((k_mdct_long_v2<W, MW, DB>), dim3((unsigned)blocks), dim3(64 * (W)), 0, st, T, \
                            in, flags, n_cf, skip_cur, lines, scale_out, scale_stride);                \
     } while (0)
     switch (variant) {
-    case 1: LAUNCH(8, 2, 1); break;      /* 8 waves/CU, 256 VGPRs            */
-    case 2: LAUNCH(4, 2, 2); break;      /* 8 waves/CU in two workgroups     */
-    case 3: LAUNCH(4, 3, 3); break;      /* 12 waves/CU in three workgroups  */
-    case 4: LAUNCH(8, 4, 2); break;      /* 16 waves/CU, 128 VGPRs (LDS 81920 B x 2) */
-    default: LAUNCH(6, 3, 2); break;     /* 12 waves/CU, 168 VGPRs           */
+    case 1: LAUNCH(6, 3, 2, false); break;   /* 12 waves/CU in two workgroups                 */
+    case 2: LAUNCH(4, 2, 2, false); break;   /* 8 waves/CU in two workgroups                  */
+    case 3: LAUNCH(8, 2, 1, true); break;    /* 8 waves/CU, PCM landing buffer (120 KB LDS)   */
+    case 4: LAUNCH(4, 2, 2, true); break;    /* 2 x 4 waves, landing buffer (2 x 72 KB)       */
+    case 5: LAUNCH(16, 4, 1, false); break;  /* 16 waves/CU, 128 VGPRs (152 KB LDS)           */
+    case 6: LAUNCH(12, 3, 1, false); break;  /* 12 waves/CU in one workgroup (120 KB LDS)     */
+    default: LAUNCH(8, 2, 1, false); break;  /* 8 waves/CU, one workgroup per CU              */
     }
 #undef LAUNCH
 }
