@@ -18,25 +18,44 @@
 #include "wave_fft.h"   /* wave_max */
 
 /* ---------------------------------------------------------------- bitalloc */
+/* BitAlloc, cooperatively: lanes = bands, one (sub-)block per 32-lane half wave
+ * (two per wave).  Same arithmetic, in the same order, as pacx_bit_alloc() in
+ * pacx_exact.h (the serial statement of coder/bitalloc.py:77-121, checked on the
+ * CPU against the oracle); tests compare the two on the GPU bit for bit.
+ *   - np.sum(nLines[valid]*SMR[valid]): valid bands are compacted (prefix
+ *     popcount of the ballot mask) into LDS and added in NumPy's pairwise order
+ *     (8 running sums, fixed tree, scalar tail);
+ *   - the rounding "ladder": the n_flip-th smallest positive fraction is found
+ *     by an all-pairs rank count over the half wave instead of a sort;
+ *   - np.round -> rint (half to even); the 200-pass guard is kept.
+ */
+__device__ __forceinline__ int half_sum_i(int v)
+{
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 32);
+    return v;
+}
+
 __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
                                                 long long n_cf, int short_blocks, int mixed,
                                                 const double *__restrict__ smr,
                                                 int32_t *__restrict__ bit_alloc,
                                                 uint32_t *__restrict__ status)
 {
-    const long long tid = (long long)blockIdx.x * 64 + threadIdx.x;
-    /* one lane per (cf, sub-block) when short blocks can occur, else one per cf */
+    __shared__ double cp[2][32];
+    const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
     const bool dense = !short_blocks && !(mixed && flags);
-    const long long cf = dense ? tid : tid / PACX_SUB;
-    const int sb = dense ? 0 : (int)(tid % PACX_SUB);
-    if (cf >= n_cf)
-        return;
-    const unsigned fl = flags ? flags[cf / n_ch] : 0u;
+    const long long unit = (long long)blockIdx.x * 2 + half;
+    const long long cf = dense ? unit : unit / PACX_SUB;
+    const int sb = dense ? 0 : (int)(unit % PACX_SUB);
+    bool alive = cf < n_cf;
+    const unsigned fl = (alive && flags) ? flags[cf / n_ch] : 0u;
     const bool is_short = mixed ? ((fl & 2u) != 0) : (short_blocks != 0);
     if (!is_short && sb != 0)
-        return;
+        alive = false;
     const int nb = is_short ? T.nb_short : T.nb_long;
-    const int32_t *n_lines = is_short ? T.band_lines_short : T.band_lines_long;
+    const int32_t *__restrict__ n_lines = is_short ? T.band_lines_short : T.band_lines_long;
     const double budget = pacx_bit_budget(T.target_bps, is_short ? PACX_M_SHORT : PACX_M_LONG,
                                           is_short ? 1 : 0, (fl & 5u) != 0, T.n_scale_bits,
                                           T.n_mant_size_bits, nb);
@@ -44,17 +63,105 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
     if (max_mant > 16)
         max_mant = 16;
     const long long off = cf * T.band_stride + (is_short ? sb * nb : 0);
-    double s[PACX_MAX_BANDS];
-    int32_t nl[PACX_MAX_BANDS], bits[PACX_MAX_BANDS];
-    for (int b = 0; b < nb; ++b) {
-        s[b] = smr[off + b];
-        nl[b] = n_lines[b];
+    const bool has = alive && l < nb;
+    const double s = has ? smr[off + l] : 0.0;
+    const int nl = has ? n_lines[l] : 0;
+    const unsigned lt_mask = (1u << l) - 1u;
+    double *c = cp[half];
+
+    int bits = 0, n_flip = 0, passes = 0, cap = 0;
+    unsigned dropped = 0;
+    bool done = !alive;
+    while (__ballot(!done)) {
+        const bool valid = has && !((dropped >> l) & 1u);
+        const unsigned vmask = (unsigned)(__ballot(valid) >> (32 * half));
+        const int nv = __popc(vmask);
+        const int pos = __popc(vmask & lt_mask);
+        const int total_i = half_sum_i(valid ? nl : 0);
+        double total = (double)total_i;
+        if (total_i == 0)
+            total = total + 1e-12;
+        if (valid)
+            c[pos] = (double)nl * s;
+        wave_lds_fence();
+        /* np.sum of c[0..nv) */
+        double sum;
+        if (nv < 8) {
+            sum = -0.0;
+            for (int i = 0; i < nv; ++i)
+                sum = sum + c[i];
+        } else {
+            const int n8 = nv - (nv & 7);
+            double r = 0.0;
+            if (l < 8) {
+                r = c[l];
+                for (int i = 8; i < n8; i += 8)
+                    r = r + c[i + l];
+            }
+            double t = r + __shfl_down(r, 1, 32);           /* lanes 0,2,4,6: r0+r1, r2+r3, ... */
+            double u = t + __shfl_down(t, 2, 32);           /* lanes 0,4 */
+            sum = u + __shfl_down(u, 4, 32);                /* lane 0 */
+            for (int i = n8; i < nv; ++i)
+                sum = sum + c[i];
+            sum = __shfl(sum, 0, 32);
+        }
+        wave_lds_fence();
+        const double mean = sum / total;
+        const double want = budget / total + (1.0 / PACX_DB_PER_BIT) * (s - mean);
+        const double frac = (want - floor(want)) - 0.5;
+        const bool posf = valid && frac > 0.0;
+        const unsigned pmask = (unsigned)(__ballot(posf) >> (32 * half));
+        const int nd = __popc(pmask);
+        int new_bits = bits;
+        int new_flip = n_flip;
+        if (n_flip > nd) {
+            new_flip = n_flip - 1;                           /* bits keep their previous values */
+        } else {
+            double level = 0.0;
+            if (n_flip > 0) {                                /* ladder[n_flip-1]: rank select */
+                int lt = 0, le = 0;
+                for (int k = 0; k < 32; ++k) {
+                    const double fk = __shfl(frac, k, 32);
+                    if ((pmask >> k) & 1u) {
+                        lt += fk < frac;
+                        le += fk <= frac;
+                    }
+                }
+                const bool sel = posf && lt <= n_flip - 1 && n_flip - 1 < le;
+                const unsigned smask = (unsigned)(__ballot(sel) >> (32 * half));
+                level = __shfl(frac, smask ? __builtin_ctz(smask) : 0, 32);
+            }
+            if (valid)
+                new_bits = (int)rint(want - level);
+        }
+        if (new_bits > max_mant)
+            new_bits = max_mant;
+        const bool drop = has && new_bits < 2;
+        if (drop || !has)
+            new_bits = 0;
+        const unsigned now = (unsigned)(__ballot(drop) >> (32 * half));
+        const int spent = half_sum_i(new_bits * nl);
+        if (!done) {
+            const bool stable = (now == dropped);
+            bits = new_bits;
+            dropped = now;
+            n_flip = new_flip;
+            if (stable && (double)spent <= budget) {
+                done = true;
+            } else {
+                if (stable && (double)spent > budget)
+                    n_flip += 1;
+                ++passes;
+                if (passes > PACX_ALLOC_MAX_PASSES) {
+                    cap = 1;
+                    done = true;
+                }
+            }
+        }
     }
-    int cap = 0;
-    pacx_bit_alloc(budget, max_mant, nb, nl, s, bits, &cap);
-    for (int b = 0; b < nb; ++b)
-        bit_alloc[off + b] = bits[b];
-    if (cap && status)
+    if (has)
+        bit_alloc[off + l] = bits;
+    if (alive && cap && status && l == 0)
         atomicOr(&status[cf], 4u);
 }
 
@@ -347,8 +454,8 @@ void pacx_launch_bitalloc(const PacxTables &T, const uint8_t *flags, int n_ch, l
     if (n_cf <= 0)
         return;
     const bool dense = !short_blocks && !(mixed && flags);
-    const long long threads = dense ? n_cf : n_cf * PACX_SUB;
-    hipLaunchKernelGGL(k_bitalloc, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, T, flags, n_ch,
+    const long long units = dense ? n_cf : n_cf * PACX_SUB;       /* two units per wave */
+    hipLaunchKernelGGL(k_bitalloc, dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st, T, flags, n_ch,
                        n_cf, short_blocks, mixed, smr, bit_alloc, status);
 }
 

@@ -200,6 +200,47 @@ def test_bitalloc_and_quantize_stage_kernels(A, torch, stages):
                 assert not mant[i][~keep].any()
 
 
+def test_bitalloc_cooperative_vs_serial_random(A, torch):
+    """The lanes=bands BitAlloc kernel against the serial statement of the same
+    algorithm (k_bitalloc_generic -> pacx_bit_alloc, itself checked on the CPU
+    against the oracle) on random SMRs, ties and hard budgets, long and short."""
+    rng = np.random.default_rng(77)
+    for sr in (48000, 44100):
+        enc = enc_for(A, sr)
+        for short in (False, True):
+            bands = enc.sfBandsShort if short else enc.sfBands
+            nb = bands.nBands
+            n = 12000
+            spread = rng.choice([2.0, 10.0, 30.0, 80.0], size=(n, 1))
+            smr = rng.standard_normal((n, nb)) * spread + rng.uniform(-40, 40, size=(n, 1))
+            smr[::7] = np.round(smr[::7])                 # ties on the rounding ladder
+            smr[::11] = smr[::11, :1]                      # all bands equal
+            smr[5::13] -= 150                              # starved: everything dropped
+            flags = rng.integers(0, 8, n).astype(np.uint8)
+            flags = (flags & 5) | (2 if short else 0)
+            full = np.zeros((n, enc.band_stride))
+            if short:
+                for sb in range(8):
+                    full[:, sb * nb:(sb + 1) * nb] = smr + sb     # eight different problems per frame
+            else:
+                full[:, :nb] = smr
+            got, status = enc.bit_alloc(torch.as_tensor(full, device=enc.device), 1, flags, short=short)
+            got = got.cpu().numpy()
+            p = po.make_params(sr, 1, 128)
+            if short:
+                p.nMDCTLines = 128
+            budget = np.array([po.bit_budget(p, f & 1, (f >> 1) & 1, (f >> 2) & 1) for f in flags])
+            for sb in range(8 if short else 1):
+                probs = smr + sb if short else smr
+                want = enc.bit_alloc_generic(torch.as_tensor(budget, device=enc.device), 16, bands.nLines,
+                                             torch.as_tensor(probs, device=enc.device)).cpu().numpy()
+                assert np.array_equal(got[:, sb * nb:(sb + 1) * nb], want), (sr, short, sb)
+            # and a slice against the oracle itself
+            for i in range(0, n, 397):
+                ref = po.bit_alloc(budget[i], 16, nb, bands.nLines, smr[i])
+                assert got[i, :nb].tolist() == ref.tolist()
+
+
 # --------------------------------------------------------------- whole path
 @pytest.mark.parametrize("kind", ["long", "short"])
 def test_encode_golden_codes(A, torch, stages, kind):
