@@ -230,117 +230,185 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 
 /* ------------------------------------------------------ mask + per-band SMR */
 /* One wave per unit: a long cf (M = 1024, 16 lines per lane) or one short
- * sub-block (M = 128, 2 lines per lane; unit = 8*cf + sub-block).
+ * sub-block (M = 128, 2 lines per lane; unit = 8*cf + sub-block).  Persistent
+ * workgroups of MASK_WAVES waves walk the units; Bark and threshold-in-quiet
+ * tables sit in LDS once per workgroup.
  *
- * Lines are walked in chunks of 64 consecutive lines (one per lane), i.e. one
- * contiguous Bark interval [zlo, zhi] per chunk.  For every chunk the maskers
- * are first screened 64 at a time (one masker per lane): a masker whose curve
- * cannot rise above (min threshold-in-quiet of the chunk - 0.01 dB) anywhere in
- * [zlo, zhi] cannot change max(quiet, SPL(Intensity(.))) there and is skipped;
- * the survivors (ballot mask) are evaluated for all 64 lines with exactly the
- * reference's operation order.  The screen is exact: spreading curves fall
- * monotonically away from the masker, and the SPL/Intensity round trip adds at
- * most 1.2e-5 dB at levels >= the lowest threshold in quiet (-5 dB).
+ * Lines are handled in chunks of 64 consecutive lines (one per lane), i.e. one
+ * contiguous Bark interval [zlo, zhi] per chunk.  Maskers are taken 64 at a
+ * time, one per lane, straight from HBM into registers; for every chunk each
+ * lane screens ITS masker: if the masker's curve cannot rise, anywhere in
+ * [zlo, zhi], above (lowest threshold in quiet of the chunk - 0.01 dB) it cannot
+ * change max(quiet, SPL(Intensity(max_p .))) there and is skipped.  Survivors
+ * (ballot mask, ~8 % of the masker x chunk pairs on the bench workload) are
+ * broadcast from the screening lane's registers (v_readlane) and evaluated for
+ * all 64 lines with exactly the reference's operation order.  The screen is
+ * exact: spreading curves fall monotonically away from the masker and the
+ * SPL/Intensity round trip adds at most 1.2e-5 dB at levels >= the lowest
+ * threshold in quiet (-5 dB).
  */
+#define MASK_WAVES 8
+
 template <int M>
-__global__ __launch_bounds__(64) void k_mask(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
-                                            long long n_units, int mixed,
-                                            const PacxPeak *__restrict__ peaks,
-                                            const int32_t *__restrict__ n_peaks,
-                                            const double *__restrict__ lines,
-                                            double *__restrict__ smr, double *__restrict__ thr_out)
+__global__ __launch_bounds__(64 * MASK_WAVES, 4) void k_mask(PacxTables T, const uint8_t *__restrict__ flags,
+                                                         int n_ch, long long n_units, int mixed,
+                                                         const PacxPeak *__restrict__ peaks,
+                                                         const int32_t *__restrict__ n_peaks,
+                                                         const double *__restrict__ lines,
+                                                         double *__restrict__ smr,
+                                                         double *__restrict__ thr_out)
 {
     constexpr bool SHORT = (M == PACX_M_SHORT);
     constexpr int PER = M / 64;
-    constexpr int MAXP = SHORT ? 64 : PACX_MAX_PEAKS;
-    constexpr int LDS_DOUBLES = (3 * MAXP > M) ? 3 * MAXP : M;
-    __shared__ __attribute__((aligned(16))) double lds[LDS_DOUBLES];   /* maskers, later the SMR terms */
-    const int lane = threadIdx.x;
-    const long long unit = blockIdx.x;
-    if (unit >= n_units)
-        return;
-    const long long cf = SHORT ? unit / PACX_SUB : unit;
-    const int sb = SHORT ? (int)(unit % PACX_SUB) : 0;
-    if (mixed) {
-        const unsigned fl = flags ? flags[cf / n_ch] : 0u;
-        if (SHORT != ((fl & 2u) != 0))
-            return;
+    __shared__ __attribute__((aligned(16))) double bark_s[M];
+    __shared__ __attribute__((aligned(16))) double quiet_s[M];
+    __shared__ __attribute__((aligned(16))) double chunk_c[PER][4];        /* zlo-0.5, zhi+0.5, qmin-0.01 */
+    __shared__ __attribute__((aligned(16))) double bufs[MASK_WAVES][M];    /* best, then mdct_spl - thr */
+    __shared__ __attribute__((aligned(16))) double xbufs[MASK_WAVES][M];   /* this unit's MDCT lines     */
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {
+        const double *__restrict__ bark = SHORT ? T.bark_short : T.bark_long;
+        const double *__restrict__ quiet = SHORT ? T.thresh_short : T.thresh_long;
+        for (int i = tid; i < M; i += 64 * MASK_WAVES) {
+            bark_s[i] = bark[i];
+            quiet_s[i] = quiet[i];
+        }
     }
-    const double *__restrict__ bark = SHORT ? T.bark_short : T.bark_long;
-    const double *__restrict__ quiet = SHORT ? T.thresh_short : T.thresh_long;
-    const PacxPeak *__restrict__ pk = peaks + cf * PACX_MAX_PEAKS + sb * 64;
-    const int np = n_peaks[cf * PACX_SUB + sb];
-    const double *__restrict__ x = lines + cf * PACX_M_LONG + sb * PACX_M_SHORT;
-    PacxPeak *pks = (PacxPeak *)lds;
-    for (int p = lane; p < np; p += 64)
-        pks[p] = pk[p];
     __syncthreads();
-
-    double dif[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int k = lane + 64 * j;
-        const double zk = bark[k], qk = quiet[k];
-        const double zlo = bark[64 * j], zhi = bark[64 * j + 63];
-        double qmin = qk;
+    for (int j = wv; j < PER; j += MASK_WAVES) {
+        double qm = quiet_s[64 * j + lane];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
-            qmin = fmin(qmin, __shfl_xor(qmin, off, 64));
-        qmin -= 0.01;
-        double best = -INFINITY;
-        for (int pb = 0; pb < np; pb += 64) {
-            bool live = false;
-            if (pb + lane < np) {
-                const PacxPeak q = pks[pb + lane];
-                double ub = 0.0;                       /* best case of the spreading gain on [zlo, zhi] */
-                if (q.z < zlo - 0.5)
-                    ub = q.slope * ((zlo - q.z) - 0.5);
-                else if (q.z > zhi + 0.5)
-                    ub = -27.0 * ((q.z - zhi) - 0.5);
-                live = (q.slope > 0.0) || ((q.spl - 16.0) + ub > qmin);
-            }
-            unsigned long long todo = __ballot(live);
-            while (todo) {
-                const int b = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const PacxPeak q = pks[pb + b];        /* wave-uniform address: LDS broadcast */
-                const double dz = zk - q.z;
-                const double a = fabs(dz) - 0.5;
-                double gain = 0.0;
-                if (dz < -0.5)
-                    gain = -27.0 * a;
-                else if (dz > 0.5)
-                    gain = q.slope * a;
-                best = fmax(best, (q.spl + gain) - 16.0);
-            }
+            qm = fmin(qm, __shfl_xor(qm, off, 64));
+        if (lane == 0) {
+            chunk_c[j][0] = bark_s[64 * j] - 0.5;
+            chunk_c[j][1] = bark_s[64 * j + 63] + 0.5;
+            chunk_c[j][2] = qm - 0.01;
         }
-        double thr = qk;
-        if (best > -INFINITY) {
-            const double inten = pow(10.0, (best - 96.0) / 10.0);
-            thr = fmax(thr, pacx_spl_array(inten));
-        }
-        if (thr_out)
-            thr_out[cf * PACX_M_LONG + sb * PACX_M_SHORT + k] = thr;
-        const double v = x[k];
-        dif[j] = pacx_spl_array((v * v) * 4.0) - thr;
     }
-    __syncthreads();                                   /* maskers no longer needed */
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
-        lds[lane + 64 * j] = dif[j];
     __syncthreads();
+
+    double *buf = bufs[wv];
+    double *xbuf = xbufs[wv];
     const int nb = SHORT ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
-    double *__restrict__ out = smr + cf * T.band_stride + sb * T.nb_short;
-    for (int b = 0; b < nb; ++b) {
-        const int lo = lower[b], hi = lo + count[b];
-        double m = -INFINITY;
-        for (int k = lo + lane; k < hi; k += 64)
-            m = fmax(m, lds[k]);
-        m = wave_max(m);
-        if (lane == 0)
-            out[b] = m;
+
+    for (long long unit = (long long)blockIdx.x * MASK_WAVES + wv; unit < n_units;
+         unit += (long long)gridDim.x * MASK_WAVES) {
+        const long long cf = SHORT ? unit / PACX_SUB : unit;
+        const int sb = SHORT ? (int)(unit % PACX_SUB) : 0;
+        if (mixed) {
+            const unsigned fl = flags ? flags[cf / n_ch] : 0u;
+            if (SHORT != ((fl & 2u) != 0))
+                continue;
+        }
+        const PacxPeak *__restrict__ pk = peaks + cf * PACX_MAX_PEAKS + sb * 64;
+        const int np = n_peaks[cf * PACX_SUB + sb];
+        const long long loff = cf * PACX_M_LONG + sb * PACX_M_SHORT;
+
+        /* all global loads of this unit are issued up front (lines -> LDS for the
+           per-line loop, first masker batch -> registers); later ones are
+           software-pipelined one batch ahead, so no loop iteration waits on HBM */
+        double z[PER], best[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            xbuf[lane + 64 * j] = lines[loff + lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            z[j] = bark_s[lane + 64 * j];
+            best[j] = -INFINITY;
+        }
+        PacxPeak qn;
+        qn.z = 0.0; qn.spl = -1000.0; qn.slope = 0.0;             /* padding lanes never survive */
+        if (lane < np)
+            qn = pk[lane];
+        for (int pb = 0; pb < np; pb += 64) {
+            const PacxPeak q = qn;
+            qn.z = 0.0; qn.spl = -1000.0; qn.slope = 0.0;
+            if (pb + 64 + lane < np)
+                qn = pk[pb + 64 + lane];
+            const double lvl = q.spl - 16.0;
+            /* batch summary for the cheap first screen: maskers arrive in bin order,
+               so the batch covers the Bark interval [bz_lo, bz_hi]; no masker in it is
+               louder than b_lvl or decays upward slower than b_slope */
+            const int n_in = min(64, np - pb);
+            const double bz_lo = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q.z), 0),
+                                                  __builtin_amdgcn_readlane(__double2loint(q.z), 0));
+            const double bz_hi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q.z), n_in - 1),
+                                                  __builtin_amdgcn_readlane(__double2loint(q.z), n_in - 1));
+            const double b_lvl = wave_max(lvl);
+            const double b_slope = wave_max(q.slope);
+            const int zl = __double2loint(q.z), zh = __double2hiint(q.z);
+            const int sl = __double2loint(q.spl), sh = __double2hiint(q.spl);
+            const int ul = __double2loint(q.slope), uh = __double2hiint(q.slope);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                /* keep the 3 x 16 chunk constants in LDS (broadcast reads), not hoisted
+                   into 96 registers */
+                asm volatile("" ::: "memory");
+                const double lo_edge = chunk_c[j][0], hi_edge = chunk_c[j][1], need = chunk_c[j][2];
+                /* whole batch out of reach of this chunk?  (wave-uniform test) */
+                if (b_slope <= 0.0) {
+                    double bb = 0.0;
+                    if (bz_hi < lo_edge)
+                        bb = b_slope * (lo_edge - bz_hi);
+                    else if (bz_lo > hi_edge)
+                        bb = -27.0 * (bz_lo - hi_edge);
+                    if (b_lvl + bb <= need)
+                        continue;
+                }
+                /* best case of the spreading gain on the chunk (branch-free: at most one
+                   of the two distances is positive) */
+                const double ub = q.slope * fmax(lo_edge - q.z, 0.0) + -27.0 * fmax(q.z - hi_edge, 0.0);
+                const bool live = (q.slope > 0.0 && q.spl > -1000.0) || (lvl + ub > need);
+                unsigned long long todo = __ballot(live);
+                while (todo) {
+                    const int b = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const double pz = __hiloint2double(__builtin_amdgcn_readlane(zh, b), __builtin_amdgcn_readlane(zl, b));
+                    const double ps = __hiloint2double(__builtin_amdgcn_readlane(sh, b), __builtin_amdgcn_readlane(sl, b));
+                    const double pu = __hiloint2double(__builtin_amdgcn_readlane(uh, b), __builtin_amdgcn_readlane(ul, b));
+                    /* gain = -27 a below the masker, pu a above, 0 inside +-0.5 Bark
+                       (a = |dz| - 0.5): select the slope by the sign of dz and clamp a
+                       at 0 -- same products as the reference's masked assignments
+                       (coder/psychoac.py:92-94), no divergent branches */
+                    const double dz = z[j] - pz;
+                    const double a = fmax(fabs(dz) - 0.5, 0.0);
+                    const double gain = (dz < 0.0 ? -27.0 : pu) * a;
+                    best[j] = fmax(best[j], (ps + gain) - 16.0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            buf[lane + 64 * j] = best[j];
+        wave_lds_fence();
+        /* per line: round trip of the winner, max with quiet, SMR term */
+#pragma unroll 1
+        for (int j = 0; j < PER; ++j) {
+            const int k = lane + 64 * j;
+            const double bst = buf[k];
+            double thr = quiet_s[k];
+            if (bst > -INFINITY)
+                thr = fmax(thr, pacx_spl_of_intensity_of(bst));
+            if (thr_out)
+                thr_out[loff + k] = thr;
+            const double v = xbuf[k];
+            buf[k] = pacx_spl_array((v * v) * 4.0) - thr;
+        }
+        wave_lds_fence();
+        double *__restrict__ out = smr + cf * T.band_stride + sb * T.nb_short;
+        for (int b = 0; b < nb; ++b) {
+            const int lo = lower[b], hi = lo + count[b];
+            double m = -INFINITY;
+            for (int k = lo + lane; k < hi; k += 64)
+                m = fmax(m, buf[k]);
+            m = wave_max(m);
+            if (lane == 0)
+                out[b] = m;
+        }
+        wave_lds_fence();
     }
 }
 
@@ -373,14 +441,24 @@ void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int
 
 void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
                       int short_blocks, int mixed, const PacxPeak *peaks, const int32_t *n_peaks,
-                      const double *lines, double *smr, double *thr_out, hipStream_t st)
+                      const double *lines, double *smr, double *thr_out, int n_cu, hipStream_t st)
 {
     if (n_cf <= 0)
         return;
-    if (!short_blocks || mixed)
-        hipLaunchKernelGGL((k_mask<PACX_M_LONG>), dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch,
-                           n_cf, mixed, peaks, n_peaks, lines, smr, thr_out);
-    if (short_blocks || mixed)
-        hipLaunchKernelGGL((k_mask<PACX_M_SHORT>), dim3((unsigned)(n_cf * PACX_SUB)), dim3(64), 0, st, T,
-                           flags, n_ch, n_cf * PACX_SUB, mixed, peaks, n_peaks, lines, smr, thr_out);
+    /* persistent grids: two 8-wave workgroups per CU for the long kernel (80 KB LDS each) */
+    if (!short_blocks || mixed) {
+        long long blocks = (n_cf + MASK_WAVES - 1) / MASK_WAVES;
+        if (blocks > 2LL * n_cu)
+            blocks = 2LL * n_cu;
+        hipLaunchKernelGGL((k_mask<PACX_M_LONG>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T, flags,
+                           n_ch, n_cf, mixed, peaks, n_peaks, lines, smr, thr_out);
+    }
+    if (short_blocks || mixed) {
+        const long long units = n_cf * PACX_SUB;
+        long long blocks = (units + MASK_WAVES - 1) / MASK_WAVES;
+        if (blocks > 4LL * n_cu)
+            blocks = 4LL * n_cu;
+        hipLaunchKernelGGL((k_mask<PACX_M_SHORT>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T, flags,
+                           n_ch, units, mixed, peaks, n_peaks, lines, smr, thr_out);
+    }
 }

@@ -27,7 +27,7 @@ void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int
                       PacxPeak *peaks, int32_t *n_peaks, hipStream_t st);
 void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
                       int short_blocks, int mixed, const PacxPeak *peaks, const int32_t *n_peaks,
-                      const double *lines, double *smr, double *thr_out, hipStream_t st);
+                      const double *lines, double *smr, double *thr_out, int n_cu, hipStream_t st);
 void pacx_launch_bitalloc(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
                           int short_blocks, int mixed, const double *smr, int32_t *bit_alloc,
                           uint32_t *status, hipStream_t st);
@@ -418,7 +418,7 @@ extern "C" int pacx_smr_batch(pacx_handle *h, const pacx_pcm *in, const double *
     const int sb = short_blocks ? 1 : 0;
     pacx_launch_side(h->T, v, in->dtype, fast, nullptr, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, st);
     pacx_launch_mask(h->T, nullptr, in->n_channels, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, lines, smr,
-                     threshold, st);
+                     threshold, h->n_cu, st);
     if (n_peaks) {
         if (sb)
             HIP_TRY(h, hipMemcpyAsync(n_peaks, h->ws_npeaks, (size_t)n_cf * PACX_SUB * sizeof(int32_t),
@@ -493,7 +493,7 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
     }
     pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, st);
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_lines, h->ws_smr,
-                     nullptr, st);
+                     nullptr, h->n_cu, st);
     pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_smr, bit_alloc, status, st);
     pacx_launch_quantize(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_lines, overall_scale, PACX_SUB, bit_alloc,
                          scale_factor, mantissa, st);

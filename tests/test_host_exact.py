@@ -33,7 +33,7 @@ def hc(tmp_path_factory):
     lib.hc_bit_budget.argtypes = [ctypes.c_double] + [ctypes.c_int] * 6
     lib.hc_bit_alloc.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    for f in ("hc_spl_array", "hc_spl_scalar", "hc_bark", "hc_thresh_quiet"):
+    for f in ("hc_spl_array", "hc_spl_scalar", "hc_bark", "hc_thresh_quiet", "hc_round_trip"):
         getattr(lib, f).restype = ctypes.c_double
         getattr(lib, f).argtypes = [ctypes.c_double]
     lib.hc_window_kind.argtypes = [ctypes.c_uint]
@@ -144,6 +144,18 @@ def test_bit_alloc_random(hc):
     smr = np.full(b.nBands, -200.0)
     assert c_bit_alloc(hc, 10.0, 16, b.nLines, smr)[0].tolist() == \
         po.bit_alloc(10.0, 16, b.nBands, b.nLines, smr).tolist()
+
+
+def test_masker_round_trip(hc):
+    """SPL(Intensity(x)) as the kernels evaluate it (one exp2 + log1p series)
+    against the reference's pow/log10 evaluation, over the whole range a masker
+    curve can take, the -30 dB floor included."""
+    x = np.concatenate((np.linspace(-800, 120, 20001), np.linspace(-31.5, -29.5, 4001),
+                        [-30.0, -30.57, -30.566, 96.0, 0.0]))
+    want = po.spl_of(po.intensity_of(x.copy()))
+    got = np.array([hc.hc_round_trip(float(v)) for v in x])
+    assert np.max(np.abs(got - want)) < 5e-13
+    assert np.all(got >= -30.0) and np.all(got[x < -30.6] == -30.0)
 
 
 def test_psycho_scalars(hc, tables):
