@@ -139,6 +139,17 @@ def main():
     mdct_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / train
     mdct_gbs = n_cf * MDCT_BYTES_PER_CF / (mdct_ms * 1e-3) / 1e9
 
+    # HBM bytes of the MDCT kernel from the PMC passes of this same command
+    # (profiles/r01_mdct_pmc.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950
+    # correction applied); only quoted when the launch geometry matches
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_mdct_pmc.json")))
+        if pmc["cf_per_launch"] == n_cf:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+
     if rank == 0:
         res = {
             "metric": "audio channel-frames/s encode (48 kHz, 1024-line long blocks, 128 kb/s/ch)",
@@ -160,7 +171,10 @@ def main():
                        "sharding": f"{world} x frame-range shards, no data-path collective"},
             "roofline": {"kernel": "k_mdct_long_v2 (window + MDCT, int16 in, float64 lines out)",
                          "bound": "hbm", "achieved": mdct_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": mdct_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": mdct_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
+                                         "profiles/r01_mdct_pmc.json",
+                         "algorithmic_bytes_per_launch": n_cf * MDCT_BYTES_PER_CF,
                          "launch_ms": mdct_ms, "bytes_per_cf": MDCT_BYTES_PER_CF, "cf_per_launch": n_cf,
                          "mdct_cf_per_s": n_cf / (mdct_ms * 1e-3)},
         }
