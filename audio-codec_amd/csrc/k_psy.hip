@@ -56,6 +56,23 @@ __device__ __forceinline__ void stage_samples(typename PcmStage<DT>::elem *dst, 
     }
 }
 
+/* Hann-windowed sample i of the staged block.  int16 input: the code enters as an
+ * integer and the table carries 2/65535 (the side chain is linear up to the
+ * intensities; one rounding per product instead of two moves a bin by ~1e-16
+ * relative), with the code -32768 mapped to 0 as coder/pcmfile.py:93-97 does. */
+template <int DT>
+__device__ __forceinline__ double hann_sample(const typename PcmStage<DT>::elem *raw, int i,
+                                              const double *__restrict__ hw,
+                                              const double *__restrict__ hw_pcm)
+{
+    if constexpr (DT == 0) {
+        const int c = raw[i];
+        return hw_pcm[i] * (double)(c == -32768 ? 0 : c);
+    } else {
+        return hw[i] * raw[i];
+    }
+}
+
 /* intensity of real-FFT bin i from the packed complex spectrum Z (period P) */
 __device__ __forceinline__ double bin_intensity(const cplx *Z, int i, int P, cplx w, double norm)
 {
@@ -65,8 +82,9 @@ __device__ __forceinline__ double bin_intensity(const cplx *Z, int i, int P, cpl
     const cplx d = make_double2(a.x - bz.x, a.y + bz.y);      /* a - conj(b) */
     const cplx wd = c_mul(w, d);
     const double xr = 0.5 * (s.x + wd.y), xi = 0.5 * (s.y - wd.x);
-    const double mag = hypot(xr, xi);                         /* abs(x_fft)  */
-    return norm * (mag * mag);
+    /* |X|^2 directly; the reference squares abs(x_fft) = hypot(re, im), equal to
+       this within an ulp or two */
+    return norm * fma(xr, xr, xi * xi);
 }
 
 /* one tonal masker from bins f-1, f (coder/psychoac.py:321-328, :61-68) */
@@ -110,13 +128,13 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
     stage_samples<DT, FAST>(raw, in, cf, 0, PACX_N_LONG, lane);
     __syncthreads();
 
-    const double *__restrict__ hw = T.hann_long;
+    const double *__restrict__ hw = T.hann_long, *__restrict__ hwp = T.hann_long_pcm;
     cplx ev[8], od[8];
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) {
         const int i = 4 * (lane + 64 * n1);
-        ev[n1] = make_double2(hw[i] * PcmStage<DT>::get(raw, i), hw[i + 1] * PcmStage<DT>::get(raw, i + 1));
-        od[n1] = make_double2(hw[i + 2] * PcmStage<DT>::get(raw, i + 2), hw[i + 3] * PcmStage<DT>::get(raw, i + 3));
+        ev[n1] = make_double2(hann_sample<DT>(raw, i, hw, hwp), hann_sample<DT>(raw, i + 1, hw, hwp));
+        od[n1] = make_double2(hann_sample<DT>(raw, i + 2, hw, hwp), hann_sample<DT>(raw, i + 3, hw, hwp));
     }
     __syncthreads();                  /* raw fully consumed before anything reuses LDS */
     fft512(ev, tile, T.w512, lane);
@@ -134,23 +152,29 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
         inten[i] = bin_intensity(Z, i, 1024, T.w2048[i], T.norm_long);
     __syncthreads();
 
-    PacxPeak *__restrict__ out = peaks + cf * PACX_MAX_PEAKS;
+    /* pass 1: strict local maxima (coder/psychoac.py:312-317), their bin numbers
+       compacted in ascending order into LDS (ballot + prefix popcount) */
+    unsigned short *idx = (unsigned short *)Z;          /* Z is dead once inten is complete */
+    __syncthreads();
     int count = 0;
     for (int base = 0; base <= 1024; base += 64) {
         const int i = base + lane;
         bool pk = false;
-        double c = 0.0, l = 0.0;
         if (i >= 1 && i <= 1024) {
-            c = inten[i];
-            l = inten[i - 1];
-            pk = (c > l) && (i == 1024 || c > inten[i + 1]);
+            const double c = inten[i];
+            pk = (c > inten[i - 1]) && (i == 1024 || c > inten[i + 1]);
         }
         const unsigned long long m = __ballot(pk);
-        if (pk) {
-            const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-            out[pos] = make_peak(l, c, i, T.fstep_long);
-        }
+        if (pk)
+            idx[count + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
         count += __popcll(m);
+    }
+    __syncthreads();
+    /* pass 2: one masker per lane, 64 at a time (log10 + two atan each) */
+    PacxPeak *__restrict__ out = peaks + cf * PACX_MAX_PEAKS;
+    for (int p = lane; p < count; p += 64) {
+        const int i = idx[p];
+        out[p] = make_peak(inten[i - 1], inten[i], i, T.fstep_long);
     }
     if (lane == 0)
         n_peaks[cf * PACX_SUB] = count;
@@ -182,13 +206,13 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 
     const int g = lane >> 3, r = lane & 7;
     const E *sub = raw + g * PACX_M_SHORT;
-    const double *__restrict__ hw = T.hann_short;
+    const double *__restrict__ hw = T.hann_short, *__restrict__ hwp = T.hann_short_pcm;
     cplx ev[8], od[8];
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) {
         const int i = 4 * (r + 8 * n1);
-        ev[n1] = make_double2(hw[i] * PcmStage<DT>::get(sub, i), hw[i + 1] * PcmStage<DT>::get(sub, i + 1));
-        od[n1] = make_double2(hw[i + 2] * PcmStage<DT>::get(sub, i + 2), hw[i + 3] * PcmStage<DT>::get(sub, i + 3));
+        ev[n1] = make_double2(hann_sample<DT>(sub, i, hw, hwp), hann_sample<DT>(sub, i + 1, hw, hwp));
+        od[n1] = make_double2(hann_sample<DT>(sub, i + 2, hw, hwp), hann_sample<DT>(sub, i + 3, hw, hwp));
     }
     fft64x8(ev, tile, T.w512, lane);
     fft64x8(od, tile, T.w512, lane);

@@ -235,6 +235,12 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     {
         std::vector<double> ones(NL, 1.0);
         TRY(upload(h, ones.data(), ones.size(), &T.ones));
+        /* Hann tables with the PCM scale folded in (see k_psy.hip) */
+        std::vector<double> hlp(NL), hsp(NS);
+        for (int i = 0; i < NL; ++i) hlp[i] = hl[i] * (2.0 / 65535.0);
+        for (int i = 0; i < NS; ++i) hsp[i] = hs[i] * (2.0 / 65535.0);
+        TRY(upload(h, hlp.data(), hlp.size(), &T.hann_long_pcm));
+        TRY(upload(h, hsp.data(), hsp.size(), &T.hann_short_pcm));
     }
 
     /* twiddles */
