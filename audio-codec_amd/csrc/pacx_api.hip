@@ -24,7 +24,7 @@ void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8
                          hipStream_t st);
 void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
                       const uint8_t *flags, long long n_cf, int short_blocks, int mixed,
-                      PacxPeak *peaks, int32_t *n_peaks, hipStream_t st);
+                      PacxPeak *peaks, int32_t *n_peaks, int32_t *n_kept, hipStream_t st);
 void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
                       int short_blocks, int mixed, const PacxPeak *peaks, const int32_t *n_peaks,
                       const double *lines, double *smr, double *thr_out, int n_cu, hipStream_t st);
@@ -62,7 +62,8 @@ struct pacx_handle {
     double *ws_lines;                 /* [ws_cf][1024]                          */
     double *ws_smr;                   /* [ws_cf][band_stride]                   */
     PacxPeak *ws_peaks;               /* [ws_cf][512]                           */
-    int32_t *ws_npeaks;               /* [ws_cf][8]                             */
+    int32_t *ws_npeaks;               /* [ws_cf][8] maskers found               */
+    int32_t *ws_nkept;                /* [ws_cf][8] maskers left after pruning  */
     int32_t *ws_overall;              /* [ws_cf][8]                             */
     long long *ws_chunks;             /* [ws_cf/256 + 2]                        */
     long long *ws_offs;               /* [ws_cf]                                */
@@ -175,7 +176,7 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->device = cfg->device;
     h->ws_cf = 0;
     h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
-    h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr;
+    h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr; h->ws_nkept = nullptr;
     memset(&h->T, 0, sizeof(h->T));
     int rc = PACX_OK;
 #define TRY(x) do { rc = (x); if (rc) { g_create_err = h->err; pacx_destroy(h); return rc; } } while (0)
@@ -304,12 +305,13 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
 
 static void free_ws(pacx_handle *h)
 {
-    void *p[] = {h->ws_lines, h->ws_smr, h->ws_peaks, h->ws_npeaks, h->ws_overall, h->ws_chunks, h->ws_offs};
+    void *p[] = {h->ws_lines, h->ws_smr, h->ws_peaks, h->ws_npeaks, h->ws_overall, h->ws_chunks, h->ws_offs,
+                 h->ws_nkept};
     for (void *q : p)
         if (q)
             (void)hipFree(q);
     h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
-    h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr;
+    h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr; h->ws_nkept = nullptr;
     h->ws_cf = 0;
 }
 
@@ -338,6 +340,7 @@ extern "C" int pacx_reserve(pacx_handle *h, int64_t n_cf)
     HIP_TRY(h, hipMalloc((void **)&h->ws_smr, n * h->T.band_stride * sizeof(double)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_peaks, n * PACX_MAX_PEAKS * sizeof(PacxPeak)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_npeaks, n * PACX_SUB * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_nkept, n * PACX_SUB * sizeof(int32_t)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_overall, n * PACX_SUB * sizeof(int32_t)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_chunks, (n / 256 + 2) * sizeof(long long)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_offs, (n + 1) * sizeof(long long)));
@@ -422,8 +425,8 @@ extern "C" int pacx_smr_batch(pacx_handle *h, const pacx_pcm *in, const double *
         return rc;
     hipStream_t st = (hipStream_t)stream;
     const int sb = short_blocks ? 1 : 0;
-    pacx_launch_side(h->T, v, in->dtype, fast, nullptr, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, st);
-    pacx_launch_mask(h->T, nullptr, in->n_channels, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, lines, smr,
+    pacx_launch_side(h->T, v, in->dtype, fast, nullptr, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, h->ws_nkept, st);
+    pacx_launch_mask(h->T, nullptr, in->n_channels, n_cf, sb, 0, h->ws_peaks, h->ws_nkept, lines, smr,
                      threshold, h->n_cu, st);
     if (n_peaks) {
         if (sb)
@@ -497,8 +500,9 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
         pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
                          PACX_SUB, status, st);
     }
-    pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, st);
-    pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_lines, h->ws_smr,
+    pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
+                     st);
+    pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
                      nullptr, h->n_cu, st);
     pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_smr, bit_alloc, status, st);
     pacx_launch_quantize(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_lines, overall_scale, PACX_SUB, bit_alloc,
