@@ -166,6 +166,11 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
 }
 
 /* ---------------------------------------------------------------- quantize */
+/* One wave per (sub-)block.  Each lane owns M/64 CONSECUTIVE lines (coalesced
+ * 16-byte loads and stores); band maxima go through 64-bit LDS atomic max on
+ * the bit pattern of |x| (non-negative doubles order like integers), so no
+ * per-band loop and no dependent global loads; lanes < nBands then turn the
+ * maxima into scale factors in parallel. */
 template <int M>
 __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
                                                 long long n_units, int mixed,
@@ -177,8 +182,8 @@ __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__
 {
     constexpr bool SHORT = (M == PACX_M_SHORT);
     constexpr int PER = M / 64;
-    __shared__ double mag[M];
-    __shared__ int sfs[PACX_MAX_BANDS];
+    __shared__ unsigned long long bmax[PACX_MAX_BANDS];
+    __shared__ int ba_s[PACX_MAX_BANDS], sf_s[PACX_MAX_BANDS];
     const int lane = threadIdx.x;
     const long long unit = blockIdx.x;
     if (unit >= n_units)
@@ -191,41 +196,70 @@ __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__
             return;
     }
     const int nb = SHORT ? T.nb_short : T.nb_long;
-    const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
-    const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
     const uint8_t *__restrict__ band_of = SHORT ? T.line_band_short : T.line_band_long;
     const long long boff = cf * T.band_stride + sb * T.nb_short;
     const long long loff = cf * PACX_M_LONG + sb * PACX_M_SHORT;
     const int ov = overall[SHORT ? (cf * overall_stride + (overall_stride == 1 ? 0 : sb)) : cf * overall_stride];
     const double up = (double)(1 << ov);            /* mdctLines *= (1 << overallScale) */
-
+    if (lane < nb) {
+        bmax[lane] = 0ull;
+        ba_s[lane] = bit_alloc[boff + lane];
+    }
+    const int k0 = PER * lane;
     double x[PER];
+    uint8_t band[PER];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int k = lane + 64 * j;
-        x[j] = lines[loff + k] * up;
-        mag[k] = fabs(x[j]);
+    for (int j = 0; j < PER; j += 2) {
+        const double2 v = *(const double2 *)(lines + loff + k0 + j);
+        x[j] = v.x * up;
+        x[j + 1] = v.y * up;
+    }
+    if constexpr (SHORT) {
+        const uchar2 b2 = *(const uchar2 *)(band_of + k0);
+        band[0] = b2.x;
+        band[1] = b2.y;
+    } else {
+        const uint4 b16 = *(const uint4 *)(band_of + k0);
+        const unsigned w[4] = {b16.x, b16.y, b16.z, b16.w};
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            band[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
     }
     __syncthreads();
-    for (int b = 0; b < nb; ++b) {
-        const int lo = lower[b], hi = lo + count[b];
+    {
+        int cur = band[0];
         double m = 0.0;
-        for (int k = lo + lane; k < hi; k += 64)
-            m = fmax(m, mag[k]);
-        m = wave_max(m);
-        if (lane == 0) {
-            const int sf = pacx_scale_factor(m, T.n_scale_bits, bit_alloc[boff + b]);
-            sfs[b] = sf;
-            scale_factor[boff + b] = sf;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (band[j] != cur) {
+                atomicMax(&bmax[cur], (unsigned long long)__double_as_longlong(m));
+                cur = band[j];
+                m = 0.0;
+            }
+            m = fmax(m, fabs(x[j]));
         }
+        atomicMax(&bmax[cur], (unsigned long long)__double_as_longlong(m));
     }
     __syncthreads();
+    if (lane < nb) {
+        const int sf = pacx_scale_factor(__longlong_as_double((long long)bmax[lane]), T.n_scale_bits, ba_s[lane]);
+        sf_s[lane] = sf;
+        scale_factor[boff + lane] = sf;
+    }
+    __syncthreads();
+    int32_t mant[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const int k = lane + 64 * j;
-        const int b = band_of[k];
-        const int ba = bit_alloc[boff + b];
-        mantissa[loff + k] = ba ? pacx_mantissa(x[j], sfs[b], T.n_scale_bits, ba) : 0;
+        const int b = band[j];
+        const int ba = ba_s[b];
+        mant[j] = ba ? pacx_mantissa(x[j], sf_s[b], T.n_scale_bits, ba) : 0;
+    }
+    if constexpr (SHORT) {
+        *(int2 *)(mantissa + loff + k0) = make_int2(mant[0], mant[1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; j += 4)
+            *(int4 *)(mantissa + loff + k0 + j) = make_int4(mant[j], mant[j + 1], mant[j + 2], mant[j + 3]);
     }
 }
 
@@ -260,21 +294,28 @@ __device__ __forceinline__ int pack_body(const PacxTables &T, unsigned *words, i
     const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
     const uint8_t *__restrict__ band_of = SHORT ? T.line_band_short : T.line_band_long;
-    if (lane == 0) {
-        int p = pos + T.n_scale_bits;
-        for (int b = 0; b < nb; ++b) {
-            offs[b] = p;
-            p += T.n_mant_size_bits + T.n_scale_bits + ba[b] * count[b];
-        }
-        offs[nb] = p;
+    /* bit offset of every band header: exclusive prefix sum over lanes = bands */
+    const int a_mine = (lane < nb) ? ba[lane] : 0;
+    const int width = (lane < nb) ? T.n_mant_size_bits + T.n_scale_bits + a_mine * count[lane] : 0;
+    int incl = width;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off)
+            incl += t;
+    }
+    const int my_off = pos + T.n_scale_bits + incl - width;
+    if (lane < nb)
+        offs[lane] = my_off;
+    if (lane == nb - 1)
+        offs[nb] = my_off + width;
+    if (lane == 0)
         put_bits(words, pos, (unsigned)ov, T.n_scale_bits);
+    if (lane < nb) {
+        put_bits(words, my_off, (unsigned)(a_mine ? a_mine - 1 : 0), T.n_mant_size_bits);
+        put_bits(words, my_off + T.n_mant_size_bits, (unsigned)sf[lane], T.n_scale_bits);
     }
     __syncthreads();
-    if (lane < nb) {
-        const int a = ba[lane];
-        put_bits(words, offs[lane], (unsigned)(a ? a - 1 : 0), T.n_mant_size_bits);
-        put_bits(words, offs[lane] + T.n_mant_size_bits, (unsigned)sf[lane], T.n_scale_bits);
-    }
     for (int k = lane; k < M; k += 64) {
         const int b = band_of[k];
         const int a = ba[b];
