@@ -282,19 +282,43 @@ __device__ __forceinline__ void put_bits(unsigned *words, int pos, unsigned val,
     }
 }
 
-/* one (sub-)block body starting at stream bit `pos`; returns its bit length */
+/* one (sub-)block body starting at stream bit `pos`; returns its bit length.
+ * Lanes < nBands write the band headers (their offsets come from an exclusive
+ * prefix sum across lanes); every lane then packs its M/64 consecutive lines
+ * (one 16-byte load of mantissas at a time, band tables from LDS). */
 template <int M>
-__device__ __forceinline__ int pack_body(const PacxTables &T, unsigned *words, int *offs, int pos,
-                                         int ov, const int32_t *__restrict__ ba,
+__device__ __forceinline__ int pack_body(const PacxTables &T, unsigned *words, int *offs, int *ba_s,
+                                         int *lower_s, int pos, int ov, const int32_t *__restrict__ ba,
                                          const int32_t *__restrict__ sf,
                                          const int32_t *__restrict__ mant, int lane)
 {
     constexpr bool SHORT = (M == PACX_M_SHORT);
+    constexpr int PER = M / 64;
     const int nb = SHORT ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
     const uint8_t *__restrict__ band_of = SHORT ? T.line_band_short : T.line_band_long;
-    /* bit offset of every band header: exclusive prefix sum over lanes = bands */
+    const int k0 = PER * lane;
+    /* loads first: mantissas and band ids of this lane's lines, band tables */
+    int32_t m[PER];
+    uint8_t band[PER];
+    if constexpr (SHORT) {
+        const int2 v = *(const int2 *)(mant + k0);
+        m[0] = v.x; m[1] = v.y;
+        const uchar2 b2 = *(const uchar2 *)(band_of + k0);
+        band[0] = b2.x; band[1] = b2.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; j += 4) {
+            const int4 v = *(const int4 *)(mant + k0 + j);
+            m[j] = v.x; m[j + 1] = v.y; m[j + 2] = v.z; m[j + 3] = v.w;
+        }
+        const uint4 b16 = *(const uint4 *)(band_of + k0);
+        const unsigned w[4] = {b16.x, b16.y, b16.z, b16.w};
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            band[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+    }
     const int a_mine = (lane < nb) ? ba[lane] : 0;
     const int width = (lane < nb) ? T.n_mant_size_bits + T.n_scale_bits + a_mine * count[lane] : 0;
     int incl = width;
@@ -305,8 +329,11 @@ __device__ __forceinline__ int pack_body(const PacxTables &T, unsigned *words, i
             incl += t;
     }
     const int my_off = pos + T.n_scale_bits + incl - width;
-    if (lane < nb)
-        offs[lane] = my_off;
+    if (lane < nb) {
+        offs[lane] = my_off + T.n_mant_size_bits + T.n_scale_bits;      /* first mantissa bit of the band */
+        ba_s[lane] = a_mine;
+        lower_s[lane] = lower[lane];
+    }
     if (lane == nb - 1)
         offs[nb] = my_off + width;
     if (lane == 0)
@@ -316,12 +343,12 @@ __device__ __forceinline__ int pack_body(const PacxTables &T, unsigned *words, i
         put_bits(words, my_off + T.n_mant_size_bits, (unsigned)sf[lane], T.n_scale_bits);
     }
     __syncthreads();
-    for (int k = lane; k < M; k += 64) {
-        const int b = band_of[k];
-        const int a = ba[b];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = band[j];
+        const int a = ba_s[b];
         if (a)
-            put_bits(words, offs[b] + T.n_mant_size_bits + T.n_scale_bits + (k - lower[b]) * a,
-                     (unsigned)mant[k], a);
+            put_bits(words, offs[b] + (k0 + j - lower_s[b]) * a, (unsigned)m[j], a);
     }
     const int end = offs[nb];
     __syncthreads();
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(64) void k_pack(PacxTables T, const uint8_t *__rest
                                             int32_t *__restrict__ n_bytes)
 {
     __shared__ unsigned words[PACX_PACK_WORDS];
-    __shared__ int offs[PACX_MAX_BANDS + 1];
+    __shared__ int offs[PACX_MAX_BANDS + 1], ba_s[PACX_MAX_BANDS], lower_s[PACX_MAX_BANDS];
     const int lane = threadIdx.x;
     const long long cf = blockIdx.x;
     if (cf >= n_cf)
@@ -371,10 +398,10 @@ __global__ __launch_bounds__(64) void k_pack(PacxTables T, const uint8_t *__rest
     const int32_t *mant = mantissa + cf * PACX_M_LONG;
     const int32_t *ov = overall + cf * PACX_SUB;
     if (!is_short) {
-        pos += pack_body<PACX_M_LONG>(T, words, offs, pos, ov[0], ba, sf, mant, lane);
+        pos += pack_body<PACX_M_LONG>(T, words, offs, ba_s, lower_s, pos, ov[0], ba, sf, mant, lane);
     } else {
         for (int sb = 0; sb < PACX_SUB; ++sb)
-            pos += pack_body<PACX_M_SHORT>(T, words, offs, pos, ov[sb], ba + sb * T.nb_short,
+            pos += pack_body<PACX_M_SHORT>(T, words, offs, ba_s, lower_s, pos, ov[sb], ba + sb * T.nb_short,
                                            sf + sb * T.nb_short, mant + sb * PACX_M_SHORT, lane);
     }
     /* size rule of coder/pacfile.py:552-565: body bits + 4, rounded up */
