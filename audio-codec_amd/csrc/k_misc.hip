@@ -57,6 +57,96 @@ __global__ void k_bitalloc_generic(long long n, int nb, const int32_t *__restric
         bits_out[i * nb + b] = bits[b];
 }
 
+/* Block-switching caller: parTransientDetect
+ * (coder/detect_transients.py:5-23) on (hop || 1024 zeros), the only input the
+ * reference's driver ever gives it (coder/pacfile.py:728-732).  One wave per hop:
+ * per channel the peak |x| and its first position, then the mean of |x| over the
+ * first min(max_ch(argmax)+500, 2048) columns of BOTH channels (zeros past 1024),
+ * transient = any(peak / avg > 4.5); avg == 0 -> not a transient.
+ * |x| = 2 (|c| & 32767) / 65535; the sum is taken exactly in integers and scaled
+ * once (the reference adds the float fractions pairwise: same value to ~1e-16). */
+__global__ __launch_bounds__(64) void k_transient(PacxPcmView in, long long n_hops, int hop,
+                                                  uint8_t *__restrict__ transient)
+{
+    const int lane = threadIdx.x;
+    const long long h = blockIdx.x;
+    if (h >= n_hops)
+        return;
+    const short *base = (const short *)in.base + h * in.frame_stride;
+    const int n_ch = in.n_ch < 8 ? in.n_ch : 8;
+    /* pass 1: per channel the peak magnitude and its first position */
+    int upto = 0;
+    int peak_c[8];
+    for (int ch = 0; ch < n_ch; ++ch) {
+        const short *src = base + (long long)ch * in.ch_stride;
+        int best = -1, where = 0;
+        for (int i = lane; i < hop; i += 64) {           /* ascending i per lane: first maximum kept */
+            const int c = src[(long long)i * in.samp_stride];
+            const int mag = (c < 0 ? -c : c) & 32767;
+            if (mag > best) { best = mag; where = i; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {          /* wave arg-max, lowest index wins ties */
+            const int ob = __shfl_xor(best, off, 64), ow = __shfl_xor(where, off, 64);
+            if (ob > best || (ob == best && ow < where)) { best = ob; where = ow; }
+        }
+        peak_c[ch] = best;
+        upto = max(upto, where + 500);
+    }
+    if (upto > 2 * hop)
+        upto = 2 * hop;
+    const int cols = upto < hop ? upto : hop;            /* columns that are not padding zeros */
+    /* pass 2: sum of |c| over the first `cols` samples of every channel (exact) */
+    long long total = 0;
+    for (int ch = 0; ch < n_ch; ++ch) {
+        const short *src = base + (long long)ch * in.ch_stride;
+        int part = 0;
+        for (int i = lane; i < cols; i += 64) {
+            const int c = src[(long long)i * in.samp_stride];
+            part += (c < 0 ? -c : c) & 32767;
+        }
+        for (int off = 32; off > 0; off >>= 1)
+            part += __shfl_xor(part, off, 64);
+        total += part;
+    }
+    if (lane == 0) {
+        bool tr = false;
+        if (total > 0) {
+            const double avg = ((double)total * (2.0 / 65535.0)) / (double)((long long)in.n_ch * upto);
+            for (int ch = 0; ch < n_ch; ++ch)
+                tr = tr || (pacx_pcm16_to_f64(peak_c[ch]) / avg > 4.5);
+        }
+        transient[h] = tr ? 1 : 0;
+    }
+}
+
+/* flags of every written hop of the driver loop (coder/pacfile.py:717-741) plus
+ * the Close block: frame f gets last = T[f-2], cur = T[f-1], next = T[f]
+ * (T[n_hops] = 0: the pass after EOF), the final zero block (0,0,0). */
+__global__ void k_stream_flags(const uint8_t *__restrict__ transient, long long n_hops,
+                               uint8_t *__restrict__ flags)
+{
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_hops + 2)
+        return;
+    unsigned v = 0;
+    if (f <= n_hops) {
+        if (f >= 2 && transient[f - 2]) v |= 1u;
+        if (f >= 1 && transient[f - 1]) v |= 2u;
+        if (f < n_hops && transient[f]) v |= 4u;
+    }
+    flags[f] = (uint8_t)v;
+}
+
+void pacx_launch_transient(const PacxPcmView &in, long long n_hops, int hop, uint8_t *transient,
+                           uint8_t *flags, hipStream_t st)
+{
+    if (n_hops > 0)
+        hipLaunchKernelGGL(k_transient, dim3((unsigned)n_hops), dim3(64), 0, st, in, n_hops, hop, transient);
+    if (flags)
+        hipLaunchKernelGGL(k_stream_flags, dim3((unsigned)((n_hops + 2 + 255) / 256)), dim3(256), 0, st,
+                           transient, n_hops, flags);
+}
+
 void pacx_launch_window(const double *win, long long n_rows, int len, const double *x, double *y,
                         hipStream_t st)
 {

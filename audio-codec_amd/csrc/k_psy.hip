@@ -26,35 +26,8 @@
  */
 #include "pacx_dev.h"
 #include "wave_fft.h"
+#include "pcm_stage.h"
 
-template <int DT> struct PcmStage;
-template <> struct PcmStage<0> {
-    typedef short elem;
-    static __device__ __forceinline__ double get(const short *s, int i) { return pacx_pcm16_to_f64(s[i]); }
-};
-template <> struct PcmStage<1> {
-    typedef double elem;
-    static __device__ __forceinline__ double get(const double *s, int i) { return s[i]; }
-};
-
-template <int DT, bool FAST>
-__device__ __forceinline__ void stage_samples(typename PcmStage<DT>::elem *dst, const PacxPcmView &in,
-                                              long long cf, int first, int count, int lane)
-{
-    typedef typename PcmStage<DT>::elem E;
-    const long long f = cf / in.n_ch;
-    const int ch = (int)(cf - f * in.n_ch);
-    const E *src = (const E *)in.base + f * in.frame_stride + ch * in.ch_stride;
-    if constexpr (FAST) {
-        const int4 *s4 = (const int4 *)(src + first);
-        int4 *d4 = (int4 *)dst;
-        for (int i = lane; i < count / 8; i += 64)
-            d4[i] = s4[i];
-    } else {
-        for (int i = lane; i < count; i += 64)
-            dst[i] = src[(long long)(first + i) * in.samp_stride];
-    }
-}
 
 /* Hann-windowed sample i of the staged block.  int16 input: the code enters as an
  * integer and the table carries 2/65535 (the side chain is linear up to the

@@ -50,6 +50,9 @@ void pacx_launch_quant_elem(int op, long long n, const double *x, int scale, int
 void pacx_launch_bitalloc_generic(long long n, int nb, const int32_t *n_lines, const double *budget,
                                   int max_mant, const double *smr, int32_t *bits, hipStream_t st);
 
+void pacx_launch_transient(const PacxPcmView &in, long long n_hops, int hop, uint8_t *transient,
+                           uint8_t *flags, hipStream_t st);
+
 #define PACX_PAYLOAD_STRIDE 2192
 
 struct pacx_handle {
@@ -610,4 +613,24 @@ extern "C" int pacx_bitalloc_generic(pacx_handle *h, int64_t n, int n_bands, con
     pacx_launch_bitalloc_generic(n, n_bands, band_lines, budget, max_mant_bits, smr, bit_alloc,
                                  (hipStream_t)stream);
     return post_launch(h, "pacx_bitalloc_generic");
+}
+
+extern "C" int pacx_transient_flags(pacx_handle *h, const pacx_pcm *hops, uint8_t *transient,
+                                    uint8_t *frame_flags, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    PacxPcmView v;
+    int fast;
+    long long n_cf;
+    int rc = check_pcm(h, hops, &v, &fast, &n_cf);
+    if (rc)
+        return rc;
+    if (hops->dtype != PACX_PCM_I16 || !transient)
+        return fail(h, PACX_E_ARG, "pacx_transient_flags: int16 hops and a transient buffer are required");
+    if (hops->n_channels > 8)
+        return fail(h, PACX_E_UNSUPPORTED, "pacx_transient_flags: at most 8 channels");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_transient(v, hops->n_frames, PACX_M_LONG, transient, frame_flags, (hipStream_t)stream);
+    return post_launch(h, "pacx_transient_flags");
 }

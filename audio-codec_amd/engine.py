@@ -254,6 +254,17 @@ class Encoder:
                    ctypes.c_int64(capacity), _ptr(total), self._stream())
         return body, total
 
+    def transient_flags(self, planar, n_hops, hop=N_LONG):
+        """Block-switching flags on the GPU for a device stream laid out as
+        pacfile.device_stream builds it ([nCh, (n_hops+3)*hop]: zeros, the hops, the
+        last hop again, zeros).  Returns (transient uint8[n_hops], flags uint8[n_hops+2])."""
+        n_ch, n = planar.shape
+        view = _lib.PacxPcm(planar.data_ptr() + 2 * hop, _lib.PCM_I16, n_ch, int(n_hops), hop, n, 1)
+        tr = self._empty((max(n_hops, 1),), torch.uint8)
+        fl = self._empty((n_hops + 2,), torch.uint8)
+        self._call("pacx_transient_flags", ctypes.byref(view), _ptr(tr), _ptr(fl), self._stream())
+        return tr[:n_hops], fl
+
     # ------------------------------------------- function-level entry points
     def window(self, kind, x):
         """window * x for rows of x ([n, 2048] or [n, 256] float64 on the GPU)."""

@@ -130,9 +130,12 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, hea
     cp.useSBR = cp.useVQ = False
     head = header_bytes(cp)
     enc = context.encoder_for_params(cp)
-    flags = stream_flags(pcm, block_switching, hop)
-    view = PcmView.stream(device_stream(enc, pcm, hop), hop)
-    assert view.n_frames == len(flags)
+    planar = device_stream(enc, pcm, hop)
+    view = PcmView.stream(planar, hop)
+    if block_switching:
+        _, flags = enc.transient_flags(planar, len(pcm) // hop, hop)     # detector + flag shifting on the GPU
+    else:
+        flags = None
     out = enc.encode(view, flags)
     payload, n_bytes = enc.pack(out, cp.nChannels)
     body, total = enc.gather_body(payload, n_bytes)

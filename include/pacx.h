@@ -275,6 +275,15 @@ int pacx_bitalloc_generic(pacx_handle *h, int64_t n, int n_bands, const int32_t 
                           const double *budget, int max_mant_bits, const double *smr,
                           int32_t *bit_alloc, void *stream);
 
+/* detect_transients.py + the flag shifting of the driver loop
+ * (coder/detect_transients.py:5-23, coder/pacfile.py:717-741): `hops` views the
+ * stream hop by hop (frame_stride = one hop, n_frames = number of hops read from
+ * the file); transient[h] = parTransientDetect(hop h || zeros).  If frame_flags
+ * is not NULL it receives n_frames + 2 PACX_FLAG_* bytes: one per block the
+ * driver writes (every hop, the last hop a second time, the Close block). */
+int pacx_transient_flags(pacx_handle *h, const pacx_pcm *hops, uint8_t *transient,
+                         uint8_t *frame_flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -328,6 +328,22 @@ def test_excerpt_pac_bytes(A, name, variant):
     assert got == want
 
 
+@pytest.mark.parametrize("name", EXCERPTS)
+def test_gpu_transient_flags(A, torch, name):
+    """detect_transients + flag shifting on the GPU against the flags the
+    reference's driver produced for the golden excerpts."""
+    ex = load_excerpt(name)
+    pcm = pad_hop(ex["pcm"]) if len(ex["pcm"]) % 1024 else ex["pcm"]
+    enc = enc_for(A, int(ex["sr"]))
+    planar = A.pacfile.device_stream(enc, pcm)
+    tr, fl = enc.transient_flags(planar, len(pcm) // 1024)
+    fl = fl.cpu().numpy()
+    want = ex["flags_bs"]
+    got = np.stack([fl & 1, (fl >> 1) & 1, (fl >> 2) & 1], axis=1)
+    assert got[:-1].tolist() == want.tolist() and got[-1].tolist() == [0, 0, 0]
+    assert tr.cpu().numpy().tolist() == want[:len(pcm) // 1024, 2].tolist()
+
+
 def pad_hop(pcm):
     n = -len(pcm) % 1024
     return np.concatenate((pcm, np.zeros((n, pcm.shape[1]), pcm.dtype)))
