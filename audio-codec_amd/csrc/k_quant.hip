@@ -72,6 +72,14 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
     int bits = 0, n_flip = 0, passes = 0, cap = 0;
     unsigned dropped = 0;
     bool done = !alive;
+    /* The reference's loop can oscillate for ever and then leaves through its
+       200-pass guard (coder/bitalloc.py:116-119; ~0.5 % of short blocks).  The
+       loop is a deterministic map of (bits, dropped, n_flip), so once a state
+       repeats with period L the state after the 201st pass is known: Brent's
+       cycle detection (snapshot at passes 1, 2, 4, ...) finds L, the loop then
+       runs only (201 - passes) mod L more passes.  Same result, ~10 passes. */
+    int snap_bits = -1, snap_flip = -1, snap_pass = 0, snap_next = 1, stop_at = -1;
+    unsigned snap_dropped = 0xFFFFFFFFu;
     while (__ballot(!done)) {
         const bool valid = has && !((dropped >> l) & 1u);
         const unsigned vmask = (unsigned)(__ballot(valid) >> (32 * half));
@@ -152,10 +160,31 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
                 if (stable && (double)spent > budget)
                     n_flip += 1;
                 ++passes;
-                if (passes > PACX_ALLOC_MAX_PASSES) {
+                if (passes > PACX_ALLOC_MAX_PASSES || passes == stop_at) {
                     cap = 1;
                     done = true;
                 }
+            }
+        }
+        /* cycle detection on the state after this pass (per half wave) */
+        {
+            const bool same_lane = (bits == snap_bits);
+            const unsigned eq = (unsigned)(__ballot(same_lane || !has) >> (32 * half));
+            const bool same = (eq == 0xFFFFFFFFu) && dropped == snap_dropped && n_flip == snap_flip;
+            if (!done && stop_at < 0 && same) {
+                const int period = passes - snap_pass;
+                stop_at = passes + ((PACX_ALLOC_MAX_PASSES + 1 - passes) % period);
+                if (stop_at == passes) {            /* already at the state the guard would leave in */
+                    cap = 1;
+                    done = true;
+                }
+            }
+            if (passes == snap_next) {
+                snap_bits = bits;
+                snap_dropped = dropped;
+                snap_flip = n_flip;
+                snap_pass = passes;
+                snap_next *= 2;
             }
         }
     }
