@@ -196,10 +196,10 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
 
 /* ---------------------------------------------------------------- quantize */
 /* One wave per (sub-)block.  Each lane owns M/64 CONSECUTIVE lines (coalesced
- * 16-byte loads and stores); band maxima go through 64-bit LDS atomic max on
- * the bit pattern of |x| (non-negative doubles order like integers), so no
- * per-band loop and no dependent global loads; lanes < nBands then turn the
- * maxima into scale factors in parallel. */
+ * 16-byte loads and stores); band maxima go through LDS atomic max on the bit
+ * pattern of |x| (non-negative doubles order like integers), so no per-band
+ * loop and no dependent global loads; lanes < nBands then turn the maxima into
+ * scale factors in parallel. */
 template <int M>
 __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
                                                 long long n_units, int mixed,
@@ -230,10 +230,10 @@ __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__
     const long long loff = cf * PACX_M_LONG + sb * PACX_M_SHORT;
     const int ov = overall[SHORT ? (cf * overall_stride + (overall_stride == 1 ? 0 : sb)) : cf * overall_stride];
     const double up = (double)(1 << ov);            /* mdctLines *= (1 << overallScale) */
-    if (lane < nb) {
+    if (lane < PACX_MAX_BANDS)
         bmax[lane] = 0ull;
+    if (lane < nb)
         ba_s[lane] = bit_alloc[boff + lane];
-    }
     const int k0 = PER * lane;
     double x[PER];
     uint8_t band[PER];
@@ -255,19 +255,66 @@ __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__
             band[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
     }
     __syncthreads();
-    {
-        int cur = band[0];
-        double m = 0.0;
+    if constexpr (SHORT) {
+        /* 6 bands, 2 lines per lane: one masked wave reduction per band */
+        for (int b = 0; b < nb; ++b) {
+            double m = 0.0;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            if (band[j] != cur) {
-                atomicMax(&bmax[cur], (unsigned long long)__double_as_longlong(m));
-                cur = band[j];
-                m = 0.0;
-            }
-            m = fmax(m, fabs(x[j]));
+            for (int j = 0; j < PER; ++j)
+                if (band[j] == b)
+                    m = fmax(m, fabs(x[j]));
+            m = wave_max(m);
+            if (lane == b)
+                bmax[b] = (unsigned long long)__double_as_longlong(m);
         }
-        atomicMax(&bmax[cur], (unsigned long long)__double_as_longlong(m));
+    } else {
+        /* Each lane owns runs of consecutive lines of one band.  The band maximum of
+           |x| is taken on the bit pattern (non-negative doubles order like unsigned
+           integers) with 32-bit LDS atomics in two rounds -- high words, then low
+           words among the lanes that hold the winning high word.  (64-bit ds_max_u64
+           gave wrong maxima on gfx950 / ROCm 7.2 once in ~1500 bands when several
+           lanes hit one address; 32-bit LDS atomics are used everywhere else too.) */
+        unsigned *hi_w = (unsigned *)bmax;                 /* [nb] high words, then [nb] low words */
+        unsigned *lo_w = hi_w + PACX_MAX_BANDS;
+        {
+            int cur = band[0];
+            double m = 0.0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (band[j] != cur) {
+                    atomicMax(&hi_w[cur], (unsigned)__double2hiint(m));
+                    cur = band[j];
+                    m = 0.0;
+                }
+                m = fmax(m, fabs(x[j]));
+            }
+            atomicMax(&hi_w[cur], (unsigned)__double2hiint(m));
+        }
+        __syncthreads();
+        {
+            int cur = band[0];
+            double m = 0.0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (band[j] != cur) {
+                    if ((unsigned)__double2hiint(m) == hi_w[cur])
+                        atomicMax(&lo_w[cur], (unsigned)__double2loint(m));
+                    cur = band[j];
+                    m = 0.0;
+                }
+                m = fmax(m, fabs(x[j]));
+            }
+            if ((unsigned)__double2hiint(m) == hi_w[cur])
+                atomicMax(&lo_w[cur], (unsigned)__double2loint(m));
+        }
+        __syncthreads();
+        if (lane < nb) {
+            const unsigned hw = hi_w[lane], lw = lo_w[lane];
+            __syncthreads();
+            bmax[lane] = ((unsigned long long)hw << 32) | lw;
+        } else {
+            __syncthreads();
+        }
     }
     __syncthreads();
     if (lane < nb) {

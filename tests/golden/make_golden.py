@@ -417,6 +417,19 @@ def _full_one(args):
             int(sum(f[1] for f in flags)), len(flags))
 
 
+def make_full_inputs(names):
+    """The PCM the reference's driver feeds the coder for each whole test WAV
+    (data chunk + the bytes it reads past it, zero padded to a hop): the input
+    side of fullfile.json, so the GPU box can reproduce the whole-file hashes."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import pac_oracle as po
+    for n in names:
+        raw = open(os.path.join(REF, "test_signals", n + ".wav"), "rb").read()
+        sr, pcm, declared = po.wav_effective_stream(raw)
+        np.savez_compressed(os.path.join(HERE, f"full_{n}.npz"), pcm=pcm, sr=np.array(sr),
+                            declared=np.array(declared))
+
+
 def make_full(names):
     from multiprocessing import Pool
     jobs = [(n, bs) for n in names for bs in (False, True)]
@@ -437,6 +450,7 @@ if __name__ == "__main__":
             for n in names}
     if "--full" in sys.argv:
         make_full(names)
+        make_full_inputs(names)
     else:
         make_tables()
         make_stages(wavs)
