@@ -354,7 +354,7 @@ extern "C" int pacx_reserve(pacx_handle *h, int64_t n_cf)
 /* validate a pcm view; fills the device-side view and the fast-path flag */
 static int check_pcm(pacx_handle *h, const pacx_pcm *in, PacxPcmView *v, int *fast, long long *n_cf)
 {
-    if (!in || !in->data)
+    if (!in || (!in->data && in->n_frames != 0))
         return fail(h, PACX_E_ARG, "pcm view or data pointer is null");
     if (in->dtype != PACX_PCM_I16 && in->dtype != PACX_PCM_F64)
         return fail(h, PACX_E_ARG, "pcm dtype must be PACX_PCM_I16 or PACX_PCM_F64");
@@ -393,6 +393,8 @@ extern "C" int pacx_mdct_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t
     int rc = check_pcm(h, in, &v, &fast, &n_cf);
     if (rc)
         return rc;
+    if (n_cf == 0)
+        return PACX_OK;
     if (!lines)
         return fail(h, PACX_E_ARG, "pacx_mdct_batch: lines is null");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -421,6 +423,8 @@ extern "C" int pacx_smr_batch(pacx_handle *h, const pacx_pcm *in, const double *
     int rc = check_pcm(h, in, &v, &fast, &n_cf);
     if (rc)
         return rc;
+    if (n_cf == 0)
+        return PACX_OK;
     if (!lines || !smr)
         return fail(h, PACX_E_ARG, "pacx_smr_batch: lines or smr is null");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -448,6 +452,8 @@ extern "C" int pacx_bitalloc_batch(pacx_handle *h, int64_t n_cf, int n_channels,
 {
     if (!h)
         return PACX_E_ARG;
+    if (n_cf == 0)
+        return PACX_OK;
     if (n_cf < 0 || n_channels < 1 || !smr || !bit_alloc)
         return fail(h, PACX_E_ARG, "pacx_bitalloc_batch: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -462,6 +468,8 @@ extern "C" int pacx_quantize_batch(pacx_handle *h, int64_t n_cf, const double *l
 {
     if (!h)
         return PACX_E_ARG;
+    if (n_cf == 0)
+        return PACX_OK;
     if (n_cf < 0 || !lines || !overall_scale || !bit_alloc || !scale_factor || !mantissa)
         return fail(h, PACX_E_ARG, "pacx_quantize_batch: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -482,6 +490,8 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
     int rc = check_pcm(h, in, &v, &fast, &n_cf);
     if (rc)
         return rc;
+    if (n_cf == 0)
+        return PACX_OK;
     if (!overall_scale || !scale_factor || !bit_alloc || !mantissa || !status)
         return fail(h, PACX_E_ARG, "pacx_encode_batch: null output pointer");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -520,6 +530,8 @@ extern "C" int pacx_pack_batch(pacx_handle *h, int64_t n_cf, int n_channels, con
 {
     if (!h)
         return PACX_E_ARG;
+    if (n_cf == 0)
+        return PACX_OK;
     if (n_cf < 0 || n_channels < 1 || !overall_scale || !scale_factor || !bit_alloc || !mantissa || !payload ||
         !n_bytes)
         return fail(h, PACX_E_ARG, "pacx_pack_batch: bad argument");
@@ -534,6 +546,11 @@ extern "C" int pacx_gather_body(pacx_handle *h, int64_t n_cf, const uint8_t *pay
 {
     if (!h)
         return PACX_E_ARG;
+    if (n_cf == 0) {
+        if (total_bytes)
+            HIP_TRY(h, hipMemsetAsync(total_bytes, 0, sizeof(int64_t), (hipStream_t)stream));
+        return PACX_OK;
+    }
     if (n_cf < 0 || !payload || !n_bytes || !body || body_capacity < 0)
         return fail(h, PACX_E_ARG, "pacx_gather_body: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));

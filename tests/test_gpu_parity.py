@@ -448,6 +448,44 @@ def test_pacfile_block_api(A, tmp_path):
     assert open(tmp_path / "t.pac", "rb").read() == want
 
 
+def test_edge_cases(A, torch):
+    """Empty and ragged inputs, mono, interleaved layout, error reporting."""
+    enc = enc_for(A, 48000)
+    # empty stream: header + the duplicated... nothing to duplicate, only the Close block
+    p = po.make_params(48000, 2, 128)
+    empty = np.zeros((0, 2), np.int16)
+    assert A.pacfile.encode_stream(empty, 48000, 128) == po.encode_stream(empty, 48000, 128)
+    # one hop, mono, block switching on
+    mono = A.synth.stream(1, 1)
+    assert A.pacfile.encode_stream(mono, 48000, 128, True) == po.encode_stream(mono, 48000, 128, True)
+    # three channels
+    tri = A.synth.stream(3, 3)
+    assert A.pacfile.encode_stream(tri, 48000, 128) == po.encode_stream(tri, 48000, 128)
+    # interleaved (WAV order) stereo through the strided view == planar
+    pcm = A.synth.stream(5, 2)
+    planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=enc.device)
+    a = enc.encode(A.engine.PcmView.stream(planar))
+    inter = torch.as_tensor(np.concatenate((np.zeros((1024, 2), np.int16), pcm)), device=enc.device)
+    b = enc.encode(A.engine.PcmView(inter, 2, 5, 2048, 1, 2))
+    for k in ("overall", "scale_factor", "bit_alloc", "mantissa"):
+        assert torch.equal(a[k], b[k]), k
+    # zero frames: nothing launched, no error
+    z = A.engine.PcmView(planar, 2, 0, 1024, planar.shape[1], 1)
+    out = enc.encode(z)
+    assert out["mantissa"].shape[0] == 0
+    # errors come back as exceptions with the library's text
+    with pytest.raises(A.PacxError, match="dtype|stride|null|bad"):
+        bad = A.engine.PcmView(planar, 2, 5, 1024, planar.shape[1], 1)
+        bad.c.sample_stride = 0
+        enc.encode(bad)
+    with pytest.raises(A.PacxError, match="1024"):
+        A.engine.Encoder(48000, 128 / 48.0, n_mdct_lines=512)
+    with pytest.raises(NotImplementedError):
+        cp = A.audiofile.CodingParams()
+        cp.useVQ, cp.useSBR = True, False
+        A.codec.Encode([np.zeros(2048)], cp)
+
+
 # --------------------------------------------------- function-level mirrors
 def test_mirror_functions(A, stages, tables):
     i = [str(t) for t in stages["long_tag"]].index("six_tone")
