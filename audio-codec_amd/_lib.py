@@ -78,6 +78,8 @@ SIGNATURES = {
     "pacx_quantize_uniform": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P]),
     "pacx_scale_factor": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, _P, _P]),
     "pacx_mantissa": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "pacx_unpack_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pacx_decode_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pacx_transient_flags": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, _P, _P]),
     "pacx_bitalloc_generic": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, ctypes.c_int, _P, _P, _P]),
 }

@@ -1,0 +1,299 @@
+/*
+ * k_decode.hip -- the decode side, scalar-mantissa coder:
+ *
+ *   k_unpack   : MSB-first payload of one channel-block -> flags, overall scale,
+ *                bit allocation, scale factors, line-indexed mantissas
+ *                (coder/pacfile.py:185-213, 264-266; the inverse of k_pack)
+ *   k_imdct<M> : vDequantize (coder/quantize.py:254-274) -> / 2^overall -> IMDCT
+ *                (coder/mdct.py:56-62) -> window (coder/codec.py:81-89); short
+ *                frames: eight sub-blocks overlap-added at n = 448 + 128 j
+ *                (coder/pacfile.py:272-287).  Output: the 2048-sample block
+ *                before overlap-and-add.
+ *   k_ola_pcm  : hop h = second half of block h-1 + first half of block h
+ *                (coder/pacfile.py:289-295; the last half is flushed at EOF,
+ *                :245-249), then the 16-bit PCM mapping of coder/pcmfile.py:127-134.
+ *
+ * The IMDCT reuses the forward machinery: y = 2 * unfold(DCT4(X)) where DCT4 is the
+ * same "pre-twiddle, N/4-point complex FFT, post-twiddle" pipeline the MDCT
+ * kernels apply to the folded input (tools/proto_wave_fft.py:imdct_via_dct4).
+ */
+#include "pacx_dev.h"
+#include "wave_fft.h"
+
+#define UNPACK_WORDS 552
+
+__device__ __forceinline__ unsigned get_bits(const unsigned *words, int pos, int width)
+{
+    /* stream bit p lives in word p>>5 at bit 31-(p&31) (MSB first) */
+    if (width <= 0)
+        return 0u;
+    const int w = pos >> 5, o = pos & 31;
+    const unsigned long long two = ((unsigned long long)words[w] << 32) | words[w + 1];
+    return (unsigned)((two >> (64 - o - width)) & ((1ull << width) - 1ull));
+}
+
+/* ------------------------------------------------------------------ unpack */
+__global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, const uint8_t *__restrict__ payload,
+                                              int payload_stride, const long long *__restrict__ offsets,
+                                              const int32_t *__restrict__ n_bytes,
+                                              uint8_t *__restrict__ flags_out, int32_t *__restrict__ overall,
+                                              int32_t *__restrict__ scale_factor, int32_t *__restrict__ bit_alloc,
+                                              int32_t *__restrict__ mantissa)
+{
+    __shared__ unsigned words[UNPACK_WORDS];
+    __shared__ int offs[PACX_SUB][PACX_MAX_BANDS], bas[PACX_SUB][PACX_MAX_BANDS];
+    __shared__ int is_short_s;
+    const int lane = threadIdx.x;
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf)
+        return;
+    const int nbytes = n_bytes[cf];
+    const uint8_t *src = payload + (offsets ? offsets[cf] : cf * (long long)payload_stride);
+    const int n_words = (nbytes + 3) >> 2;
+    for (int i = lane; i < UNPACK_WORDS; i += 64) {
+        unsigned v = 0;
+        if (i < n_words) {
+            /* byte loads: the record may start at any byte offset of a file body */
+            const int b0 = 4 * i;
+            v = ((unsigned)src[b0] << 24) | ((b0 + 1 < nbytes ? (unsigned)src[b0 + 1] : 0u) << 16) |
+                ((b0 + 2 < nbytes ? (unsigned)src[b0 + 2] : 0u) << 8) | (b0 + 3 < nbytes ? (unsigned)src[b0 + 3] : 0u);
+        }
+        words[i] = v;
+    }
+    __syncthreads();
+    int32_t *ba_o = bit_alloc + cf * T.band_stride, *sf_o = scale_factor + cf * T.band_stride;
+    if (lane == 0) {
+        const unsigned fl = get_bits(words, 0, 1) | (get_bits(words, 1, 1) << 1) | (get_bits(words, 2, 1) << 2);
+        flags_out[cf] = (uint8_t)fl;
+        const int shrt = (fl >> 1) & 1;
+        is_short_s = shrt;
+        const int nb = shrt ? T.nb_short : T.nb_long;
+        const int32_t *cnt = shrt ? T.band_lines_short : T.band_lines_long;
+        int pos = 3;
+        for (int s = 0; s < (shrt ? PACX_SUB : 1); ++s) {
+            overall[cf * PACX_SUB + s] = (int)get_bits(words, pos, T.n_scale_bits);
+            pos += T.n_scale_bits;
+            for (int b = 0; b < nb; ++b) {
+                int a = (int)get_bits(words, pos, T.n_mant_size_bits);
+                if (a)
+                    a += 1;
+                const int sf = (int)get_bits(words, pos + T.n_mant_size_bits, T.n_scale_bits);
+                pos += T.n_mant_size_bits + T.n_scale_bits;
+                offs[s][b] = pos;
+                bas[s][b] = a;
+                ba_o[s * nb + b] = a;
+                sf_o[s * nb + b] = sf;
+                pos += a * cnt[b];
+            }
+        }
+        if (!shrt)
+            for (int s = 1; s < PACX_SUB; ++s)
+                overall[cf * PACX_SUB + s] = 0;
+    }
+    __syncthreads();
+    const int shrt = is_short_s;
+    const uint8_t *band_of = shrt ? T.line_band_short : T.line_band_long;
+    const int32_t *lower = shrt ? T.band_lower_short : T.band_lower_long;
+    const int m_lines = shrt ? PACX_M_SHORT : PACX_M_LONG;
+    for (int k = lane; k < PACX_M_LONG; k += 64) {
+        const int s = shrt ? k / PACX_M_SHORT : 0;
+        const int kk = k - s * m_lines;
+        const int b = band_of[kk];
+        const int a = bas[s][b];
+        mantissa[cf * PACX_M_LONG + k] = a ? (int32_t)get_bits(words, offs[s][b] + (kk - lower[b]) * a, a) : 0;
+    }
+}
+
+/* one dequantised line: vDequantize (coder/quantize.py:260-274) then / 2^overall */
+__device__ __forceinline__ double dequant_line(int mant, int scale, int ba, int n_scale_bits, int overall)
+{
+    if (!ba)
+        return 0.0;
+    const int r_bits = (1 << n_scale_bits) - 1 + ba;
+    const long long sign = (mant & (1 << (ba - 1))) ? -1 : 1;
+    const long long code = mant & ((1 << (ba - 1)) - 1);
+    const int shift = r_bits - scale - ba;                 /* = 2^nScaleBits - 1 - scale */
+    long long a = code << (shift > 0 ? shift : 0);
+    if (scale < (1 << n_scale_bits) - 1 && code > 0)
+        a += 1ll << (shift - 1);
+    const double v = (double)(sign * 2 * a) / (double)((1ll << r_bits) - 1);
+    return v / (double)(1 << overall);
+}
+
+/* -------------------------------------------------------------- IMDCT long */
+__global__ __launch_bounds__(64) void k_imdct_long(PacxTables T, long long n_cf, const uint8_t *__restrict__ cf_flags,
+                                                  const int32_t *__restrict__ overall,
+                                                  const int32_t *__restrict__ scale_factor,
+                                                  const int32_t *__restrict__ bit_alloc,
+                                                  const int32_t *__restrict__ mantissa,
+                                                  double *__restrict__ blocks)
+{
+    __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
+    __shared__ __attribute__((aligned(16))) double buf[PACX_M_LONG];
+    const int lane = threadIdx.x;
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf)
+        return;
+    const unsigned fl = cf_flags[cf];
+    if (fl & 2u)
+        return;                                            /* short frame: k_imdct_short */
+    const int ov = overall[cf * PACX_SUB];
+    const int32_t *ba = bit_alloc + cf * T.band_stride, *sf = scale_factor + cf * T.band_stride;
+    for (int k = lane; k < PACX_M_LONG; k += 64) {
+        const int b = T.line_band_long[k];
+        buf[k] = dequant_line(mantissa[cf * PACX_M_LONG + k], sf[b], ba[b], T.n_scale_bits, ov);
+    }
+    __syncthreads();
+    const int M = PACX_M_LONG, Q = M / 2;
+    cplx v[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = lane + 64 * n1;
+        v[n1] = c_mul(make_double2(buf[2 * n], buf[M - 1 - 2 * n]), T.tw_long[n]);
+    }
+    __syncthreads();
+    fft512(v, tile, T.w512, lane);
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) {
+        const int k = fft512_out_index(lane, k3);
+        const cplx y = c_mul(v[k3], T.tw_long[k]);
+        buf[2 * k] = y.x;                                  /* DCT-IV of the lines */
+        buf[M - 1 - 2 * k] = -y.y;
+    }
+    __syncthreads();
+    /* y = 2 * unfold(DCT4), then the block's window */
+    const double *__restrict__ w = T.win_long + pacx_window_kind(fl) * PACX_N_LONG;
+    double *__restrict__ out = blocks + cf * PACX_N_LONG;
+    for (int i = lane; i < PACX_N_LONG; i += 64) {
+        double t;
+        if (i < Q)
+            t = buf[Q + i];
+        else if (i < M)
+            t = -buf[Q + (M - 1 - i)];
+        else if (i < 3 * Q)
+            t = -buf[3 * Q - 1 - i];
+        else
+            t = -buf[i - 3 * Q];
+        out[i] = w[i] * (2.0 * t);
+    }
+}
+
+/* ------------------------------------------------------------- IMDCT short */
+__global__ __launch_bounds__(64) void k_imdct_short(PacxTables T, long long n_cf, const uint8_t *__restrict__ cf_flags,
+                                                   const int32_t *__restrict__ overall,
+                                                   const int32_t *__restrict__ scale_factor,
+                                                   const int32_t *__restrict__ bit_alloc,
+                                                   const int32_t *__restrict__ mantissa,
+                                                   double *__restrict__ blocks)
+{
+    __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
+    __shared__ __attribute__((aligned(16))) double buf[PACX_SUB][PACX_M_SHORT];
+    const int lane = threadIdx.x;
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf)
+        return;
+    const unsigned fl = cf_flags[cf];
+    if (!(fl & 2u))
+        return;
+    const int32_t *ba = bit_alloc + cf * T.band_stride, *sf = scale_factor + cf * T.band_stride;
+    for (int k = lane; k < PACX_M_LONG; k += 64) {
+        const int s = k / PACX_M_SHORT, kk = k % PACX_M_SHORT;
+        const int b = T.line_band_short[kk];
+        buf[s][kk] = dequant_line(mantissa[cf * PACX_M_LONG + k], sf[s * T.nb_short + b], ba[s * T.nb_short + b],
+                                  T.n_scale_bits, overall[cf * PACX_SUB + s]);
+    }
+    __syncthreads();
+    const int g = lane >> 3, r = lane & 7;
+    const int M = PACX_M_SHORT, Q = M / 2;
+    cplx v[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = r + 8 * n1;
+        v[n1] = c_mul(make_double2(buf[g][2 * n], buf[g][M - 1 - 2 * n]), T.tw_short[n]);
+    }
+    __syncthreads();
+    fft64x8(v, tile, T.w512, lane);
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) {
+        const int k = fft64_out_index(lane, k3);
+        const cplx y = c_mul(v[k3], T.tw_short[k]);
+        buf[g][2 * k] = y.x;
+        buf[g][M - 1 - 2 * k] = -y.y;
+    }
+    __syncthreads();
+    /* sample i of the 2048 block: sum over the (at most two) sub-blocks that cover it,
+       in ascending sub-block order as the reference's += does */
+    const double *__restrict__ w = T.win_short;
+    double *__restrict__ out = blocks + cf * PACX_N_LONG;
+    for (int i = lane; i < PACX_N_LONG; i += 64) {
+        double acc = 0.0;
+        for (int s = 0; s < PACX_SUB; ++s) {
+            const int ii = i - (PACX_SHORT_FIRST + PACX_M_SHORT * s);
+            if (ii < 0 || ii >= PACX_N_SHORT)
+                continue;
+            double t;
+            if (ii < Q)
+                t = buf[s][Q + ii];
+            else if (ii < M)
+                t = -buf[s][Q + (M - 1 - ii)];
+            else if (ii < 3 * Q)
+                t = -buf[s][3 * Q - 1 - ii];
+            else
+                t = -buf[s][ii - 3 * Q];
+            acc += w[ii] * (2.0 * t);
+        }
+        out[i] = acc;
+    }
+}
+
+/* ------------------------------------------------- overlap-add + PCM mapping */
+__global__ void k_ola_pcm(long long n_blocks, int n_ch, const double *__restrict__ blocks,
+                          int16_t *__restrict__ pcm)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   /* (hop, sample, channel) */
+    const long long total = (n_blocks + 1) * PACX_M_LONG * n_ch;
+    if (idx >= total)
+        return;
+    const int ch = (int)(idx % n_ch);
+    const long long t = idx / n_ch;
+    const long long h = t / PACX_M_LONG;
+    const int i = (int)(t % PACX_M_LONG);
+    double s;
+    if (h < n_blocks) {
+        const double prev = (h >= 1) ? blocks[((h - 1) * n_ch + ch) * PACX_N_LONG + PACX_M_LONG + i] : 0.0;
+        s = prev + blocks[(h * n_ch + ch) * PACX_N_LONG + i];
+    } else {
+        s = (h >= 1) ? blocks[((h - 1) * n_ch + ch) * PACX_N_LONG + PACX_M_LONG + i] : 0.0;   /* EOF flush */
+    }
+    const bool neg = signbit(s);
+    const long long q = pacx_quant_mag(fabs(s), 16);
+    pcm[idx] = (int16_t)(neg ? -q : q);
+}
+
+/* ------------------------------------------------------------- launchers */
+void pacx_launch_unpack(const PacxTables &T, long long n_cf, const uint8_t *payload, int payload_stride,
+                        const long long *offsets, const int32_t *n_bytes, uint8_t *flags_out, int32_t *overall,
+                        int32_t *scale_factor, int32_t *bit_alloc, int32_t *mantissa, hipStream_t st)
+{
+    if (n_cf > 0)
+        hipLaunchKernelGGL(k_unpack, dim3((unsigned)n_cf), dim3(64), 0, st, T, n_cf, payload, payload_stride,
+                           offsets, n_bytes, flags_out, overall, scale_factor, bit_alloc, mantissa);
+}
+
+void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const uint8_t *cf_flags,
+                        const int32_t *overall, const int32_t *scale_factor, const int32_t *bit_alloc,
+                        const int32_t *mantissa, double *blocks, int16_t *pcm, hipStream_t st)
+{
+    const long long n_cf = n_blocks * n_ch;
+    if (n_cf > 0) {
+        hipLaunchKernelGGL(k_imdct_long, dim3((unsigned)n_cf), dim3(64), 0, st, T, n_cf, cf_flags, overall,
+                           scale_factor, bit_alloc, mantissa, blocks);
+        hipLaunchKernelGGL(k_imdct_short, dim3((unsigned)n_cf), dim3(64), 0, st, T, n_cf, cf_flags, overall,
+                           scale_factor, bit_alloc, mantissa, blocks);
+    }
+    if (pcm) {
+        const long long total = (n_blocks + 1) * PACX_M_LONG * n_ch;
+        hipLaunchKernelGGL(k_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n_blocks, n_ch, blocks,
+                           pcm);
+    }
+}

@@ -53,6 +53,13 @@ void pacx_launch_bitalloc_generic(long long n, int nb, const int32_t *n_lines, c
 void pacx_launch_transient(const PacxPcmView &in, long long n_hops, int hop, uint8_t *transient,
                            uint8_t *flags, hipStream_t st);
 
+void pacx_launch_unpack(const PacxTables &T, long long n_cf, const uint8_t *payload, int payload_stride,
+                        const long long *offsets, const int32_t *n_bytes, uint8_t *flags_out, int32_t *overall,
+                        int32_t *scale_factor, int32_t *bit_alloc, int32_t *mantissa, hipStream_t st);
+void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const uint8_t *cf_flags,
+                        const int32_t *overall, const int32_t *scale_factor, const int32_t *bit_alloc,
+                        const int32_t *mantissa, double *blocks, int16_t *pcm, hipStream_t st);
+
 #define PACX_PAYLOAD_STRIDE 2192
 
 struct pacx_handle {
@@ -70,6 +77,8 @@ struct pacx_handle {
     int32_t *ws_overall;              /* [ws_cf][8]                             */
     long long *ws_chunks;             /* [ws_cf/256 + 2]                        */
     long long *ws_offs;               /* [ws_cf]                                */
+    long long ws_blocks_cf;           /* decode: capacity of ws_blocks          */
+    double *ws_blocks;                /* [cf][2048] blocks before overlap-add   */
     std::string err;
 };
 
@@ -178,6 +187,8 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     pacx_handle *h = new pacx_handle();
     h->device = cfg->device;
     h->ws_cf = 0;
+    h->ws_blocks_cf = 0;
+    h->ws_blocks = nullptr;
     h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
     h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr; h->ws_nkept = nullptr;
     memset(&h->T, 0, sizeof(h->T));
@@ -324,6 +335,8 @@ extern "C" void pacx_destroy(pacx_handle *h)
         return;
     (void)hipSetDevice(h->device);
     free_ws(h);
+    if (h->ws_blocks)
+        (void)hipFree(h->ws_blocks);
     for (void *p : h->owned)
         (void)hipFree(p);
     delete h;
@@ -650,4 +663,53 @@ extern "C" int pacx_transient_flags(pacx_handle *h, const pacx_pcm *hops, uint8_
     HIP_TRY(h, hipSetDevice(h->device));
     pacx_launch_transient(v, hops->n_frames, PACX_M_LONG, transient, frame_flags, (hipStream_t)stream);
     return post_launch(h, "pacx_transient_flags");
+}
+
+/* ---- decode side (k_decode.hip) ------------------------------------------ */
+extern "C" int pacx_unpack_batch(pacx_handle *h, int64_t n_cf, const uint8_t *payload, int payload_stride,
+                                 const int64_t *offsets, const int32_t *n_bytes, uint8_t *cf_flags,
+                                 int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,
+                                 int32_t *mantissa, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_cf == 0)
+        return PACX_OK;
+    if (n_cf < 0 || !payload || !n_bytes || !cf_flags || !overall_scale || !scale_factor || !bit_alloc ||
+        !mantissa || (!offsets && payload_stride <= 0))
+        return fail(h, PACX_E_ARG, "pacx_unpack_batch: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_unpack(h->T, n_cf, payload, payload_stride, (const long long *)offsets, n_bytes, cf_flags,
+                       overall_scale, scale_factor, bit_alloc, mantissa, (hipStream_t)stream);
+    return post_launch(h, "pacx_unpack_batch");
+}
+
+extern "C" int pacx_decode_batch(pacx_handle *h, int64_t n_blocks, int n_channels, const uint8_t *cf_flags,
+                                 const int32_t *overall_scale, const int32_t *scale_factor,
+                                 const int32_t *bit_alloc, const int32_t *mantissa, double *blocks,
+                                 int16_t *pcm, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_blocks < 0 || n_channels < 1 || (n_blocks > 0 && (!cf_flags || !overall_scale || !scale_factor ||
+                                                              !bit_alloc || !mantissa)) || (!blocks && !pcm))
+        return fail(h, PACX_E_ARG, "pacx_decode_batch: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const long long n_cf = n_blocks * n_channels;
+    double *work = blocks;
+    if (!work && n_cf > 0) {
+        if (n_cf > h->ws_blocks_cf) {
+            HIP_TRY(h, hipDeviceSynchronize());
+            if (h->ws_blocks)
+                (void)hipFree(h->ws_blocks);
+            h->ws_blocks = nullptr;
+            h->ws_blocks_cf = 0;
+            HIP_TRY(h, hipMalloc((void **)&h->ws_blocks, (size_t)n_cf * PACX_N_LONG * sizeof(double)));
+            h->ws_blocks_cf = n_cf;
+        }
+        work = h->ws_blocks;
+    }
+    pacx_launch_decode(h->T, n_blocks, n_channels, cf_flags, overall_scale, scale_factor, bit_alloc, mantissa,
+                       work, pcm, (hipStream_t)stream);
+    return post_launch(h, "pacx_decode_batch");
 }

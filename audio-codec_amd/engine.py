@@ -265,6 +265,30 @@ class Encoder:
         self._call("pacx_transient_flags", ctypes.byref(view), _ptr(tr), _ptr(fl), self._stream())
         return tr[:n_hops], fl
 
+    # ------------------------------------------------------------ decode side
+    def unpack(self, payload, n_bytes, offsets=None):
+        """Parse packed channel-blocks (slot layout, or a byte stream + int64 offsets)."""
+        n_cf = n_bytes.shape[0]
+        out = self.alloc_outputs(n_cf)
+        out["flags"] = self._empty((n_cf,), torch.uint8)
+        stride = 0 if offsets is not None else int(payload.shape[1])
+        self._call("pacx_unpack_batch", ctypes.c_int64(n_cf), _ptr(payload), stride, _ptr(offsets),
+                   _ptr(n_bytes), _ptr(out["flags"]), _ptr(out["overall"]), _ptr(out["scale_factor"]),
+                   _ptr(out["bit_alloc"]), _ptr(out["mantissa"]), self._stream())
+        return out
+
+    def decode(self, codes, n_channels, want_blocks=False, want_pcm=True):
+        """codec.Decode + overlap-and-add + PCM for blocks in stream order.
+        codes: dict with flags (per cf), overall, scale_factor, bit_alloc, mantissa."""
+        n_cf = codes["bit_alloc"].shape[0]
+        n_blocks = n_cf // n_channels
+        blocks = self._empty((n_cf, 2 * N_LONG), torch.float64) if want_blocks else None
+        pcm = self._empty(((n_blocks + 1) * N_LONG, n_channels), torch.int16) if want_pcm else None
+        self._call("pacx_decode_batch", ctypes.c_int64(n_blocks), int(n_channels), _ptr(codes["flags"]),
+                   _ptr(codes["overall"]), _ptr(codes["scale_factor"]), _ptr(codes["bit_alloc"]),
+                   _ptr(codes["mantissa"]), _ptr(blocks), _ptr(pcm), self._stream())
+        return (blocks, pcm) if want_blocks and want_pcm else (blocks if want_blocks else pcm)
+
     # ------------------------------------------- function-level entry points
     def window(self, kind, x):
         """window * x for rows of x ([n, 2048] or [n, 256] float64 on the GPU)."""

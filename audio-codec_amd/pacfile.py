@@ -141,3 +141,47 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, hea
     body, total = enc.gather_body(payload, n_bytes)
     n = int(total.item())
     return head + body[:n].cpu().numpy().tobytes()
+
+
+def parse_header(data):
+    """coder/pacfile.py:142-151 -> (CodingParams, header length)."""
+    from struct import unpack, calcsize
+    from .audiofile import CodingParams
+    if data[:4] != b"PAC ":
+        raise RuntimeError("Tried to read a non-PAC file into a PACFile object")
+    fmt = "<LHLLHHHH"
+    (sr, n_ch, n_samples, n_lines, n_scale, n_mant_size, use_sbr, use_vq) = unpack(fmt, data[4:4 + calcsize(fmt)])
+    pos = 4 + calcsize(fmt)
+    n_bands = unpack("<L", data[pos:pos + 4])[0]
+    n_lines_band = unpack("<" + str(n_bands) + "H", data[pos + 4:pos + 4 + 2 * n_bands])
+    cp = CodingParams()
+    cp.sampleRate, cp.nChannels, cp.numSamples = sr, n_ch, n_samples
+    cp.nMDCTLines = cp.nSamplesPerBlock = n_lines
+    cp.nScaleBits, cp.nMantSizeBits = n_scale, n_mant_size
+    cp.useSBR, cp.useVQ = bool(use_sbr), bool(use_vq)
+    cp.sfBands = ScaleFactorBands(n_lines_band)
+    cp.sfBandsShort = ScaleFactorBands(AssignMDCTLinesFromFreqLimits(128, sr))
+    cp.targetBitsPerSample = 128 / (sr / 1000)            # not used by the decoder
+    return cp, pos + 4 + 2 * n_bands
+
+
+def decode_stream(data):
+    """Whole scalar-path .pac (bytes) -> int16 [n, nCh], batched on the GPU: what
+    the reference's decode loop (coder/pacfile.py:745-757) writes as PCM."""
+    import torch
+    cp, pos = parse_header(data)
+    if cp.useVQ or cp.useSBR:
+        raise NotImplementedError("the GPU decoder handles scalar-mantissa streams (useVQ/useSBR False)")
+    enc = context.encoder_for_params(cp)
+    offs, sizes = [], []
+    while pos < len(data):                                # the '<L nBytes' chain is sequential by nature
+        n = int.from_bytes(data[pos:pos + 4], "little")
+        offs.append(pos + 4)
+        sizes.append(n)
+        pos += 4 + n
+    if len(offs) % cp.nChannels:
+        raise RuntimeError("Only read a partial block of coded PACFile data")
+    body = torch.frombuffer(bytearray(data) + bytearray(8), dtype=torch.uint8).to(enc.device)
+    codes = enc.unpack(body, torch.tensor(sizes, dtype=torch.int32, device=enc.device),
+                       torch.tensor(offs, dtype=torch.int64, device=enc.device))
+    return enc.decode(codes, cp.nChannels).cpu().numpy()

@@ -284,6 +284,35 @@ int pacx_bitalloc_generic(pacx_handle *h, int64_t n, int n_bands, const int32_t 
 int pacx_transient_flags(pacx_handle *h, const pacx_pcm *hops, uint8_t *transient,
                          uint8_t *frame_flags, void *stream);
 
+/* ---- decode side (scalar-mantissa streams) ---------- */
+
+/*
+ * Inverse of pacx_pack_batch: parse the payload of every channel-block
+ * (coder/pacfile.py:185-213, 264-266).  Payload i starts at
+ * payload + offsets[i] (offsets != NULL, e.g. a .pac body) or at
+ * payload + i*payload_stride.  Outputs use the layouts of pacx_encode_batch;
+ * cf_flags: uint8 [n_cf] PACX_FLAG_* read from each payload.
+ */
+int pacx_unpack_batch(pacx_handle *h, int64_t n_cf, const uint8_t *payload, int payload_stride,
+                      const int64_t *offsets, const int32_t *n_bytes, uint8_t *cf_flags,
+                      int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,
+                      int32_t *mantissa, void *stream);
+
+/*
+ * codec.Decode for a batch (coder/codec.py:47-92: vDequantize, / 2^overall, IMDCT,
+ * window) and the overlap-and-add + 16-bit PCM mapping around it
+ * (coder/pacfile.py:272-295, coder/pcmfile.py:127-134).  Blocks are in stream
+ * order, n_blocks hops of n_channels channels.
+ *   blocks: optional float64 [n_blocks*n_channels][2*n_lines_long], the windowed
+ *           IMDCT output before overlap-and-add (what codec.Decode returns);
+ *   pcm:    optional int16 [(n_blocks+1)*n_lines_long][n_channels] (interleaved):
+ *           every hop plus the final half-block the reference flushes at EOF.
+ */
+int pacx_decode_batch(pacx_handle *h, int64_t n_blocks, int n_channels, const uint8_t *cf_flags,
+                      const int32_t *overall_scale, const int32_t *scale_factor,
+                      const int32_t *bit_alloc, const int32_t *mantissa, double *blocks,
+                      int16_t *pcm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -772,3 +772,98 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False,
         last_t, cur_t = cur_t, nxt
     emit([np.zeros(hop_n) for _ in range(n_ch)], (False, False, False))
     return b''.join(out)
+
+
+# ------------------------------------------------------ section 8f-4: decode path
+def fraction_to_pcm16(x):
+    """Signed fractions -> int16 codes as coder/pcmfile.py:127-134 does it:
+    magnitude through the 16-bit midtread quantiser, then the sign back."""
+    x = np.array(x, dtype=np.float64)
+    neg = np.signbit(x)
+    x[neg] *= -1.
+    q = quantize_uniform_vec(x, 16).astype(np.int16)
+    q[neg] *= -1
+    return q
+
+
+def decode_block(p, sf, alloc, mant_lines, overall, last_t, cur_t, next_t):
+    """coder/codec.py:59-92: dequantise allocated bands, undo the overall scale,
+    IMDCT, window.  mant_lines is LINE-indexed (coder/pacfile.py:190,212-213)."""
+    bands = p.sfBandsShort if cur_t else p.sfBands
+    half_n = p.nMDCTLines
+    lines = np.zeros(half_n, dtype=np.float64)
+    at = 0
+    for b in range(bands.nBands):
+        n = bands.nLines[b]
+        if alloc[b]:
+            lines[at:at + n] = dequantize_vec(sf[b], mant_lines[at:at + n], p.nScaleBits, alloc[b])
+        at += n
+    lines /= 1. * (1 << overall)
+    win = window_table(window_kind(last_t, cur_t, next_t), 2 * half_n)
+    return win * mdct_inverse(lines, half_n, half_n)
+
+
+def parse_block_body(br, p, cur_t):
+    """coder/pacfile.py:185-213."""
+    bands = p.sfBandsShort if cur_t else p.sfBands
+    overall = br.get(p.nScaleBits)
+    alloc, sf = [], []
+    mant = np.zeros(p.nMDCTLines, np.int32)
+    for b in range(bands.nBands):
+        a = br.get(p.nMantSizeBits)
+        if a:
+            a += 1
+        alloc.append(a)
+        sf.append(br.get(p.nScaleBits))
+        if a:
+            for j in range(bands.nLines[b]):
+                mant[bands.lowerLine[b] + j] = br.get(a)
+    return sf, alloc, mant, overall
+
+
+def parse_header(data):
+    """coder/pacfile.py:142-151.  Returns (params, numSamples, header length)."""
+    assert data[:4] == b'PAC '
+    (sr, n_ch, n_samples, n_lines, n_scale, n_mant_size, use_sbr, use_vq) = struct.unpack(
+        '<LHLLHHHH', data[4:4 + struct.calcsize('<LHLLHHHH')])
+    pos = 4 + struct.calcsize('<LHLLHHHH')
+    n_bands = struct.unpack('<L', data[pos:pos + 4])[0]
+    pos += 4 + 2 * n_bands
+    assert not use_sbr and not use_vq and n_lines == 1024
+    p = make_params(sr, n_ch, 128, n_lines, n_scale, n_mant_size)
+    return p, n_samples, pos
+
+
+def decode_stream(data):
+    """Whole scalar-path .pac -> int16 [n, nCh]: coder/pacfile.py:231-298 block by
+    block (short frames: eight 256-sample sub-blocks overlap-added at
+    n = 448 + 128 j), overlap-add of halves, the last half flushed at EOF
+    (:245-249), PCM conversion of coder/pcmfile.py:127-134."""
+    p, _, pos = parse_header(data)
+    n_ch, hop = p.nChannels, p.nMDCTLines
+    ola = [np.zeros(hop) for _ in range(n_ch)]
+    out = []
+    while pos < len(data):
+        hop_out = []
+        for ch in range(n_ch):
+            n_bytes = struct.unpack('<L', data[pos:pos + 4])[0]
+            br = BitReader(data[pos + 4:pos + 4 + n_bytes])
+            pos += 4 + n_bytes
+            last_t, cur_t, next_t = br.get(1), br.get(1), br.get(1)
+            if not cur_t:
+                block = decode_block(p, *parse_block_body(br, p, False), last_t, cur_t, next_t)
+            else:
+                block = np.zeros(2 * hop)
+                p.nMDCTLines = p.nSamplesPerBlock = SHORT_LINES
+                try:
+                    pad = hop // 2 - SHORT_LINES // 2
+                    for n in range(pad, 2 * hop - SHORT_LINES - pad, SHORT_LINES):
+                        block[n:n + 2 * SHORT_LINES] += decode_block(
+                            p, *parse_block_body(br, p, True), last_t, cur_t, next_t)
+                finally:
+                    p.nMDCTLines = p.nSamplesPerBlock = hop
+            hop_out.append(np.add(ola[ch], block[:hop]))
+            ola[ch] = block[hop:]
+        out.append(np.stack([fraction_to_pcm16(h) for h in hop_out], axis=1))
+    out.append(np.stack([fraction_to_pcm16(o) for o in ola], axis=1))
+    return np.concatenate(out)

@@ -408,6 +408,42 @@ def make_excerpts(wavs):
         np.savez_compressed(os.path.join(HERE, f"excerpt_{name}.npz"), **res)
 
 
+def ref_decode_file(pac_path, wav_path):
+    """The reference's own PACFile -> PCMFile decode loop (coder/pacfile.py:745-757).
+    Shim: PackedBits keeps `bytes` (NumPy-2 uint8 overflow in ReadBits)."""
+    def keep_bytes(self, data):
+        self.nBytes = len(data)
+        self.data = bytes(data)
+    bitpack.PackedBits.SetPackedData = keep_bytes
+    src = pacfile.PACFile(pac_path)
+    dst = pcmfile.PCMFile(wav_path)
+    cp = src.OpenForReading()
+    cp.bitsPerSample = 16
+    dst.OpenForWriting(cp)
+    while True:
+        data = src.ReadDataBlock(cp)
+        if not data:
+            break
+        dst.WriteDataBlock(data, cp)
+    src.Close(cp)
+    dst.Close(cp)
+    raw = open(wav_path, "rb").read()
+    return np.frombuffer(raw[44:], dtype="<i2").reshape(-1, cp.nChannels).copy()
+
+
+def make_decoded():
+    """Decode the excerpt .pac goldens with the reference's decoder."""
+    for name in ["castanet", "harpsichord", "quar48_1", "spmg"]:
+        ex = np.load(os.path.join(HERE, f"excerpt_{name}.npz"))
+        res = {}
+        for tag in ("long", "bs"):
+            pac = os.path.join(_work, f"dec_{name}_{tag}.pac")
+            open(pac, "wb").write(bytes(ex[f"pac_{tag}"]))
+            res[f"pcm_{tag}"] = ref_decode_file(pac, os.path.join(_work, f"dec_{name}_{tag}.wav"))
+            print(name, tag, res[f"pcm_{tag}"].shape)
+        np.savez_compressed(os.path.join(HERE, f"decoded_{name}.npz"), **res)
+
+
 def _full_one(args):
     name, bs = args
     path = os.path.join(REF, "test_signals", name + ".wav")
@@ -448,7 +484,9 @@ if __name__ == "__main__":
     names = ["castanet", "harpsichord", "quar48_1", "spmg"]
     wavs = {n: read_wav(os.path.join(REF, "test_signals", n + ".wav"))
             for n in names}
-    if "--full" in sys.argv:
+    if "--decoded" in sys.argv:
+        make_decoded()
+    elif "--full" in sys.argv:
         make_full(names)
         make_full_inputs(names)
     else:

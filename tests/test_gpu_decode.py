@@ -1,0 +1,91 @@
+"""GPU decode side against the PCM the reference's own decoder
+produced from the golden excerpt .pac files, plus size-independent round trips."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import EXCERPTS, GOLDEN, load_excerpt
+from oracle import pac_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import audio_codec_amd as a
+    a.load()
+    return a
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    return t
+
+
+@pytest.mark.parametrize("name", EXCERPTS)
+@pytest.mark.parametrize("tag", ["long", "bs"])
+def test_decode_matches_reference_pcm(A, name, tag):
+    ex = load_excerpt(name)
+    want = np.load(os.path.join(GOLDEN, f"decoded_{name}.npz"))[f"pcm_{tag}"]
+    got = A.pacfile.decode_stream(bytes(ex[f"pac_{tag}"]))
+    assert got.dtype == np.int16 and got.shape == want.shape
+    # IMDCT rounding (1e-13) against a 3e-5 PCM step: bit-exact in practice
+    assert np.array_equal(got, want), int(np.sum(got != want))
+
+
+def test_unpack_inverts_pack(A, torch):
+    """Block-switched castanet excerpt: unpack(pack(codes)) == codes, flags included."""
+    ex = load_excerpt("castanet")
+    sr = int(ex["sr"])
+    enc = A.context.encoder(sr, 128 / (sr / 1000))
+    planar = A.pacfile.device_stream(enc, ex["pcm"])
+    _, fl = enc.transient_flags(planar, len(ex["pcm"]) // 1024)
+    out = enc.encode(A.engine.PcmView.stream(planar), fl)
+    payload, n_bytes = enc.pack(out, 2)
+    keep = n_bytes > 0                                   # dropped hops have no payload
+    back = enc.unpack(payload[keep], n_bytes[keep])
+    assert torch.equal(back["flags"], fl.repeat_interleave(2)[keep])
+    for k in ("scale_factor", "bit_alloc", "mantissa"):
+        assert torch.equal(back[k], out[k][keep]), k
+    short = (back["flags"] & 2).bool()
+    assert torch.equal(back["overall"][short], out["overall"][keep][short])
+    assert torch.equal(back["overall"][~short][:, 0], out["overall"][keep][~short][:, 0])
+    # blocks (codec.Decode output) of a few frames against the oracle
+    blocks = enc.decode(back, 2, want_blocks=True, want_pcm=False).cpu().numpy()
+    host = {k: v.cpu().numpy() for k, v in back.items()}
+    p = po.make_params(sr, 2, 128)
+    for i in (0, 5, 40, 41, 90):
+        f = host["flags"][i]
+        last, cur, nxt = f & 1, (f >> 1) & 1, (f >> 2) & 1
+        if cur:
+            continue
+        sf, ba, mant, ov = A.codec.unpack_long(enc, host, i)
+        line_mant = host["mantissa"][i]
+        want = po.decode_block(p, sf, ba, line_mant, ov, last, cur, nxt)
+        assert np.max(np.abs(blocks[i] - want)) <= 1e-12 * max(np.max(np.abs(want)), 1e-30)
+
+
+def test_full_size_round_trip(A, torch):
+    """BASELINE configs[1] size: encode 4096 stereo frames, pack, unpack, decode on the
+    GPU; the decoded PCM is the input delayed by one hop at the coder's SNR."""
+    n = 4096
+    pcm = A.synth.stream(n, 2)
+    enc = A.context.encoder(48000, 128 / 48.0)
+    planar = A.pacfile.device_stream(enc, pcm)
+    out = enc.encode(A.engine.PcmView.stream(planar))
+    payload, n_bytes = enc.pack(out, 2)
+    back = enc.unpack(payload, n_bytes)
+    for k in ("scale_factor", "bit_alloc", "mantissa"):
+        assert torch.equal(back[k], out[k]), k
+    dec = enc.decode(back, 2).cpu().numpy()
+    assert dec.shape == ((n + 3) * 1024, 2)
+    x = pcm.astype(np.float64)
+    y = dec[1024:1024 + len(x)].astype(np.float64)
+    snr = 10 * np.log10(np.sum(x ** 2) / np.sum((x - y) ** 2))
+    assert snr > 12.0, snr            # 128 kb/s perceptual coder on tones + white noise: ~15.5 dB
+    # shard-wise decode with a one-block overlap equals the whole decode
+    half = n + 2
+    a = enc.decode({k: v[:half] for k, v in back.items()}, 2).cpu().numpy()
+    assert np.array_equal(a[:(half // 2) * 1024], dec[:(half // 2) * 1024])

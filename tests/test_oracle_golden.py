@@ -199,6 +199,17 @@ def test_excerpt_pac_96k():
     assert got == bytes(ex["pac_long96"])
 
 
+@pytest.mark.parametrize("name", EXCERPTS)
+def test_decode_matches_reference_decoder(name):
+    """oracle.decode_stream vs the PCM the reference's own decoder produced
+    from the golden excerpt .pac files (tests/golden/decoded_*.npz)."""
+    ex = load_excerpt(name)
+    d = np.load(os.path.join(GOLDEN, f"decoded_{name}.npz"))
+    for tag in ("long", "bs"):
+        got = po.decode_stream(bytes(ex[f"pac_{tag}"]))
+        assert got.dtype == np.int16 and np.array_equal(got, d[f"pcm_{tag}"]), (name, tag)
+
+
 def test_numpy_sum_order():
     """np.sum on a contiguous float64 vector = 8-accumulator pairwise scheme;
     the HIP bit allocator (csrc) re-implements exactly this order."""

@@ -241,3 +241,42 @@ if __name__ == "__main__":
     xw = po.sine_window(2048) * rng.standard_normal(2048)
     ref = po.mdct_forward(xw, 1024, 1024)
     print("mdct v2 rel err", np.max(np.abs(mdct_long_v2(xw) - ref)) / np.max(np.abs(ref)))
+
+
+# ---------------------------------------------------------------------------
+# IMDCT through the SAME DCT-IV pipeline as the forward transform: the lines are
+# fed where the folded input u went, the result is unfolded (transpose of the fold)
+def dct4_pipeline(u, M):
+    """what the forward kernel computes from the folded input u (without 2/N)."""
+    Q = M // 2
+    n = np.arange(Q)
+    d = np.exp(-1j * np.pi * (8 * n + 1) / (8 * M))
+    t = (u[2 * n] + 1j * u[M - 1 - 2 * n]) * d
+    T = np.fft.fft(t)
+    y = T * d
+    out = np.zeros(M)
+    out[2 * n] = y.real
+    out[M - 1 - 2 * n] = -y.imag
+    return out
+
+
+def imdct_via_dct4(X, N):
+    M, Q = N // 2, N // 4
+    v = dct4_pipeline(X, M)
+    y = np.zeros(N)
+    n = np.arange(Q)
+    y[3 * Q - 1 - n] = -v[n]
+    y[3 * Q + n] = -v[n]
+    y[n] = v[Q + n]
+    y[M - 1 - n] = -v[Q + n]
+    return y
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(5)
+    for N in (2048, 256):
+        X = rng.standard_normal(N // 2)
+        ref = po.mdct_inverse(X, N // 2, N // 2)
+        got = imdct_via_dct4(X, N)
+        scale = np.dot(ref, got) / np.dot(got, got)
+        print("imdct", N, "scale", scale, "rel err", np.max(np.abs(ref - scale * got)) / np.max(np.abs(ref)))
