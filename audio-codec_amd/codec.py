@@ -88,3 +88,30 @@ def EncodeSingleChannel(data, codingParams, lastTrans=False, curTrans=False, nex
     one.nChannels = 1
     s, b, m, o = Encode([data], one, lastTrans, curTrans, nextTrans)
     return s[0], b[0], m[0], o[0]
+
+
+def Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,
+           lastTrans=False, curTrans=False, nextTrans=False):
+    """coder/codec.py:47-92 for one channel on the GPU (pacx_decode_batch): the
+    windowed IMDCT output, 2*nMDCTLines samples, before overlap-and-add.
+    `mantissa` is line-indexed, as PACFile.getDecodedBlock builds it."""
+    import torch
+    if getattr(codingParams, "useVQ", False):
+        raise NotImplementedError("the GPU decoder handles scalar-mantissa streams (useVQ False)")
+    enc = context.encoder_for_params(codingParams)
+    n_lines = codingParams.nMDCTLines
+    if n_lines not in (1024, 128) or bool(curTrans) != (n_lines == 128):
+        raise NotImplementedError("long blocks have 1024 lines, short (curTrans) blocks 128")
+    nb = len(bitAlloc)
+    codes = enc.alloc_outputs(1)
+    for k in ("overall", "scale_factor", "bit_alloc", "mantissa"):
+        codes[k].zero_()
+    dev = enc.device
+    codes["flags"] = torch.tensor([int(bool(lastTrans)) | int(bool(curTrans)) << 1 | int(bool(nextTrans)) << 2],
+                                  dtype=torch.uint8, device=dev)
+    codes["overall"][0, 0] = int(overallScaleFactor)
+    codes["scale_factor"][0, :nb] = torch.as_tensor(np.asarray(scaleFactor, dtype=np.int32), device=dev)
+    codes["bit_alloc"][0, :nb] = torch.as_tensor(np.asarray(bitAlloc, dtype=np.int32), device=dev)
+    codes["mantissa"][0, :n_lines] = torch.as_tensor(np.asarray(mantissa, dtype=np.int32)[:n_lines], device=dev)
+    block = enc.decode(codes, 1, want_blocks=True, want_pcm=False)[0].cpu().numpy()
+    return block[448:448 + 256].copy() if curTrans else block

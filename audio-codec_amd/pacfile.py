@@ -81,6 +81,55 @@ class PACFile(AudioFile):
         """coder/pacfile.py:627-643."""
         return codec.Encode(data, codingParams, lastTrans, curTrans, nextTrans)
 
+    def Decode(self, scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,
+               lastTrans=False, curTrans=False, nextTrans=False):
+        """coder/pacfile.py:645-668 (no SBR)."""
+        return codec.Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,
+                            lastTrans, curTrans, nextTrans)
+
+    def ReadFileHeader(self):
+        """coder/pacfile.py:136-175."""
+        head = self.fp.read(4 + 22 + 4)
+        n_bands = int.from_bytes(head[-4:], "little")
+        head += self.fp.read(2 * n_bands)
+        cp, _ = parse_header(head)
+        cp.omittedBands = []
+        cp.overlapAndAdd = [np.zeros(cp.nMDCTLines, dtype=np.float64) for _ in range(cp.nChannels)]
+        return cp
+
+    def ReadDataBlock(self, codingParams):
+        """coder/pacfile.py:231-298: one hop of every channel as signed fractions
+        (overlap-and-add done); at the end of the file the pending half-block once,
+        then None.  Unpacking and codec.Decode run on the GPU."""
+        import torch
+        cp = codingParams
+        enc = context.encoder_for_params(cp)
+        payloads = []
+        for ch in range(cp.nChannels):
+            s = self.fp.read(4)
+            if not s:
+                if cp.overlapAndAdd:
+                    tail, cp.overlapAndAdd = cp.overlapAndAdd, 0
+                    return tail
+                return None
+            n = int.from_bytes(s, "little")
+            blob = self.fp.read(n)
+            if len(blob) < n:
+                raise RuntimeError("Only read a partial block of coded PACFile data")
+            payloads.append(blob)
+        slot = enc.payload_stride
+        buf = np.zeros((cp.nChannels, slot), dtype=np.uint8)
+        for ch, blob in enumerate(payloads):
+            buf[ch, :len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+        codes = enc.unpack(torch.as_tensor(buf, device=enc.device),
+                           torch.tensor([len(b) for b in payloads], dtype=torch.int32, device=enc.device))
+        blocks = enc.decode(codes, cp.nChannels, want_blocks=True, want_pcm=False).cpu().numpy()
+        data = []
+        for ch in range(cp.nChannels):
+            data.append(np.add(cp.overlapAndAdd[ch], blocks[ch][:cp.nMDCTLines]))
+            cp.overlapAndAdd[ch] = blocks[ch][cp.nMDCTLines:]
+        return data
+
 
 def stream_flags(pcm, block_switching, hop=1024):
     """(last, cur, next) for every written hop of the driver loop

@@ -100,3 +100,16 @@ def wav_effective_stream(path, hop=1024):
     f.Close(cp)
     pcm = np.concatenate(blocks) if blocks else np.zeros((0, cp.nChannels), dtype=np.int16)
     return cp.sampleRate, pcm, declared
+
+
+def fraction_to_codes(x):
+    """Signed fractions -> int16 codes, coder/pcmfile.py:127-134 (host I/O glue;
+    the batched decoder does this on the GPU in k_ola_pcm)."""
+    x = np.array(x, dtype=np.float64)
+    neg = np.signbit(x)
+    mag = np.abs(x)
+    q = np.floor((65535 * mag + 1) / 2)
+    q[mag >= 1] = 32767
+    q = q.astype(np.int16)
+    q[neg] *= -1
+    return q
