@@ -20,6 +20,10 @@ Outputs
   excerpt_<wav>.npz 64-hop int16 excerpts of the reference's test WAVs with the
                     scalar-path .pac bytes (long-only and block-switched)
   fullfile.json     (--full) sha256 + size of whole-file scalar-path encodes
+  vqfile.json/.npz  (--vq) whole-file encodes in the shipped configuration
+                    (gain-shape PVQ, SBR below 128 kb/s) vs the reference's own
+                    committed test_decoded_full/*.pac; per-block CRCs
+  excerpt_vq_*.npz  (--vq) 24-hop excerpts in the shipped configuration
 """
 import hashlib
 import io
@@ -113,9 +117,10 @@ def ref_params(sr, n_ch, kbps, n_lines=1024):
     return cp
 
 
-def ref_encode_file(wav_path, kbps, block_switching, out_path):
+def ref_encode_file(wav_path, kbps, block_switching, out_path, vq=False):
     """The reference's own PCMFile -> PACFile objects driven the way its
-    encode_decode_test does, with the scalar mantissa path selected."""
+    encode_decode_test does, with the scalar mantissa path selected (or, with
+    vq=True, exactly the shipped settings: useVQ, useSBR below 128 kb/s)."""
     src = pcmfile.PCMFile(wav_path)
     dst = pacfile.PACFile(out_path)
     cp = src.OpenForReading()
@@ -123,8 +128,8 @@ def ref_encode_file(wav_path, kbps, block_switching, out_path):
     cp.nScaleBits = 4
     cp.nMantSizeBits = 12
     cp.targetBitsPerSample = kbps / (cp.sampleRate / 1000)
-    cp.useSBR = False
-    cp.useVQ = False
+    cp.useSBR = bool(vq and kbps < 128)
+    cp.useVQ = bool(vq)
     cp.nSamplesPerBlock = cp.nMDCTLines
     dst.OpenForWriting(cp)
     look = np.zeros((cp.nChannels, 2 * cp.nSamplesPerBlock))
@@ -466,6 +471,77 @@ def make_full_inputs(names):
                             declared=np.array(declared))
 
 
+def _vq_one(args):
+    """One whole-file run of the reference's shipped configuration (useVQ,
+    useSBR below 128 kb/s, block switching) + the per-channel-block CRCs the
+    GPU tests use to compare block by block."""
+    import zlib
+    name, kbps = args
+    sys.setrecursionlimit(12000)
+    path = os.path.join(REF, "test_signals", name + ".wav")
+    out = os.path.join(_work, f"{name}_vq_{kbps}.pac")
+    pac, flags = ref_encode_file(path, kbps, True, out, vq=True)
+    committed = open(os.path.join(REF, "test_decoded_full",
+                                  f"{name}_coded_{kbps}.pac"), "rb").read()
+    pos = 4 + struct.calcsize("<LHLLHHHH")
+    pos += 4 + 2 * struct.unpack("<L", pac[pos:pos + 4])[0]
+    crcs, differs, blk = [], [], 0
+    while pos < len(pac):
+        n = struct.unpack("<L", pac[pos:pos + 4])[0]
+        crcs.append(zlib.crc32(pac[pos:pos + 4 + n]))
+        if len(committed) == len(pac) and committed[pos:pos + 4 + n] != pac[pos:pos + 4 + n]:
+            differs.append(blk)
+        pos += 4 + n
+        blk += 1
+    return (name, kbps, hashlib.sha256(pac).hexdigest(), len(pac),
+            hashlib.sha256(committed).hexdigest(), len(committed),
+            np.array(crcs, dtype=np.uint32), differs)
+
+
+def make_vq(names):
+    """vqfile.json / vqfile.npz: whole-file outputs of the reference run HERE in
+    its shipped configuration, next to the hashes of the .pac files the
+    reference itself committed under test_decoded_full/ (made by its author in
+    2020).  Where the two differ the blocks are listed: they are the
+    rounding-noise-decided DC sub-blocks of quar48_1."""
+    from multiprocessing import Pool
+    jobs = [(n, r) for n in names for r in (128, 96)]
+    with Pool(8) as pool:
+        rows = pool.map(_vq_one, jobs)
+    res, crc = {}, {}
+    for name, kbps, sha, size, csha, csize, crcs, differs in rows:
+        res[f"{name}:{kbps}"] = dict(sha256=sha, size=size, committed_sha256=csha,
+                                     committed_size=csize,
+                                     blocks_differing_from_committed=differs)
+        crc[f"{name}_{kbps}"] = crcs
+        print(name, kbps, sha, size, "== committed" if sha == csha else f"differs in {differs}")
+    json.dump(res, open(os.path.join(HERE, "vqfile.json"), "w"), indent=1,
+              sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "vqfile.npz"), **crc)
+
+
+VQ_EXCERPT_HOPS = 24
+
+
+def make_vq_excerpts(names):
+    """excerpt_vq_<wav>.npz: the first 24 hops of each committed excerpt through
+    the reference's shipped configuration at 128 and 96 kb/s."""
+    sys.setrecursionlimit(12000)
+    for name in names:
+        ex = np.load(os.path.join(HERE, f"excerpt_{name}.npz"))
+        pcm = ex["pcm"][:VQ_EXCERPT_HOPS * 1024]
+        path = os.path.join(_work, f"{name}_vqex.wav")
+        open(path, "wb").write(wav_bytes(int(ex["sr"]), pcm))
+        res = {"hops": np.array(VQ_EXCERPT_HOPS)}
+        for kbps in (128, 96):
+            pac, flags = ref_encode_file(path, kbps, True,
+                                         os.path.join(_work, f"{name}_vqex_{kbps}.pac"), vq=True)
+            res[f"pac_vq{kbps}"] = np.frombuffer(pac, dtype=np.uint8)
+            res[f"flags_vq{kbps}"] = np.array(flags, dtype=np.uint8)
+            print(name, kbps, len(pac))
+        np.savez_compressed(os.path.join(HERE, f"excerpt_vq_{name}.npz"), **res)
+
+
 def make_full(names):
     from multiprocessing import Pool
     jobs = [(n, bs) for n in names for bs in (False, True)]
@@ -486,6 +562,9 @@ if __name__ == "__main__":
             for n in names}
     if "--decoded" in sys.argv:
         make_decoded()
+    elif "--vq" in sys.argv:
+        make_vq_excerpts(names)
+        make_vq(names)
     elif "--full" in sys.argv:
         make_full(names)
         make_full_inputs(names)
