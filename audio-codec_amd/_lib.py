@@ -6,10 +6,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpacx.so")
 
-PACX_ABI_VERSION = 1
+PACX_ABI_VERSION = 2
 PCM_I16, PCM_F64 = 0, 1
 FLAG_LAST, FLAG_CUR, FLAG_NEXT = 1, 2, 4
-ST_SHORT, ST_ZERO_SUBBLOCK, ST_ALLOC_CAP = 1, 2, 4
+ST_SHORT, ST_ZERO_SUBBLOCK, ST_ALLOC_CAP, ST_VQ_UNDEFINED = 1, 2, 4, 8
+MAX_BANDS = 32
 SUB = 8
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
@@ -42,7 +43,15 @@ class PacxConfig(ctypes.Structure):
         ("fft_norm_short", ctypes.c_double),
         ("fft_freq_step_long", ctypes.c_double),
         ("fft_freq_step_short", ctypes.c_double),
+        ("use_vq", ctypes.c_int32),
+        ("use_sbr", ctypes.c_int32),
+        ("half_log2", c_double_p),
+        ("log_mu1", ctypes.c_double),
     ]
+
+
+class PacxVqEntry(ctypes.Structure):
+    _fields_ = [("value", ctypes.c_uint64), ("width", ctypes.c_int32), ("band", ctypes.c_int32)]
 
 
 class PacxPcm(ctypes.Structure):
@@ -72,6 +81,8 @@ SIGNATURES = {
     "pacx_bitalloc_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, _P]),
     "pacx_quantize_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int, _P, _P, _P]),
     "pacx_encode_batch": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, _P, _P, _P, _P, _P, _P]),
+    "pacx_encode_vq_batch": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, _P, _P, _P, _P, _P, _P, _P,
+                                            ctypes.c_int32, _P]),
     "pacx_pack_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pacx_gather_body": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _P]),
     "pacx_window_batch": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int64, _P, _P, _P]),

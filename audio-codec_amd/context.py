@@ -7,14 +7,15 @@ _cache = {}
 
 
 def encoder(sample_rate, target_bits_per_sample, n_scale_bits=4, n_mant_size_bits=12,
-            sf_bands=None, sf_bands_short=None):
+            sf_bands=None, sf_bands_short=None, use_vq=False, use_sbr=False):
     key = (int(sample_rate), float(target_bits_per_sample), int(n_scale_bits), int(n_mant_size_bits),
+           bool(use_vq), bool(use_sbr),
            None if sf_bands is None else tuple(int(v) for v in sf_bands.nLines),
            None if sf_bands_short is None else tuple(int(v) for v in sf_bands_short.nLines))
     enc = _cache.get(key)
     if enc is None:
         enc = engine.Encoder(sample_rate, target_bits_per_sample, n_scale_bits, n_mant_size_bits,
-                             sf_bands, sf_bands_short)
+                             sf_bands, sf_bands_short, use_vq=use_vq, use_sbr=use_sbr)
         _cache[key] = enc
     return enc
 
@@ -22,7 +23,8 @@ def encoder(sample_rate, target_bits_per_sample, n_scale_bits=4, n_mant_size_bit
 def encoder_for_params(cp):
     """From a reference-style CodingParams bag (coder/pacfile.py:699-707,323-330)."""
     return encoder(cp.sampleRate, cp.targetBitsPerSample, cp.nScaleBits, cp.nMantSizeBits,
-                   getattr(cp, "sfBands", None), getattr(cp, "sfBandsShort", None))
+                   getattr(cp, "sfBands", None), getattr(cp, "sfBandsShort", None),
+                   use_vq=bool(getattr(cp, "useVQ", False)), use_sbr=bool(getattr(cp, "useSBR", False)))
 
 
 def encoder_for_bands(sample_rate, sf_bands, short):

@@ -27,6 +27,7 @@
 #include "pacx_dev.h"
 #include "wave_fft.h"
 #include "pcm_stage.h"
+#include "wave_np_sum.h"
 
 
 /* Hann-windowed sample i of the staged block.  int16 input: the code enters as an
@@ -79,7 +80,9 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
                                                  const uint8_t *__restrict__ flags, long long n_cf,
                                                  int skip_cur, PacxPeak *__restrict__ peaks,
                                                  int32_t *__restrict__ n_peaks,
-                                                 int32_t *__restrict__ n_kept_out)
+                                                 int32_t *__restrict__ n_kept_out,
+                                                 double *__restrict__ sbr_mean,
+                                                 int32_t *__restrict__ sbr_overall)
 {
     typedef typename PcmStage<DT>::elem E;
     /* LDS lifetimes: raw (until the FFT inputs are in registers) then inten share
@@ -233,6 +236,36 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
         if (lane == 0) {
             n_peaks[cf * PACX_SUB] = count;                 /* what estimate_peaks finds */
             n_kept_out[cf * PACX_SUB] = n_kept;             /* what the mask kernel has to look at */
+        }
+    }
+    /* SBR files (EncodeSingleChannel_SBR, coder/codec.py:459-472, 503-505): the
+       same spectrum as |rfft|/halfN also bounds the overall scale factor and
+       gives each omitted band its one coded value, the mean magnitude.
+       ScaleFactor is monotone, so min(sf(max MDCT), sf(max FFT)) is
+       sf(max of both); magnitudes come back from the intensities
+       (|X| = sqrt(I/norm), two roundings away from np.abs). */
+    if (sbr_mean) {
+        __syncthreads();
+        double mx = 0.0;
+        for (int i = lane; i <= 1024; i += 64)
+            mx = fmax(mx, inten[i]);
+        mx = wave_max(mx);
+        const int first = T.first_omitted;
+        const int lo_all = T.band_lower_long[first];
+        __syncthreads();
+        for (int i = lo_all + lane; i < PACX_M_LONG; i += 64)
+            inten[i] = sqrt(inten[i] / T.norm_long) / (double)PACX_M_LONG;
+        __syncthreads();
+        for (int b = first; b < T.nb_long; ++b) {
+            const int cnt = T.band_lines_long[b];
+            const double mean = wave_np_sum(inten + T.band_lower_long[b], cnt, lane) / (double)cnt;
+            if (lane == 0)
+                sbr_mean[cf * PACX_SUB + (b - first)] = mean;
+        }
+        if (lane == 0) {
+            const int sf = pacx_scale_factor(sqrt(mx / T.norm_long) / (double)PACX_M_LONG, T.n_scale_bits, 5);
+            if (sf < sbr_overall[cf * PACX_SUB])
+                sbr_overall[cf * PACX_SUB] = sf;
         }
     }
 }
@@ -500,27 +533,33 @@ __global__ __launch_bounds__(64 * MASK_WAVES, 4) void k_mask(PacxTables T, const
 template <int DT, bool FAST>
 static void launch_side(const PacxTables &T, const PacxPcmView &in, const uint8_t *flags,
                         long long n_cf, int short_blocks, int mixed, PacxPeak *peaks,
-                        int32_t *n_peaks, int32_t *n_kept, hipStream_t st)
+                        int32_t *n_peaks, int32_t *n_kept, double *sbr_mean, int32_t *sbr_overall,
+                        hipStream_t st)
 {
     const dim3 grid((unsigned)n_cf), block(64);
     if (!short_blocks || mixed)
-        hipLaunchKernelGGL((k_side_long<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks, n_peaks, n_kept);
+        hipLaunchKernelGGL((k_side_long<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks, n_peaks,
+                           n_kept, sbr_mean, sbr_overall);
     if (short_blocks || mixed)
         hipLaunchKernelGGL((k_side_short<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks, n_peaks, n_kept);
 }
 
 void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
                       const uint8_t *flags, long long n_cf, int short_blocks, int mixed,
-                      PacxPeak *peaks, int32_t *n_peaks, int32_t *n_kept, hipStream_t st)
+                      PacxPeak *peaks, int32_t *n_peaks, int32_t *n_kept, double *sbr_mean,
+                      int32_t *sbr_overall, hipStream_t st)
 {
     if (n_cf <= 0)
         return;
     if (dtype == 0 && fast)
-        launch_side<0, true>(T, in, flags, n_cf, short_blocks, mixed, peaks, n_peaks, n_kept, st);
+        launch_side<0, true>(T, in, flags, n_cf, short_blocks, mixed, peaks, n_peaks, n_kept, sbr_mean,
+                             sbr_overall, st);
     else if (dtype == 0)
-        launch_side<0, false>(T, in, flags, n_cf, short_blocks, mixed, peaks, n_peaks, n_kept, st);
+        launch_side<0, false>(T, in, flags, n_cf, short_blocks, mixed, peaks, n_peaks, n_kept, sbr_mean,
+                              sbr_overall, st);
     else
-        launch_side<1, false>(T, in, flags, n_cf, short_blocks, mixed, peaks, n_peaks, n_kept, st);
+        launch_side<1, false>(T, in, flags, n_cf, short_blocks, mixed, peaks, n_peaks, n_kept, sbr_mean,
+                              sbr_overall, st);
 }
 
 void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,

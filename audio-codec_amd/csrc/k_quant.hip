@@ -55,10 +55,13 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
     if (!is_short && sb != 0)
         alive = false;
     const int nb = is_short ? T.nb_short : T.nb_long;
-    const int32_t *__restrict__ n_lines = is_short ? T.band_lines_short : T.band_lines_long;
+    /* an SBR file counts every omitted band of a long block as one line
+       (BitAlloc_SBR, coder/bitalloc.py:141-143) */
+    const int32_t *__restrict__ n_lines = is_short ? T.band_lines_short
+                                                   : (T.use_sbr ? T.band_lines_long_alloc : T.band_lines_long);
     const double budget = pacx_bit_budget(T.target_bps, is_short ? PACX_M_SHORT : PACX_M_LONG,
                                           is_short ? 1 : 0, (fl & 5u) != 0, T.n_scale_bits,
-                                          T.n_mant_size_bits, nb);
+                                          T.n_mant_size_bits, nb, T.use_vq, T.use_sbr && !is_short);
     int max_mant = 1 << T.n_mant_size_bits;
     if (max_mant > 16)
         max_mant = 16;

@@ -1,0 +1,749 @@
+/*
+ * k_vq.hip -- gain-shape (pyramid VQ) coding of the bands of a (sub-)block and
+ * the VQ flavour of the .pac payload (BASELINE config 4).
+ *
+ *   k_vq       one workgroup per (sub-)block; its waves take bands from a
+ *              shared ticket.  Per band: quantize_gain_shape
+ *              (coder/gain_shape_quantize.py:476-512) = mu-law gain + the
+ *              recursive mid/side split (split_band_encode :315-408) whose
+ *              leaves are pyramid-VQ searches (pvq_search :30-54) turned into
+ *              enumeration indices (encode_pvq_vector :105-124).  The band's
+ *              bit string is written straight into the block's MSB-first bit
+ *              buffer in the layout of WriiteEncodedBitsVQ
+ *              (coder/pacfile.py:363-402): overall scale, all allocations,
+ *              then the index lists.  A long block leaves the kernel as the
+ *              finished channel-block payload.
+ *   k_vq_join  short frames: concatenates the 8 sub-block strings behind the
+ *              3 flag bits (coder/pacfile.py:575-592) and applies the size
+ *              rule (:552-565, which still counts a scale factor per band).
+ *
+ * Why the band strings have static positions: a band that is coded at all
+ * uses exactly bitAlloc*nLines bits -- the gain index takes whatever the shape
+ * left over (:493) -- so the only data-dependent event is a band of zero gain,
+ * whose allocation drops to 0 (coder/codec.py:352-353).  Gains are therefore
+ * computed first (phase A), positions follow from a prefix sum, and the bands
+ * are then coded independently (phase B).  The same argument shows that the
+ * SBR spill rule (coder/codec.py:522-524: "sum(bits) < bitAlloc[iBand]", a
+ * band total against a per-line count) cannot fire; the oracle implements it
+ * literally and the tests assert it never triggers.
+ *
+ * Control flow inside a band is wave-uniform (one node of the split tree at a
+ * time, vectors in LDS, lanes across the vector's components).
+ */
+#include "../../include/pacx.h"
+#include "pacx_dev.h"
+#include "wave_np_sum.h"
+
+#define VQ_WAVES 4
+#define VQ_DEPTH 16
+#define VQ_WORDS 548                   /* 2192-byte payload slot, as k_pack */
+
+struct VqView {
+    const uint64_t *n_tab, *p_tab;
+    const int32_t *row_off;
+    const int32_t *k_of;
+    const uint8_t *w_of;
+    const double *half_log2;
+    int l_max;
+    double log_mu1;                    /* np.log(1 + 255) */
+};
+
+/* ---- table access --------------------------------------------------------- */
+__device__ __forceinline__ uint64_t vq_N(const VqView &V, int l, long long k)
+{
+    if (k < 0)
+        return 0;
+    if (l <= 0)
+        return k == 0 ? 1ull : 0ull;
+    if (k == 0)
+        return 1ull;
+    if (l == 1)
+        return 2ull;
+    if (l == 2)
+        return 4ull * (uint64_t)k;
+    return V.n_tab[V.row_off[l] + k];
+}
+
+/* sum_{j=0..k} N(l,j); 0 for k < 0 */
+__device__ __forceinline__ uint64_t vq_P(const VqView &V, int l, long long k)
+{
+    if (k < 0)
+        return 0;
+    if (l <= 0)
+        return 1ull;
+    if (l == 1)
+        return 1ull + 2ull * (uint64_t)k;
+    if (l == 2)
+        return 1ull + 2ull * (uint64_t)k * (uint64_t)(k + 1);
+    return V.p_tab[V.row_off[l] + k];
+}
+
+/* ---- wave helpers --------------------------------------------------------- */
+__device__ __forceinline__ void vq_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = v + (unsigned long long)__shfl_xor((long long)v, off, 64);
+    return v;
+}
+
+/* MSB-first bit writer into LDS words shared by the block's waves */
+__device__ __forceinline__ void vq_put32(unsigned *words, int pos, unsigned val, int width)
+{
+    if (width <= 0)
+        return;
+    val &= (width >= 32) ? 0xFFFFFFFFu : ((1u << width) - 1u);
+    const int w = pos >> 5, o = pos & 31;
+    const int room = 32 - o;
+    if (width <= room) {
+        atomicOr(&words[w], val << (room - width));
+    } else {
+        atomicOr(&words[w], val >> (width - room));
+        atomicOr(&words[w + 1], val << (32 - (width - room)));
+    }
+}
+
+__device__ __forceinline__ void vq_put64(unsigned *words, int pos, unsigned long long val, int width)
+{
+    if (width > 32) {
+        vq_put32(words, pos, (unsigned)(val >> 32), width - 32);
+        vq_put32(words, pos + width - 32, (unsigned)val, 32);
+    } else {
+        vq_put32(words, pos, (unsigned)val, width);
+    }
+}
+
+/* Per-band emission state (uniform across the wave). */
+struct VqOut {
+    unsigned *words;
+    int pos;                   /* next stream bit                          */
+    pacx_vq_entry *log;        /* optional entry log of this band          */
+    int log_cap, log_n;
+    int band;
+    unsigned flags;            /* PACX_ST_VQ_* raised while coding          */
+};
+
+__device__ __forceinline__ void vq_emit(VqOut &o, unsigned long long hi, unsigned long long lo, int width,
+                                        int lane)
+{
+    if (lane == 0) {
+        if (width > 64) {
+            vq_put64(o.words, o.pos, hi, width - 64);
+            vq_put64(o.words, o.pos + width - 64, lo, 64);
+        } else {
+            vq_put64(o.words, o.pos, lo, width);
+        }
+        if (o.log && o.log_n < o.log_cap) {
+            pacx_vq_entry e;
+            e.value = lo;
+            e.width = width;
+            e.band = o.band;
+            o.log[o.log_n] = e;
+        }
+    }
+    o.log_n += 1;
+    o.pos += width;
+}
+
+/* QuantizeUniform(x, n_bits) for x >= 0 (coder/quantize.py:14-36) evaluated the
+ * way Python does: the factor 2^n - 1 becomes a float64 (exact up to 53 bits,
+ * 2^n beyond), one multiply, +1, floor-divide by 2. */
+__device__ __forceinline__ void vq_quantize_emit(VqOut &o, double x, int n_bits, int lane)
+{
+    if (n_bits <= 0) {
+        vq_emit(o, 0, 0, 0, lane);
+        return;
+    }
+    if (n_bits > 128) {                       /* beyond what the entry format carries */
+        o.flags |= PACX_ST_VQ_UNDEFINED;
+        vq_emit(o, 0, 0, 0, lane);
+        return;
+    }
+    unsigned long long hi = 0, lo = 0;
+    if (x >= 1.0) {                           /* code = 2^(n-1) - 1 */
+        const int ones = n_bits - 1;
+        if (ones >= 64) {
+            lo = ~0ull;
+            hi = (ones - 64 >= 64) ? ~0ull : ((1ull << (ones - 64)) - 1ull);
+        } else {
+            lo = (ones == 0) ? 0ull : ((~0ull) >> (64 - ones));
+        }
+    } else {
+        const double factor = (n_bits <= 53) ? (double)((1ull << n_bits) - 1ull) : ldexp(1.0, n_bits);
+        const double code = floor((factor * x + 1.0) * 0.5);
+        if (n_bits <= 64) {
+            lo = (unsigned long long)code;
+        } else {
+            const double top = floor(ldexp(code, -64));
+            hi = (unsigned long long)top;
+            lo = (unsigned long long)(code - ldexp(top, 64));
+        }
+    }
+    vq_emit(o, hi, lo, n_bits, lane);
+}
+
+/* ---- one PVQ leaf --------------------------------------------------------- */
+/* xs[0..n): unit vector in LDS; t1, t2: n doubles of LDS scratch each. */
+__device__ __noinline__ void vq_leaf(const VqView &V, VqOut &o, const double *xs, int n, int bits,
+                                     double *t1, double *t2, int lane)
+{
+    const int K = V.k_of[n * 33 + bits];
+    const int width = V.w_of[n * 33 + bits];
+    if (K < 0) {                              /* a 1-dimensional leaf: the reference never returns */
+        o.flags |= PACX_ST_VQ_UNDEFINED;
+        return;
+    }
+    /* L1 norm in np.sum order */
+    for (int i = lane; i < n; i += 64)
+        t1[i] = fabs(xs[i]);
+    vq_fence();
+    const double l1 = wave_np_sum(t1, n, lane);
+    vq_fence();
+    if (!(l1 > 0.0)) {                        /* all-zero half: NaN pulses in the reference */
+        o.flags |= PACX_ST_VQ_UNDEFINED;
+        vq_emit(o, 0, 0, width, lane);
+        return;
+    }
+    /* target = |K x / l1|, y = floor(target) */
+    const double kd = (double)K;
+    double part = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double t = fabs(kd * xs[i] / l1);
+        const double y = floor(t);
+        t1[i] = t;
+        t2[i] = y;
+        part += y;                            /* integers: exact in any order */
+    }
+    const int missing = K - (int)wave_sum_f64(part);
+    vq_fence();
+    if (missing > 0) {
+        if (n <= 64) {
+            /* the greedy loop hands one pulse each to the `missing` largest
+               remainders, earliest index first among equals */
+            const double r = (lane < n) ? (t1[lane] - t2[lane]) : -1.0;
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const double rj = readlane_f64(r, j);
+                rank += (rj > r) || (rj == r && j < lane);
+            }
+            if (lane < n && rank < missing)
+                t2[lane] += 1.0;
+        } else {
+            for (int it = 0; it < missing; ++it) {
+                double best = -INFINITY;
+                int best_i = 0x7fffffff;
+                for (int i = lane; i < n; i += 64) {
+                    const double r = t1[i] - t2[i];
+                    if (r > best) {
+                        best = r;
+                        best_i = i;
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double ob = __shfl_xor(best, off, 64);
+                    const int oi = __shfl_xor(best_i, off, 64);
+                    if (ob > best || (ob == best && oi < best_i)) {
+                        best = ob;
+                        best_i = oi;
+                    }
+                }
+                if (lane == 0)
+                    t2[best_i] += 1.0;
+                vq_fence();
+            }
+        }
+        vq_fence();
+    }
+    /* enumeration index: component i (l = n-i dimensions left, k pulses left)
+       of magnitude a >= 1 adds N(l-1,k) + 2 sum_{j=1}^{a-1} N(l-1,k-j)
+       (+ N(l-1,k-a) if negative); np.sign(x) = 0 erases a pulse */
+    unsigned long long acc = 0;
+    long long k_left = K;
+    for (int base = 0; base < n && k_left > 0; base += 64) {
+        const int i = base + lane;
+        long long a = 0;
+        bool neg = false;
+        if (i < n) {
+            const double x = xs[i];
+            if (x != 0.0)
+                a = (long long)t2[i];
+            neg = x < 0.0;
+        }
+        long long incl = a;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long t = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += t;
+        }
+        const long long k = k_left - (incl - a);
+        if (a >= 1) {
+            const int l = n - i;
+            unsigned long long term = vq_N(V, l - 1, k);
+            term += 2ull * (vq_P(V, l - 1, k - 1) - vq_P(V, l - 1, k - a));
+            if (neg)
+                term += vq_N(V, l - 1, k - a);
+            acc += term;
+        }
+        k_left -= __shfl(incl, 63, 64);
+    }
+    const unsigned long long idx = wave_sum_u64(acc);
+    vq_emit(o, 0, idx, width, lane);
+}
+
+/* ---- the split tree of one band ------------------------------------------- */
+/* region: LDS doubles for the mid/side vectors of every depth; stack: 2*VQ_DEPTH ints */
+__device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double *x0, int n0, int bits0,
+                                         double *region, double *t1, double *t2, int *stack, int lane)
+{
+    const double half_pi = 1.5707963267948966;           /* np.pi / 2 */
+    const double *cur = x0;
+    int n = n0, bits = bits0, depth = 0;
+    double *reg = region;                                  /* region of the current depth */
+    for (;;) {
+        bool descend = false;
+        if (bits > PACX_VQ_SPLIT_BITS && depth < VQ_DEPTH) {
+            const int cut = n / 2, half = n - cut;
+            double *mv = reg, *sv = reg + half;
+            double mm = 0.0, ss = 0.0;
+            for (int i = lane; i < half; i += 64) {
+                const double left = (i < cut) ? cur[i] : 0.0;
+                const double right = cur[cut + i];
+                const double m = (left + right) / 2.0;
+                const double s = (left - right) / 2.0;
+                mv[i] = m;
+                sv[i] = s;
+                mm = fma(m, m, mm);
+                ss = fma(s, s, ss);
+            }
+            const double m_l2 = sqrt(wave_sum_f64(mm));
+            const double s_l2 = sqrt(wave_sum_f64(ss));
+            for (int i = lane; i < half; i += 64) {
+                if (m_l2 != 0.0)
+                    mv[i] = mv[i] / m_l2;
+                if (s_l2 != 0.0)
+                    sv[i] = sv[i] / s_l2;
+            }
+            vq_fence();
+            const double theta = (m_l2 == 0.0) ? 0.0 : atan(s_l2 / m_l2);
+            /* gain_shape_alloc(bits, half): floor(bits/half + 0.5 log2(half)) for the angle */
+            int a_theta = (int)floor((double)bits / (double)half + V.half_log2[half]);
+            int a_rest = bits - a_theta;
+            if (a_rest < 0)
+                a_rest = 0;
+            /* QuantizeUniform / DequantizeUniform of theta/(pi/2) */
+            const double tn = theta / half_pi;
+            double theta_q = 0.0;
+            if (a_theta <= 0) {
+                vq_emit(o, 0, 0, a_theta < 0 ? 0 : a_theta, lane);
+            } else if (a_theta > 62) {
+                o.flags |= PACX_ST_VQ_UNDEFINED;
+                vq_emit(o, 0, 0, 0, lane);
+            } else {
+                unsigned long long code;
+                if (tn >= 1.0) {
+                    code = (1ull << (a_theta - 1)) - 1ull;
+                } else {
+                    const double factor = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull)
+                                                          : ldexp(1.0, a_theta);
+                    code = (unsigned long long)floor((factor * tn + 1.0) * 0.5);
+                }
+                vq_emit(o, 0, code, a_theta, lane);
+                const unsigned long long mag = code & ((1ull << (a_theta - 1)) - 1ull);
+                const double den = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+                double dq = (double)(2ull * mag) / den;
+                if (code >> (a_theta - 1))
+                    dq = -dq;
+                theta_q = dq * half_pi;
+            }
+            /* bit_allocation_ms */
+            int a_mid = 0;
+            if (theta_q != 0.0) {
+                const double v = ((double)a_rest - (double)(half - 1) * log2(tan(fabs(theta_q)) + PACX_EPS)) / 2.0;
+                const double f = floor(v);
+                a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
+            }
+            const int a_side = a_rest - a_mid;
+            stack[2 * depth] = half;
+            stack[2 * depth + 1] = a_side;
+            /* children live one level down */
+            reg = reg + 2 * half;
+            depth += 1;
+            if (a_mid > 0) {
+                cur = mv;
+                n = half;
+                bits = a_mid;
+                descend = true;
+            }
+        } else {
+            if (bits > PACX_VQ_SPLIT_BITS)
+                o.flags |= PACX_ST_VQ_UNDEFINED;           /* deeper than any real tree */
+            vq_leaf(V, o, cur, n, bits > 32 ? 32 : bits, t1, t2, lane);
+        }
+        if (descend)
+            continue;
+        /* climb to the nearest split whose side half is still to do */
+        bool found = false;
+        while (depth > 0) {
+            const int half = stack[2 * (depth - 1)];
+            const int a_side = stack[2 * (depth - 1) + 1];
+            if (a_side >= 0) {
+                stack[2 * (depth - 1) + 1] = -1;           /* side taken */
+                if (a_side > 0) {
+                    /* the split at depth-1 wrote into the region just below `reg` */
+                    cur = (reg - 2 * half) + half;
+                    n = half;
+                    bits = a_side;
+                    found = true;
+                    break;
+                }
+            }
+            reg = reg - 2 * half;
+            depth -= 1;
+        }
+        if (!found)
+            return;
+    }
+}
+
+/* ------------------------------------------------------------------ kernel */
+struct VqArgs {
+    const uint8_t *flags;
+    int n_ch;
+    long long n_cf;
+    int mixed;                 /* 1: units are [cf][8] and flags decide long/short */
+    const double *lines;       /* [cf][1024] unscaled                       */
+    const int32_t *overall;    /* [cf][8]                                   */
+    int32_t *bit_alloc;        /* [cf][band_stride] in: BitAlloc, out: final */
+    const double *sbr_mean;    /* [cf][8] mean |FFT|/halfN of the omitted bands */
+    const uint32_t *status_in;
+    uint32_t *status;
+    uint8_t *payload;
+    int payload_stride;
+    int32_t *n_bytes;
+    unsigned *unit_words;      /* [cf*8][VQ_WORDS] short sub-block strings  */
+    int32_t *unit_bits;        /* [cf*8][2]: written bits, size-rule bits   */
+    pacx_vq_entry *log;
+    int32_t *log_count;
+    int log_cap;               /* entries per band                          */
+    int scr_len;               /* doubles of LDS scratch per wave           */
+};
+
+__global__ __launch_bounds__(64 * VQ_WAVES) void k_vq(PacxTables T, VqView V, VqArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *words = (unsigned *)smem;                               /* VQ_WORDS        */
+    double *gain_s = (double *)(smem + VQ_WORDS * 4);                 /* 32              */
+    int *ba_s = (int *)(gain_s + PACX_MAX_BANDS);                     /* 32              */
+    int *start_s = ba_s + PACX_MAX_BANDS;                             /* 33              */
+    int *ticket = start_s + PACX_MAX_BANDS + 1;                       /* 1 (+2 pad)      */
+    int *stack_all = ticket + 3;                                      /* waves * 2*DEPTH */
+    double *scr_all = (double *)(stack_all + VQ_WAVES * 2 * VQ_DEPTH);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long unit = blockIdx.x;
+    const long long cf = A.mixed ? unit / PACX_SUB : unit;
+    const int sb = A.mixed ? (int)(unit % PACX_SUB) : 0;
+    if (cf >= A.n_cf)
+        return;
+    const long long frame = cf / A.n_ch;
+    const unsigned fl = A.flags ? A.flags[frame] : 0u;
+    const bool is_short = A.mixed && (fl & 2u);
+    if (!is_short && sb != 0)
+        return;
+    if (is_short && A.status_in) {             /* hop dropped: nothing to code */
+        unsigned st = 0;
+        for (int c = 0; c < A.n_ch; ++c)
+            st |= A.status_in[frame * A.n_ch + c];
+        if (st & PACX_ST_ZERO_SUBBLOCK)
+            return;
+    }
+    const int nb = is_short ? T.nb_short : T.nb_long;
+    const int32_t *__restrict__ lower = is_short ? T.band_lower_short : T.band_lower_long;
+    const int32_t *__restrict__ count = is_short ? T.band_lines_short : T.band_lines_long;
+    const int first_omit = (!is_short && T.use_sbr) ? T.first_omitted : nb;
+    const long long boff = cf * T.band_stride + (is_short ? sb * T.nb_short : 0);
+    const double *__restrict__ lin = A.lines + cf * PACX_M_LONG + (is_short ? sb * PACX_M_SHORT : 0);
+    const int ov = A.overall[cf * PACX_SUB + sb];
+    const double up = (double)(1 << ov);
+    const int lead = is_short ? 0 : 3;
+
+    for (int i = tid; i < VQ_WORDS; i += 64 * VQ_WAVES)
+        words[i] = 0u;
+    if (tid == 0)
+        *ticket = 0;
+    double *scr = scr_all + (size_t)wave * A.scr_len;
+    int *stack = stack_all + wave * 2 * VQ_DEPTH;
+
+    /* phase A: gains (np.linalg.norm of the scaled band; an omitted band is the
+       one-element vector [mean |FFT|]) */
+    for (int b = wave; b < nb; b += VQ_WAVES) {
+        double g;
+        if (b >= first_omit) {
+            const double v = A.sbr_mean[cf * PACX_SUB + (b - first_omit)] * up;
+            g = sqrt(v * v);
+        } else {
+            const int lo = lower[b], cnt = count[b];
+            double acc = 0.0;
+            for (int i = lane; i < cnt; i += 64) {
+                const double x = lin[lo + i] * up;
+                acc = fma(x, x, acc);
+            }
+            g = sqrt(wave_sum_f64(acc));
+        }
+        if (lane == 0)
+            gain_s[b] = g;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        /* final allocations, band positions, header fields */
+        int ba = 0, r_bits = 0;
+        if (lane < nb) {
+            ba = A.bit_alloc[boff + lane];
+            if (ba && gain_s[lane] == 0.0)
+                ba = 0;                                   /* coder/codec.py:352-353 */
+            r_bits = ba * ((lane >= first_omit) ? 1 : count[lane]);
+            A.bit_alloc[boff + lane] = ba;
+            ba_s[lane] = ba;
+        }
+        int incl = r_bits;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += t;
+        }
+        const int head = lead + T.n_scale_bits + T.n_mant_size_bits * nb;
+        if (lane < nb)
+            start_s[lane] = head + incl - r_bits;
+        if (lane == nb - 1)
+            start_s[nb] = head + incl;
+        if (lane == 0) {
+            if (!is_short) {
+                vq_put32(words, 0, fl & 1u, 1);
+                vq_put32(words, 1, (fl >> 1) & 1u, 1);
+                vq_put32(words, 2, (fl >> 2) & 1u, 1);
+            }
+            vq_put32(words, lead, (unsigned)ov, T.n_scale_bits);
+        }
+        if (lane < nb)
+            vq_put32(words, lead + T.n_scale_bits + T.n_mant_size_bits * lane, (unsigned)(ba ? ba - 1 : 0),
+                     T.n_mant_size_bits);
+    }
+    __syncthreads();
+
+    /* phase B: bands by ticket, largest first */
+    unsigned raised = 0;
+    for (;;) {
+        int tk = 0;
+        if (lane == 0)
+            tk = atomicAdd(ticket, 1);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= nb)
+            break;
+        const int b = nb - 1 - tk;
+        const int ba = ba_s[b];
+        const long long log_slot = (cf * PACX_SUB + sb) * PACX_MAX_BANDS + b;
+        if (!ba) {
+            if (A.log_count && lane == 0)
+                A.log_count[log_slot] = 0;
+            continue;
+        }
+        VqOut o;
+        o.words = words;
+        o.pos = start_s[b];
+        o.log = A.log ? A.log + log_slot * A.log_cap : nullptr;
+        o.log_cap = A.log_cap;
+        o.log_n = 0;
+        o.band = b;
+        o.flags = 0;
+        const double gain = gain_s[b];
+        if (b >= first_omit) {
+            /* L = 1: every bit goes to the gain (gain_shape_alloc(R, 1)) */
+            const double g = log(1.0 + 255.0 * fabs(gain / 1.0)) / V.log_mu1;
+            vq_quantize_emit(o, g, ba, lane);
+        } else {
+            const int lo = lower[b], cnt = count[b];
+            const int r_bits = ba * cnt;
+            int bits_gain = (int)floor((double)r_bits / (double)cnt + V.half_log2[cnt]);
+            int bits_shape = r_bits - bits_gain;
+            if (bits_shape < 0)
+                bits_shape = 0;
+            if (bits_shape != 0) {
+                double *x0 = scr;                          /* [cnt] shape = x / gain */
+                for (int i = lane; i < cnt; i += 64)
+                    x0[i] = (lin[lo + i] * up) / gain;
+                vq_fence();
+                double *t1 = scr + V.l_max, *t2 = t1 + V.l_max, *region = t2 + V.l_max;
+                const int before = o.pos;
+                vq_shape(V, o, x0, cnt, bits_shape, region, t1, t2, stack, lane);
+                bits_gain += bits_shape - (o.pos - before);
+            }
+            if (bits_gain < 0)
+                bits_gain = 0;
+            const double g = log(1.0 + 255.0 * fabs(gain / (double)cnt)) / V.log_mu1;
+            vq_quantize_emit(o, g, bits_gain, lane);
+        }
+        if (o.pos != start_s[b + 1])
+            o.flags |= PACX_ST_VQ_UNDEFINED;               /* a band must fill its slot exactly */
+        raised |= o.flags;
+        if (A.log_count && lane == 0)
+            A.log_count[log_slot] = o.log_n;
+    }
+    if (raised && A.status && lane == 0)
+        atomicOr(&A.status[cf], raised);
+    __syncthreads();
+
+    /* hand the string over */
+    const int written = start_s[nb];                       /* includes `lead` */
+    int size_rule = T.n_scale_bits;                        /* getNumBytesNeeded */
+    for (int b = 0; b < nb; ++b)
+        size_rule += T.n_mant_size_bits + T.n_scale_bits;
+    size_rule += written - (lead + T.n_scale_bits + T.n_mant_size_bits * nb);
+    if (!is_short) {
+        const int nbytes = (size_rule + 4 + 7) >> 3;
+        unsigned *dst = (unsigned *)(A.payload + cf * (long long)A.payload_stride);
+        for (int i = tid; i < (nbytes + 3) / 4; i += 64 * VQ_WAVES)
+            dst[i] = __builtin_bswap32(words[i]);
+        if (tid == 0)
+            A.n_bytes[cf] = nbytes;
+    } else {
+        unsigned *dst = A.unit_words + unit * VQ_WORDS;
+        for (int i = tid; i < (written + 31) / 32; i += 64 * VQ_WAVES)
+            dst[i] = words[i];
+        if (tid == 0) {
+            A.unit_bits[unit * 2] = written;
+            A.unit_bits[unit * 2 + 1] = size_rule;
+        }
+    }
+}
+
+/* short frames: flags + the 8 sub-block strings, back to back */
+__global__ __launch_bounds__(64) void k_vq_join(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
+                                               long long n_cf, const uint32_t *__restrict__ status,
+                                               const unsigned *__restrict__ unit_words,
+                                               const int32_t *__restrict__ unit_bits,
+                                               uint8_t *__restrict__ payload, int payload_stride,
+                                               int32_t *__restrict__ n_bytes)
+{
+    __shared__ unsigned words[VQ_WORDS];
+    const int lane = threadIdx.x;
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf)
+        return;
+    const long long frame = cf / n_ch;
+    const unsigned fl = flags[frame];
+    if (!(fl & 2u))
+        return;
+    unsigned st = 0;
+    if (status)
+        for (int c = 0; c < n_ch; ++c)
+            st |= status[frame * n_ch + c];
+    if (st & PACX_ST_ZERO_SUBBLOCK) {
+        if (lane == 0)
+            n_bytes[cf] = 0;
+        return;
+    }
+    for (int i = lane; i < VQ_WORDS; i += 64)
+        words[i] = 0u;
+    __syncthreads();
+    if (lane == 0) {
+        vq_put32(words, 0, fl & 1u, 1);
+        vq_put32(words, 1, (fl >> 1) & 1u, 1);
+        vq_put32(words, 2, (fl >> 2) & 1u, 1);
+    }
+    int pos = 3, size = 0;
+    for (int sb = 0; sb < PACX_SUB; ++sb) {
+        const long long unit = cf * PACX_SUB + sb;
+        const int nbit = unit_bits[unit * 2];
+        size += unit_bits[unit * 2 + 1];
+        const unsigned *src = unit_words + unit * VQ_WORDS;
+        for (int w = lane; w < (nbit + 31) / 32; w += 64) {
+            const int width = (nbit - 32 * w) >= 32 ? 32 : (nbit - 32 * w);
+            vq_put32(words, pos + 32 * w, src[w] >> (32 - width), width);
+        }
+        pos += nbit;
+    }
+    __syncthreads();
+    const int nbytes = (size + 4 + 7) >> 3;
+    unsigned *dst = (unsigned *)(payload + cf * (long long)payload_stride);
+    for (int i = lane; i < (nbytes + 3) / 4; i += 64)
+        dst[i] = __builtin_bswap32(words[i]);
+    if (lane == 0)
+        n_bytes[cf] = nbytes;
+}
+
+/* ---------------------------------------------------------------- launcher */
+void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *flags, int n_ch, long long n_cf,
+                    const double *lines, const int32_t *overall, int32_t *bit_alloc, const double *sbr_mean,
+                    uint32_t *status, uint8_t *payload, int payload_stride, int32_t *n_bytes,
+                    unsigned *unit_words, int32_t *unit_bits, pacx_vq_entry *log, int32_t *log_count,
+                    int log_cap, hipStream_t st)
+{
+    if (n_cf <= 0)
+        return;
+    const VqView &V = *(const VqView *)vq_view;
+    VqArgs A;
+    A.flags = flags;
+    A.n_ch = n_ch;
+    A.n_cf = n_cf;
+    A.mixed = flags ? 1 : 0;
+    A.lines = lines;
+    A.overall = overall;
+    A.bit_alloc = bit_alloc;
+    A.sbr_mean = sbr_mean;
+    A.status_in = status;
+    A.status = status;
+    A.payload = payload;
+    A.payload_stride = payload_stride;
+    A.n_bytes = n_bytes;
+    A.unit_words = unit_words;
+    A.unit_bits = unit_bits;
+    A.log = log;
+    A.log_count = log_count;
+    A.log_cap = log_cap;
+    /* per wave: shape [l_max] + two leaf scratch vectors + the mid/side regions
+       (2*ceil(n/2) per depth: at most l_max + 2 per level summed over the halving) */
+    A.scr_len = 3 * V.l_max + (2 * V.l_max + 4 * VQ_DEPTH);
+    const size_t fixed = VQ_WORDS * 4 + PACX_MAX_BANDS * 8 + (PACX_MAX_BANDS + PACX_MAX_BANDS + 1 + 3) * 4 +
+                         VQ_WAVES * 2 * VQ_DEPTH * 4;
+    const size_t smem = ((fixed + 15) & ~(size_t)15) + (size_t)VQ_WAVES * A.scr_len * 8;
+    const long long units = A.mixed ? n_cf * PACX_SUB : n_cf;
+    hipLaunchKernelGGL(k_vq, dim3((unsigned)units), dim3(64 * VQ_WAVES), smem, st, T, V, A);
+    if (A.mixed)
+        hipLaunchKernelGGL(k_vq_join, dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch, n_cf, status,
+                           unit_words, unit_bits, payload, payload_stride, n_bytes);
+}
+
+size_t pacx_vq_view_size(void) { return sizeof(VqView); }
+
+void pacx_vq_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
+                       const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
+                       double log_mu1)
+{
+    VqView *v = (VqView *)dst;
+    v->n_tab = n_tab;
+    v->p_tab = p_tab;
+    v->row_off = row_off;
+    v->k_of = k_of;
+    v->w_of = w_of;
+    v->half_log2 = half_log2;
+    v->l_max = l_max;
+    v->log_mu1 = log_mu1;
+}

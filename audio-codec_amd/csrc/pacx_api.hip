@@ -13,6 +13,7 @@
 
 #include "../../include/pacx.h"
 #include "pacx_dev.h"
+#include "pacx_vq_tables.h"
 
 /* kernels (k_mdct.hip, k_psy.hip, k_quant.hip) */
 void pacx_launch_mdct(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
@@ -24,7 +25,8 @@ void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8
                          hipStream_t st);
 void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
                       const uint8_t *flags, long long n_cf, int short_blocks, int mixed,
-                      PacxPeak *peaks, int32_t *n_peaks, int32_t *n_kept, hipStream_t st);
+                      PacxPeak *peaks, int32_t *n_peaks, int32_t *n_kept, double *sbr_mean,
+                      int32_t *sbr_overall, hipStream_t st);
 void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
                       int short_blocks, int mixed, const PacxPeak *peaks, const int32_t *n_peaks,
                       const double *lines, double *smr, double *thr_out, int n_cu, hipStream_t st);
@@ -60,7 +62,19 @@ void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const
                         const int32_t *overall, const int32_t *scale_factor, const int32_t *bit_alloc,
                         const int32_t *mantissa, double *blocks, int16_t *pcm, hipStream_t st);
 
+/* k_vq.hip */
+void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *flags, int n_ch, long long n_cf,
+                    const double *lines, const int32_t *overall, int32_t *bit_alloc, const double *sbr_mean,
+                    uint32_t *status, uint8_t *payload, int payload_stride, int32_t *n_bytes,
+                    unsigned *unit_words, int32_t *unit_bits, pacx_vq_entry *log, int32_t *log_count,
+                    int log_cap, hipStream_t st);
+size_t pacx_vq_view_size(void);
+void pacx_vq_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
+                       const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
+                       double log_mu1);
+
 #define PACX_PAYLOAD_STRIDE 2192
+#define PACX_VQ_UNIT_WORDS 548
 
 struct pacx_handle {
     int device;
@@ -79,6 +93,12 @@ struct pacx_handle {
     long long *ws_offs;               /* [ws_cf]                                */
     long long ws_blocks_cf;           /* decode: capacity of ws_blocks          */
     double *ws_blocks;                /* [cf][2048] blocks before overlap-add   */
+    /* gain-shape coder (use_vq) */
+    std::vector<char> vq_view;        /* VqView of k_vq.hip (device pointers)   */
+    double *ws_sbr_mean;              /* [ws_cf][8] omitted-band means           */
+    long long ws_vq_cf;               /* capacity of the short-frame buffers    */
+    unsigned *ws_unit_words;          /* [ws_vq_cf*8][548]                      */
+    int32_t *ws_unit_bits;            /* [ws_vq_cf*8][2]                        */
     std::string err;
 };
 
@@ -189,6 +209,10 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->ws_cf = 0;
     h->ws_blocks_cf = 0;
     h->ws_blocks = nullptr;
+    h->ws_sbr_mean = nullptr;
+    h->ws_vq_cf = 0;
+    h->ws_unit_words = nullptr;
+    h->ws_unit_bits = nullptr;
     h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
     h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr; h->ws_nkept = nullptr;
     memset(&h->T, 0, sizeof(h->T));
@@ -312,6 +336,63 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     T.n_scale_bits = cfg->n_scale_bits;
     T.n_mant_size_bits = cfg->n_mant_size_bits;
     T.target_bps = cfg->target_bits_per_sample;
+
+    /* coding variant */
+    T.use_vq = cfg->use_vq ? 1 : 0;
+    T.use_sbr = cfg->use_sbr ? 1 : 0;
+    T.first_omitted = T.nb_long;
+    T.band_lines_long_alloc = T.band_lines_long;
+    if (T.use_sbr && !T.use_vq) {
+        g_create_err = "pacx_create: use_sbr needs use_vq (the scalar SBR variant is not built)";
+        pacx_destroy(h);
+        return PACX_E_UNSUPPORTED;
+    }
+    if (T.use_sbr) {
+        /* sbr.omitted_bands (coder/sbr.py:6-9): bands starting at or above upperLine[-1] // 2 */
+        std::vector<int32_t> alloc_lines(cfg->band_lines_long, cfg->band_lines_long + T.nb_long);
+        const int cut = (ML - 1) / 2;
+        int at = 0;
+        for (int b = 0; b < T.nb_long; ++b) {
+            if (at >= cut) {
+                if (T.first_omitted == T.nb_long)
+                    T.first_omitted = b;
+                alloc_lines[b] = 1;
+            }
+            at += cfg->band_lines_long[b];
+        }
+        if (T.nb_long - T.first_omitted > PACX_SUB) {
+            g_create_err = "pacx_create: more than 8 SBR-omitted bands";
+            pacx_destroy(h);
+            return PACX_E_UNSUPPORTED;
+        }
+        TRY(upload(h, alloc_lines.data(), alloc_lines.size(), &T.band_lines_long_alloc));
+    }
+    if (T.use_vq) {
+        int l_max = 1;
+        for (int b = 0; b < T.nb_long; ++b)
+            l_max = cfg->band_lines_long[b] > l_max ? cfg->band_lines_long[b] : l_max;
+        for (int b = 0; b < T.nb_short; ++b)
+            l_max = cfg->band_lines_short[b] > l_max ? cfg->band_lines_short[b] : l_max;
+        PacxVqHostTables vt;
+        pacx_vq_build(l_max, cfg->half_log2, &vt);
+        const uint64_t *d_n, *d_p;
+        const int32_t *d_off, *d_k;
+        const uint8_t *d_w;
+        const double *d_hl;
+        if (vt.n_tab.empty()) {            /* l_max < 3: rows 0..2 are closed forms */
+            vt.n_tab.push_back(0);
+            vt.p_tab.push_back(0);
+        }
+        TRY(upload(h, vt.n_tab.data(), vt.n_tab.size(), &d_n));
+        TRY(upload(h, vt.p_tab.data(), vt.p_tab.size(), &d_p));
+        TRY(upload(h, vt.row_off.data(), vt.row_off.size(), &d_off));
+        TRY(upload(h, vt.k_of.data(), vt.k_of.size(), &d_k));
+        TRY(upload(h, vt.w_of.data(), vt.w_of.size(), &d_w));
+        TRY(upload(h, vt.half_log2.data(), vt.half_log2.size(), &d_hl));
+        h->vq_view.resize(pacx_vq_view_size());
+        pacx_vq_view_fill(h->vq_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max,
+                          cfg->log_mu1 != 0.0 ? cfg->log_mu1 : log(256.0));
+    }
 #undef TRY
     *out = h;
     return PACX_OK;
@@ -320,10 +401,11 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
 static void free_ws(pacx_handle *h)
 {
     void *p[] = {h->ws_lines, h->ws_smr, h->ws_peaks, h->ws_npeaks, h->ws_overall, h->ws_chunks, h->ws_offs,
-                 h->ws_nkept};
+                 h->ws_nkept, h->ws_sbr_mean};
     for (void *q : p)
         if (q)
             (void)hipFree(q);
+    h->ws_sbr_mean = nullptr;
     h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
     h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr; h->ws_nkept = nullptr;
     h->ws_cf = 0;
@@ -337,6 +419,10 @@ extern "C" void pacx_destroy(pacx_handle *h)
     free_ws(h);
     if (h->ws_blocks)
         (void)hipFree(h->ws_blocks);
+    if (h->ws_unit_words)
+        (void)hipFree(h->ws_unit_words);
+    if (h->ws_unit_bits)
+        (void)hipFree(h->ws_unit_bits);
     for (void *p : h->owned)
         (void)hipFree(p);
     delete h;
@@ -360,6 +446,8 @@ extern "C" int pacx_reserve(pacx_handle *h, int64_t n_cf)
     HIP_TRY(h, hipMalloc((void **)&h->ws_overall, n * PACX_SUB * sizeof(int32_t)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_chunks, (n / 256 + 2) * sizeof(long long)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_offs, (n + 1) * sizeof(long long)));
+    if (h->T.use_sbr)
+        HIP_TRY(h, hipMalloc((void **)&h->ws_sbr_mean, n * PACX_SUB * sizeof(double)));
     h->ws_cf = n_cf;
     return PACX_OK;
 }
@@ -445,7 +533,8 @@ extern "C" int pacx_smr_batch(pacx_handle *h, const pacx_pcm *in, const double *
         return rc;
     hipStream_t st = (hipStream_t)stream;
     const int sb = short_blocks ? 1 : 0;
-    pacx_launch_side(h->T, v, in->dtype, fast, nullptr, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, h->ws_nkept, st);
+    pacx_launch_side(h->T, v, in->dtype, fast, nullptr, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
+                     nullptr, nullptr, st);
     pacx_launch_mask(h->T, nullptr, in->n_channels, n_cf, sb, 0, h->ws_peaks, h->ws_nkept, lines, smr,
                      threshold, h->n_cu, st);
     if (n_peaks) {
@@ -507,6 +596,9 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
         return PACX_OK;
     if (!overall_scale || !scale_factor || !bit_alloc || !mantissa || !status)
         return fail(h, PACX_E_ARG, "pacx_encode_batch: null output pointer");
+    if (h->T.use_vq)
+        return fail(h, PACX_E_UNSUPPORTED, "pacx_encode_batch: handle was created with use_vq "
+                                           "(call pacx_encode_vq_batch)");
     HIP_TRY(h, hipSetDevice(h->device));
     if ((rc = pacx_reserve(h, n_cf)))
         return rc;
@@ -527,13 +619,77 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
                          PACX_SUB, status, st);
     }
     pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
-                     st);
+                     nullptr, nullptr, st);
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
                      nullptr, h->n_cu, st);
     pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_smr, bit_alloc, status, st);
     pacx_launch_quantize(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_lines, overall_scale, PACX_SUB, bit_alloc,
                          scale_factor, mantissa, st);
     return post_launch(h, "pacx_encode_batch");
+}
+
+extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
+                                    int32_t *overall_scale, int32_t *bit_alloc, uint8_t *payload,
+                                    int32_t *n_bytes, uint32_t *status, pacx_vq_entry *entries,
+                                    int32_t *entry_count, int32_t entries_per_band, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    PacxPcmView v;
+    int fast;
+    long long n_cf;
+    int rc = check_pcm(h, in, &v, &fast, &n_cf);
+    if (rc)
+        return rc;
+    if (n_cf == 0)
+        return PACX_OK;
+    if (!overall_scale || !bit_alloc || !payload || !n_bytes || !status)
+        return fail(h, PACX_E_ARG, "pacx_encode_vq_batch: null output pointer");
+    if ((entries && (!entry_count || entries_per_band < 1)) || (!entries && entry_count && entries_per_band != 0))
+        return fail(h, PACX_E_ARG, "pacx_encode_vq_batch: entries need entry_count and entries_per_band >= 1");
+    if (!h->T.use_vq)
+        return fail(h, PACX_E_UNSUPPORTED, "pacx_encode_vq_batch: handle was created without use_vq");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((rc = pacx_reserve(h, n_cf)))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const PacxTables &T = h->T;
+    const int mixed = frame_flags ? 1 : 0;
+    const int n_ch = in->n_channels;
+    if (mixed && n_cf > h->ws_vq_cf) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        if (h->ws_unit_words) (void)hipFree(h->ws_unit_words);
+        if (h->ws_unit_bits) (void)hipFree(h->ws_unit_bits);
+        h->ws_unit_words = nullptr;
+        h->ws_unit_bits = nullptr;
+        h->ws_vq_cf = 0;
+        HIP_TRY(h, hipMalloc((void **)&h->ws_unit_words,
+                             (size_t)n_cf * PACX_SUB * PACX_VQ_UNIT_WORDS * sizeof(unsigned)));
+        HIP_TRY(h, hipMalloc((void **)&h->ws_unit_bits, (size_t)n_cf * PACX_SUB * 2 * sizeof(int32_t)));
+        h->ws_vq_cf = n_cf;
+    }
+    HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
+    HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
+    HIP_TRY(h, hipMemsetAsync(n_bytes, 0, (size_t)n_cf * sizeof(int32_t), st));
+    if (fast) {
+        pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, h->n_cu, st);
+        if (mixed)
+            pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 3, 0, h->ws_lines, overall_scale,
+                             PACX_SUB, status, st);
+    } else {
+        pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
+                         PACX_SUB, status, st);
+    }
+    /* the side chain also folds max|FFT| into the overall scale of SBR long blocks */
+    pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
+                     T.use_sbr ? h->ws_sbr_mean : nullptr, T.use_sbr ? overall_scale : nullptr, st);
+    pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
+                     nullptr, h->n_cu, st);
+    pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_smr, bit_alloc, status, st);
+    pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
+                   h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
+                   h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, st);
+    return post_launch(h, "pacx_encode_vq_batch");
 }
 
 extern "C" int pacx_pack_batch(pacx_handle *h, int64_t n_cf, int n_channels, const uint8_t *frame_flags,

@@ -45,6 +45,10 @@ struct PacxTables {
     int nb_long, nb_short;
     int n_scale_bits, n_mant_size_bits;
     int band_stride;
+    /* gain-shape / SBR variants (coder/pacfile.py:703-705, 326-327) */
+    int use_vq, use_sbr;
+    int first_omitted;                /* first band of sbr.omitted_bands (they are the tail) */
+    const int32_t *band_lines_long_alloc;   /* nLines with omitted bands counted as 1 */
 };
 
 struct PacxPcmView {

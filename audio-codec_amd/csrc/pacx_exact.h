@@ -22,6 +22,7 @@
 #define PACX_ALLOC_MAX_PASSES 200  /* coder/bitalloc.py:116-119                    */
 #define PACX_DB_PER_BIT 6.2        /* coder/bitalloc.py:61                         */
 #define PACX_EPS 2.220446049250313e-16 /* np.finfo(float).eps, coder/psychoac.py:20 */
+#define PACX_VQ_SPLIT_BITS 32      /* coder/gain_shape_quantize.py:27              */
 
 /* A0 -- coder/pcmfile.py:89-99 + coder/quantize.py:82-95:
  * value = +-(2*(|c| & 32767)) / 65535 with a correctly rounded division
@@ -112,16 +113,22 @@ PACX_HD double pacx_np_sum(const double *a, int n)
     return res;
 }
 
-/* Budget rule of coder/codec.py:288-299 (scalar-mantissa branch). */
+/* Budget rule of coder/codec.py:288-299.  use_vq: only the overall scale
+ * factor is charged (:292-294).  sbr_long: a long block of an SBR file is
+ * budgeted from the full halfN whatever its flags (EncodeSingleChannel_SBR,
+ * coder/codec.py:446-453). */
 PACX_HD double pacx_bit_budget(double target_bits_per_sample, int half_n, int is_short,
                                int last_or_next, int n_scale_bits, int n_mant_size_bits,
-                               int n_bands)
+                               int n_bands, int use_vq, int sbr_long)
 {
     int n_eff = is_short ? (int)(1.45 * half_n) : half_n;
-    if (last_or_next)
+    if (last_or_next && !sbr_long)
         n_eff = (int)(0.85 * n_eff);
     double budget = target_bits_per_sample * (double)n_eff;
-    budget = budget - (double)(n_scale_bits * (n_bands + 1));
+    if (use_vq)
+        budget = budget - (double)n_scale_bits;
+    else
+        budget = budget - (double)(n_scale_bits * (n_bands + 1));
     budget = budget - (double)(n_mant_size_bits * n_bands);
     return budget;
 }

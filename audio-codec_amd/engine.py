@@ -62,7 +62,8 @@ class Encoder:
     """One handle = one (sampleRate, bit rate, band layout) on one GPU."""
 
     def __init__(self, sample_rate, target_bits_per_sample, n_scale_bits=4, n_mant_size_bits=12,
-                 sf_bands=None, sf_bands_short=None, device=None, n_mdct_lines=N_LONG):
+                 sf_bands=None, sf_bands_short=None, device=None, n_mdct_lines=N_LONG,
+                 use_vq=False, use_sbr=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.PacxError("no GPU visible: the encode path has no CPU implementation")
@@ -107,6 +108,11 @@ class Encoder:
         cfg.fft_norm_short = tables.fft_norm(2 * N_SHORT)
         cfg.fft_freq_step_long = tables.fft_freq_step(2 * N_LONG, sr)
         cfg.fft_freq_step_short = tables.fft_freq_step(2 * N_SHORT, sr)
+        self.use_vq, self.use_sbr = bool(use_vq), bool(use_sbr)
+        cfg.use_vq, cfg.use_sbr = int(self.use_vq), int(self.use_sbr)
+        l_max = int(max(np.max(self.sfBands.nLines), np.max(self.sfBandsShort.nLines)))
+        cfg.half_log2 = f64("hl2", tables.half_log2(l_max))
+        cfg.log_mu1 = tables.log_mu1()
         h = ctypes.c_void_p()
         rc = self.lib.pacx_create(ctypes.byref(cfg), ctypes.byref(h))
         _lib.check(self.lib, None, rc, "pacx_create")
@@ -217,6 +223,36 @@ class Encoder:
                    _ptr(out["scale_factor"]), _ptr(out["bit_alloc"]), _ptr(out["mantissa"]),
                    _ptr(out["status"]), self._stream())
         out["flags"] = fl
+        return out
+
+    def encode_vq(self, pcm, flags=None, out=None, want_entries=False, entries_per_band=160):
+        """The shipped configuration (gain-shape PVQ, SBR if the handle has it) from
+        PCM to finished payloads.  Returns dict: overall [n_cf,8], bit_alloc
+        [n_cf, band_stride] (final), payload [n_cf, payload_stride], n_bytes, status;
+        with want_entries also entries [n_cf,8,32,cap] (structured: value, width,
+        band) and entry_count [n_cf,8,32]."""
+        n_cf = pcm.n_cf
+        fl = self.flags_tensor(flags, pcm.n_frames)
+        if out is None:
+            out = {
+                "overall": self._empty((n_cf, _lib.SUB), torch.int32),
+                "bit_alloc": torch.zeros((n_cf, self.band_stride), dtype=torch.int32, device=self.device),
+                "status": self._empty((n_cf,), torch.int32),
+                "payload": self._empty((n_cf, self.payload_stride), torch.uint8),
+                "n_bytes": self._empty((n_cf,), torch.int32),
+            }
+        ent = cnt = None
+        if want_entries:
+            ent = torch.zeros((n_cf, _lib.SUB, _lib.MAX_BANDS, entries_per_band, 2), dtype=torch.int64,
+                              device=self.device)
+            cnt = torch.zeros((n_cf, _lib.SUB, _lib.MAX_BANDS), dtype=torch.int32, device=self.device)
+        self._call("pacx_encode_vq_batch", ctypes.byref(pcm.c), _ptr(fl), _ptr(out["overall"]),
+                   _ptr(out["bit_alloc"]), _ptr(out["payload"]), _ptr(out["n_bytes"]), _ptr(out["status"]),
+                   _ptr(ent), _ptr(cnt), ctypes.c_int32(entries_per_band if want_entries else 0),
+                   self._stream())
+        out["flags"] = fl
+        if want_entries:
+            out["entries"], out["entry_count"] = ent, cnt
         return out
 
     def alloc_outputs(self, n_cf, with_payload=False):

@@ -161,11 +161,14 @@ def device_stream(enc, pcm, hop=1024):
 
 
 def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, header_samples=None,
-                  n_scale_bits=4, n_mant_size_bits=12):
+                  n_scale_bits=4, n_mant_size_bits=12, use_vq=False, use_sbr=False):
     """Whole-stream batched encode -> .pac bytes identical to what the
-    reference's driver (coder/pacfile.py:674-757, scalar path) writes for the
-    same PCM.  pcm: int16 [n, nCh], n a multiple of 1024 (see
-    pcmfile.wav_effective_stream for real WAV files)."""
+    reference's driver (coder/pacfile.py:674-757) writes for the same PCM:
+    scalar mantissas by default; use_vq (+ use_sbr) selects the gain-shape
+    coder, and the driver's own settings are use_vq=True,
+    use_sbr=(kbps < 128), block_switching=True (:703-705).  pcm: int16
+    [n, nCh], n a multiple of 1024 (see pcmfile.wav_effective_stream for real
+    WAV files)."""
     from .audiofile import CodingParams
     pcm = np.ascontiguousarray(pcm)
     hop = 1024
@@ -176,7 +179,7 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, hea
     cp.nMDCTLines = cp.nSamplesPerBlock = hop
     cp.nScaleBits, cp.nMantSizeBits = n_scale_bits, n_mant_size_bits
     cp.targetBitsPerSample = kbps_per_channel / (cp.sampleRate / 1000)
-    cp.useSBR = cp.useVQ = False
+    cp.useSBR, cp.useVQ = bool(use_sbr), bool(use_vq)
     head = header_bytes(cp)
     enc = context.encoder_for_params(cp)
     planar = device_stream(enc, pcm, hop)
@@ -185,8 +188,12 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, hea
         _, flags = enc.transient_flags(planar, len(pcm) // hop, hop)     # detector + flag shifting on the GPU
     else:
         flags = None
-    out = enc.encode(view, flags)
-    payload, n_bytes = enc.pack(out, cp.nChannels)
+    if use_vq:
+        out = enc.encode_vq(view, flags)
+        payload, n_bytes = out["payload"], out["n_bytes"]
+    else:
+        out = enc.encode(view, flags)
+        payload, n_bytes = enc.pack(out, cp.nChannels)
     body, total = enc.gather_body(payload, n_bytes)
     n = int(total.item())
     return head + body[:n].cpu().numpy().tobytes()

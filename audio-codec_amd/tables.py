@@ -85,3 +85,16 @@ def band_line_counts(n_lines, sample_rate, flimit=cbFreqLimits):
             counts[i + 1:] = 0
             break
     return counts
+
+
+def half_log2(l_max):
+    """0.5*np.log2(L) for L = 0..l_max (gain_shape_alloc,
+    coder/gain_shape_quantize.py:59); entry 0 is unused."""
+    out = np.zeros(l_max + 1)
+    out[1:] = 0.5 * np.log2(np.arange(1, l_max + 1))
+    return out
+
+
+def log_mu1(mu=255):
+    """np.log(1 + mu) of mu_law_fn, coder/gain_shape_quantize.py:294-295."""
+    return float(np.log(1 + mu))

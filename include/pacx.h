@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PACX_ABI_VERSION 1
+#define PACX_ABI_VERSION 2
 
 /* error codes */
 #define PACX_OK            0
@@ -76,6 +76,12 @@ extern "C" {
 #define PACX_ST_ALLOC_CAP    4u   /* BitAlloc left through its 200-pass guard
                                      (coder/bitalloc.py:116-119)               */
 
+#define PACX_ST_VQ_UNDEFINED  8u   /* gain-shape coder reached a case where the
+                                     reference itself fails (a 1-dimensional
+                                     PVQ leaf never returns, an all-zero half
+                                     gives NaN pulses, a gain index wider than
+                                     128 bits): the band's bits are zeros     */
+
 #define PACX_SHORT_PER_FRAME 8    /* sub-blocks of a short frame (coder/pacfile.py:527) */
 
 typedef struct pacx_handle pacx_handle;
@@ -114,7 +120,26 @@ typedef struct pacx_config {
     double fft_norm_short;
     double fft_freq_step_long;      /* np.fft.rfftfreq step 1/(N*(1/sr)); 0 = compute */
     double fft_freq_step_short;
+    /* coding variant of the file (coder/pacfile.py:703-705):
+       use_vq  -- gain-shape pyramid VQ of every band instead of scale factor +
+                  mantissas (coder/gain_shape_quantize.py); the handle then
+                  serves pacx_encode_vq_batch instead of pacx_encode_batch;
+       use_sbr -- long blocks go through EncodeSingleChannel_SBR: the bands of
+                  sbr.omitted_bands (coder/sbr.py:6-9) carry one value each.
+                  Needs use_vq (the only SBR flavour the reference's driver
+                  ever selects). */
+    int32_t use_vq;
+    int32_t use_sbr;
+    const double *half_log2;        /* optional [max band lines + 1]: 0.5*np.log2(L) */
+    double log_mu1;                 /* np.log(256.0) of mu_law_fn; 0 = compute       */
 } pacx_config;
+
+/* one written field of a gain-shape coded band (see pacx_encode_vq_batch) */
+typedef struct pacx_vq_entry {
+    uint64_t value;                 /* low 64 bits of the index                    */
+    int32_t width;                  /* bits written                                */
+    int32_t band;
+} pacx_vq_entry;
 
 /*
  * Strided view of PCM input.  Sample s of frame f, channel c is element
@@ -226,6 +251,33 @@ int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_f
                       int32_t *overall_scale, int32_t *scale_factor,
                       int32_t *bit_alloc, int32_t *mantissa, uint32_t *status,
                       void *stream);
+
+/*
+ * The shipped configuration of the reference (coder/pacfile.py:699-707: useVQ
+ * always, useSBR below 128 kb/s) for a batch, from PCM to finished payloads:
+ *   codec.Encode / EncodeSingleChannel with useVQ   coder/codec.py:239-246, 292-294, 330-360
+ *   codec.Encode_SBR / EncodeSingleChannel_SBR      coder/codec.py:383-531 (long blocks of an SBR file,
+ *                                                   routing coder/pacfile.py:639-643)
+ *   BitAlloc_SBR                                    coder/bitalloc.py:123-145
+ *   quantize_gain_shape, split_band_encode, quantize_pvq, pvq_search,
+ *   encode_pvq_vector, pvq_compute_k_for_R, gain_shape_alloc,
+ *   bit_allocation_ms, mu_law_fn                    coder/gain_shape_quantize.py:30-124, 244-408, 476-512
+ *   getNumBytesNeeded + WriiteEncodedBitsVQ         coder/pacfile.py:342-402, 552-592
+ * The handle must have been created with use_vq.  Field lists are variable
+ * length, so the natural output is the bit string itself:
+ *   overall_scale: int32 [n_cf][8];  bit_alloc: int32 [n_cf][band_stride], the
+ *   FINAL allocation (a band of zero gain drops to 0, coder/codec.py:352-353);
+ *   payload: uint8 [n_cf][payload_stride], n_bytes: int32 [n_cf] as pacx_pack_batch;
+ *   status: uint32 [n_cf] PACX_ST_*.
+ * entries / entry_count (optional, for callers that want the reference's
+ * (indices, idx_bits) lists): entries [n_cf][8][32][entries_per_band] receives
+ * the fields of sub-block j, band b in writing order, entry_count [n_cf][8][32]
+ * how many there were (may exceed entries_per_band: the excess is not stored).
+ */
+int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
+                         int32_t *overall_scale, int32_t *bit_alloc, uint8_t *payload,
+                         int32_t *n_bytes, uint32_t *status, pacx_vq_entry *entries,
+                         int32_t *entry_count, int32_t entries_per_band, void *stream);
 
 /*
  * pacfile.py bit layout (coder/pacfile.py:404-447, 552-577; bitpack.py:37-102):

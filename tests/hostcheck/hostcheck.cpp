@@ -1,6 +1,7 @@
 // Host build of audio-codec_amd/csrc/pacx_exact.h for the CPU test suite:
 // the same source the HIP kernels compile, exported for ctypes.
 #include "pacx_exact.h"
+#include "pacx_vq_tables.h"
 
 extern "C" {
 double hc_pcm16_to_f64(int c) { return pacx_pcm16_to_f64(c); }
@@ -9,7 +10,9 @@ int hc_scale_factor(double ax, int nsb, int nmb) { return pacx_scale_factor(ax, 
 int hc_mantissa(double x, int scale, int nsb, int nmb) { return pacx_mantissa(x, scale, nsb, nmb); }
 double hc_np_sum(const double *a, int n) { return pacx_np_sum(a, n); }
 double hc_bit_budget(double tbps, int half_n, int is_short, int lon, int nsb, int nmsb, int nb)
-{ return pacx_bit_budget(tbps, half_n, is_short, lon, nsb, nmsb, nb); }
+{ return pacx_bit_budget(tbps, half_n, is_short, lon, nsb, nmsb, nb, 0, 0); }
+double hc_bit_budget_vq(double tbps, int half_n, int is_short, int lon, int nsb, int nmsb, int nb, int sbr_long)
+{ return pacx_bit_budget(tbps, half_n, is_short, lon, nsb, nmsb, nb, 1, sbr_long); }
 int hc_bit_alloc(double budget, int max_mant, int nb, const int32_t *n_lines, const double *smr,
                  int32_t *bits, int *hit_cap)
 { return pacx_bit_alloc(budget, max_mant, nb, n_lines, smr, bits, hit_cap); }
@@ -19,4 +22,13 @@ double hc_spl_scalar(double v) { return pacx_spl_scalar(v); }
 double hc_bark(double f) { return pacx_bark(f); }
 double hc_thresh_quiet(double f) { return pacx_thresh_quiet(f); }
 int hc_window_kind(unsigned f) { return pacx_window_kind(f); }
+
+/* pyramid-VQ tables (pacx_vq_tables.h) */
+static PacxVqHostTables g_vq;
+void hc_vq_build(int l_max) { pacx_vq_build(l_max, nullptr, &g_vq); }
+int hc_vq_k(int l, int bits) { return g_vq.k_of[(size_t)l * 33 + bits]; }
+int hc_vq_w(int l, int bits) { return g_vq.w_of[(size_t)l * 33 + bits]; }
+int hc_vq_row_len(int l) { return g_vq.row_len[l]; }
+unsigned long long hc_vq_n(int l, int k) { return g_vq.n_tab[g_vq.row_off[l] + k]; }
+unsigned long long hc_vq_p(int l, int k) { return g_vq.p_tab[g_vq.row_off[l] + k]; }
 }

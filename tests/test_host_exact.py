@@ -171,3 +171,55 @@ def test_psycho_scalars(hc, tables):
     assert np.max(np.abs(got - tables["bark_1024_48000"])) < 1e-13
     got = np.array([hc.hc_thresh_quiet(float(x)) for x in f])
     assert np.max(np.abs(got - tables["thresh_1024_48000"]) / np.abs(tables["thresh_1024_48000"])) < 1e-12
+
+
+# ------------------------------------------------- gain-shape (PVQ) host tables
+def test_vq_budget_rule(hc):
+    """coder/codec.py:292-294 (VQ) and :446-453 (SBR long block: flags ignored)."""
+    hc.hc_bit_budget_vq.restype = ctypes.c_double
+    hc.hc_bit_budget_vq.argtypes = [ctypes.c_double] + [ctypes.c_int] * 7
+    for sr in (48000, 44100):
+        for kbps in (128, 96):
+            tbps = kbps / (sr / 1000)
+            nb_long = po.band_table(1024, sr).nBands
+            nb_short = po.band_table(128, sr).nBands
+            for flags in range(8):
+                last, cur, nxt = flags & 1, (flags >> 1) & 1, (flags >> 2) & 1
+                half_n = 128 if cur else 1024
+                n_eff = int(1.45 * half_n) if cur else half_n
+                if last or nxt:
+                    n_eff = int(0.85 * n_eff)
+                nb = nb_short if cur else nb_long
+                want = tbps * n_eff
+                want -= 4
+                want -= 12 * nb
+                got = hc.hc_bit_budget_vq(tbps, half_n, cur, int(bool(last or nxt)), 4, 12, nb, 0)
+                assert got == want
+                if not cur:
+                    want = tbps * 1024
+                    want -= 4
+                    want -= 12 * nb
+                    assert hc.hc_bit_budget_vq(tbps, 1024, 0, int(bool(last or nxt)), 4, 12, nb, 1) == want
+
+
+def test_vq_tables_match_oracle(hc):
+    from oracle import pac_oracle_vq as pv
+    l_max = 363
+    hc.hc_vq_build(l_max)
+    hc.hc_vq_n.restype = ctypes.c_ulonglong
+    hc.hc_vq_p.restype = ctypes.c_ulonglong
+    for l in list(range(2, 40)) + [41, 64, 65, 91, 128, 149, 182, 304, 363]:
+        for bits in (1, 2, 3, 7, 8, 9, 15, 16, 17, 24, 31, 32):
+            k, w = pv.pulses_for_bits(l, bits) if l > 2 or bits <= 20 else (2 ** (bits - 2), bits)
+            assert (hc.hc_vq_k(l, bits), hc.hc_vq_w(l, bits)) == (k, w), (l, bits)
+    for bits in range(1, 33):
+        assert hc.hc_vq_k(1, bits) == -1            # the reference never returns for L = 1
+    for l in (3, 4, 5, 7, 13, 29, 100, 363):
+        n = hc.hc_vq_row_len(l)
+        assert pv.codebook_size(l, n - 1) > 2 ** 32 >= pv.codebook_size(l, n - 2)
+        run = 0
+        for k in list(range(min(n, 40))) + ([n - 1] if n > 40 else []):
+            assert hc.hc_vq_n(l, k) == pv.codebook_size(l, k)
+        for k in range(min(n, 300)):
+            run += pv.codebook_size(l, k)
+            assert hc.hc_vq_p(l, k) == run
