@@ -34,7 +34,12 @@
 #include "pacx_dev.h"
 #include "wave_np_sum.h"
 
+#ifndef VQ_WAVES
 #define VQ_WAVES 4
+#endif
+#ifndef VQ_OCC
+#define VQ_OCC 3                       /* waves per SIMD the register budget is set for */
+#endif
 #define VQ_DEPTH 16
 #define VQ_WORDS 548                   /* 2192-byte payload slot, as k_pack */
 
@@ -46,6 +51,11 @@ struct VqView {
     const double *half_log2;
     int l_max;
     double log_mu1;                    /* np.log(1 + 255) */
+    /* work order: bands by decreasing size (SBR-omitted long bands count as 1);
+       the first VQ_WAVES entries go to waves 0.. statically, the rest by
+       ticket, so wave w only needs scratch for the (w+1)-th largest band */
+    uint8_t order_long[PACX_MAX_BANDS], order_short[PACX_MAX_BANDS];
+    int scr_off[VQ_WAVES + 1];         /* doubles: scratch of wave w = [scr_off[w], scr_off[w+1]) */
 };
 
 /* ---- table access --------------------------------------------------------- */
@@ -199,8 +209,8 @@ __device__ __forceinline__ void vq_quantize_emit(VqOut &o, double x, int n_bits,
 
 /* ---- one PVQ leaf --------------------------------------------------------- */
 /* xs[0..n): unit vector in LDS; t1, t2: n doubles of LDS scratch each. */
-__device__ __noinline__ void vq_leaf(const VqView &V, VqOut &o, const double *xs, int n, int bits,
-                                     double *t1, double *t2, int lane)
+__device__ __forceinline__ void vq_leaf(const VqView &V, VqOut &o, const double *xs, int n, int bits,
+                                        double *t1, double *t2, int lane)
 {
     const int K = V.k_of[n * 33 + bits];
     const int width = V.w_of[n * 33 + bits];
@@ -308,9 +318,12 @@ __device__ __noinline__ void vq_leaf(const VqView &V, VqOut &o, const double *xs
 }
 
 /* ---- the split tree of one band ------------------------------------------- */
-/* region: LDS doubles for the mid/side vectors of every depth; stack: 2*VQ_DEPTH ints */
+/* region: LDS doubles for the mid/side vectors of every depth (2 n0 + 4 VQ_DEPTH:
+ * depth d takes 2*ceil(n_d/2)); a leaf borrows the still unused tail of it for
+ * its two scratch vectors (what is left at depth d is at least 2 n_d).
+ * stack: 2*VQ_DEPTH ints */
 __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double *x0, int n0, int bits0,
-                                         double *region, double *t1, double *t2, int *stack, int lane)
+                                         double *region, int *stack, int lane)
 {
     const double half_pi = 1.5707963267948966;           /* np.pi / 2 */
     const double *cur = x0;
@@ -394,7 +407,7 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
         } else {
             if (bits > PACX_VQ_SPLIT_BITS)
                 o.flags |= PACX_ST_VQ_UNDEFINED;           /* deeper than any real tree */
-            vq_leaf(V, o, cur, n, bits > 32 ? 32 : bits, t1, t2, lane);
+            vq_leaf(V, o, cur, n, bits > 32 ? 32 : bits, reg, reg + n, lane);
         }
         if (descend)
             continue;
@@ -442,10 +455,9 @@ struct VqArgs {
     pacx_vq_entry *log;
     int32_t *log_count;
     int log_cap;               /* entries per band                          */
-    int scr_len;               /* doubles of LDS scratch per wave           */
 };
 
-__global__ __launch_bounds__(64 * VQ_WAVES) void k_vq(PacxTables T, VqView V, VqArgs A)
+__global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqView V, VqArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *words = (unsigned *)smem;                               /* VQ_WORDS        */
@@ -487,9 +499,10 @@ __global__ __launch_bounds__(64 * VQ_WAVES) void k_vq(PacxTables T, VqView V, Vq
     for (int i = tid; i < VQ_WORDS; i += 64 * VQ_WAVES)
         words[i] = 0u;
     if (tid == 0)
-        *ticket = 0;
-    double *scr = scr_all + (size_t)wave * A.scr_len;
+        *ticket = VQ_WAVES;
+    double *scr = scr_all + V.scr_off[wave];
     int *stack = stack_all + wave * 2 * VQ_DEPTH;
+    const uint8_t *order = is_short ? V.order_short : V.order_long;
 
     /* phase A: gains (np.linalg.norm of the scaled band; an omitted band is the
        one-element vector [mean |FFT|]) */
@@ -548,16 +561,19 @@ __global__ __launch_bounds__(64 * VQ_WAVES) void k_vq(PacxTables T, VqView V, Vq
     }
     __syncthreads();
 
-    /* phase B: bands by ticket, largest first */
+    /* phase B: bands largest first; wave w starts on the (w+1)-th largest, the
+       rest go by ticket */
     unsigned raised = 0;
-    for (;;) {
-        int tk = 0;
-        if (lane == 0)
-            tk = atomicAdd(ticket, 1);
-        tk = __builtin_amdgcn_readfirstlane(tk);
+    int tk = wave;
+    for (;; tk = -1) {
+        if (tk < 0) {
+            if (lane == 0)
+                tk = atomicAdd(ticket, 1);
+            tk = __builtin_amdgcn_readfirstlane(tk);
+        }
         if (tk >= nb)
             break;
-        const int b = nb - 1 - tk;
+        const int b = order[tk];
         const int ba = ba_s[b];
         const long long log_slot = (cf * PACX_SUB + sb) * PACX_MAX_BANDS + b;
         if (!ba) {
@@ -590,9 +606,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES) void k_vq(PacxTables T, VqView V, Vq
                 for (int i = lane; i < cnt; i += 64)
                     x0[i] = (lin[lo + i] * up) / gain;
                 vq_fence();
-                double *t1 = scr + V.l_max, *t2 = t1 + V.l_max, *region = t2 + V.l_max;
                 const int before = o.pos;
-                vq_shape(V, o, x0, cnt, bits_shape, region, t1, t2, stack, lane);
+                vq_shape(V, o, x0, cnt, bits_shape, x0 + cnt, stack, lane);
                 bits_gain += bits_shape - (o.pos - before);
             }
             if (bits_gain < 0)
@@ -718,12 +733,9 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
     A.log = log;
     A.log_count = log_count;
     A.log_cap = log_cap;
-    /* per wave: shape [l_max] + two leaf scratch vectors + the mid/side regions
-       (2*ceil(n/2) per depth: at most l_max + 2 per level summed over the halving) */
-    A.scr_len = 3 * V.l_max + (2 * V.l_max + 4 * VQ_DEPTH);
     const size_t fixed = VQ_WORDS * 4 + PACX_MAX_BANDS * 8 + (PACX_MAX_BANDS + PACX_MAX_BANDS + 1 + 3) * 4 +
                          VQ_WAVES * 2 * VQ_DEPTH * 4;
-    const size_t smem = ((fixed + 15) & ~(size_t)15) + (size_t)VQ_WAVES * A.scr_len * 8;
+    const size_t smem = ((fixed + 15) & ~(size_t)15) + (size_t)V.scr_off[VQ_WAVES] * 8;
     const long long units = A.mixed ? n_cf * PACX_SUB : n_cf;
     hipLaunchKernelGGL(k_vq, dim3((unsigned)units), dim3(64 * VQ_WAVES), smem, st, T, V, A);
     if (A.mixed)
@@ -733,11 +745,40 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
 
 size_t pacx_vq_view_size(void) { return sizeof(VqView); }
 
+/* sizes_long / sizes_short: vector dimension of every band as the coder sees it */
 void pacx_vq_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
                        const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
-                       double log_mu1)
+                       double log_mu1, const int32_t *sizes_long, int nb_long, const int32_t *sizes_short,
+                       int nb_short)
 {
     VqView *v = (VqView *)dst;
+    auto sort_desc = [](const int32_t *sz, int nb, uint8_t *order) {
+        for (int i = 0; i < nb; ++i)
+            order[i] = (uint8_t)i;
+        for (int i = 1; i < nb; ++i)                      /* stable insertion sort, largest first */
+            for (int j = i; j > 0 && sz[order[j]] > sz[order[j - 1]]; --j) {
+                const uint8_t t = order[j];
+                order[j] = order[j - 1];
+                order[j - 1] = t;
+            }
+    };
+    sort_desc(sizes_long, nb_long, v->order_long);
+    sort_desc(sizes_short, nb_short, v->order_short);
+    v->scr_off[0] = 0;
+    for (int w = 0; w < VQ_WAVES; ++w) {
+        int n = 1;
+        if (w < nb_long)
+            n = sizes_long[v->order_long[w]];
+        if (w < nb_short && sizes_short[v->order_short[w]] > n)
+            n = sizes_short[v->order_short[w]];
+        /* tickets hand any later band to any wave */
+        if (VQ_WAVES < nb_long && sizes_long[v->order_long[VQ_WAVES]] > n)
+            n = sizes_long[v->order_long[VQ_WAVES]];
+        if (VQ_WAVES < nb_short && sizes_short[v->order_short[VQ_WAVES]] > n)
+            n = sizes_short[v->order_short[VQ_WAVES]];
+        /* shape [n] + mid/side regions [2n + 4 depth] */
+        v->scr_off[w + 1] = v->scr_off[w] + ((3 * n + 4 * VQ_DEPTH + 1) & ~1);
+    }
     v->n_tab = n_tab;
     v->p_tab = p_tab;
     v->row_off = row_off;

@@ -71,7 +71,8 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
 size_t pacx_vq_view_size(void);
 void pacx_vq_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
                        const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
-                       double log_mu1);
+                       double log_mu1, const int32_t *sizes_long, int nb_long, const int32_t *sizes_short,
+                       int nb_short);
 
 #define PACX_PAYLOAD_STRIDE 2192
 #define PACX_VQ_UNIT_WORDS 548
@@ -390,8 +391,12 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         TRY(upload(h, vt.w_of.data(), vt.w_of.size(), &d_w));
         TRY(upload(h, vt.half_log2.data(), vt.half_log2.size(), &d_hl));
         h->vq_view.resize(pacx_vq_view_size());
+        std::vector<int32_t> sizes_long(cfg->band_lines_long, cfg->band_lines_long + T.nb_long);
+        for (int b = T.first_omitted; b < T.nb_long; ++b)
+            sizes_long[b] = 1;
         pacx_vq_view_fill(h->vq_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max,
-                          cfg->log_mu1 != 0.0 ? cfg->log_mu1 : log(256.0));
+                          cfg->log_mu1 != 0.0 ? cfg->log_mu1 : log(256.0), sizes_long.data(), T.nb_long,
+                          cfg->band_lines_short, T.nb_short);
     }
 #undef TRY
     *out = h;

@@ -21,9 +21,13 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-/* n <= 128 */
-static __device__ __noinline__ double wave_np_sum_block(const double *a, int n, int lane)
+/* n <= 128.  `ga` always points into LDS: the cast lets the (deliberately not
+ * inlined) body use ds_read instead of flat loads. */
+typedef __attribute__((address_space(3))) const double wave_np_lds_f64;
+
+static __device__ __noinline__ double wave_np_sum_block(const double *ga, int n, int lane)
 {
+    wave_np_lds_f64 *a = (wave_np_lds_f64 *)ga;
     if (n < 8) {
         double r = -0.0;
         for (int i = 0; i < n; ++i)

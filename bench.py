@@ -31,22 +31,30 @@ MDCT_BYTES_PER_CF = 1024 * 2 + 1024 * 8      # int16 hop in + float64 lines out 
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(n_frames=768):
+def cpu_baseline(n_frames=768, vq_kbps=None):
     """The oracle (NumPy restatement of the reference, kind 'port') on the first
     n_frames stereo frames of the same workload, one host core."""
     from oracle import pac_oracle as po
     import audio_codec_amd as A
     pcm = A.synth.stream(n_frames, N_CH)
     halo = np.concatenate((np.zeros((1024, N_CH), np.int16), pcm))
-    p = po.make_params(SAMPLE_RATE, N_CH, KBPS)
+    if vq_kbps:
+        from oracle import pac_oracle_vq as pv
+        p = pv.make_params_vq(SAMPLE_RATE, N_CH, vq_kbps)
+        fn = pv.encode_channel_sbr_vq if p.useSBR else pv.encode_channel_vq
+        what = "oracle/pac_oracle_vq.py " + fn.__name__
+    else:
+        p = po.make_params(SAMPLE_RATE, N_CH, KBPS)
+        fn = po.encode_channel
+        what = "oracle/pac_oracle.py encode_channel"
     t0 = time.perf_counter()
     for f in range(n_frames):
         for ch in range(N_CH):
-            po.encode_channel(po.pcm16_to_fraction(halo[f * 1024:f * 1024 + 2048, ch]), p)
+            fn(po.pcm16_to_fraction(halo[f * 1024:f * 1024 + 2048, ch]), p)
     dt = time.perf_counter() - t0
     return {"value": n_frames * N_CH / dt, "unit": "channel-frames/s", "cores": 1, "kind": "port",
             "sample": f"first {n_frames} stereo frames ({n_frames * N_CH} cf) of the same synthetic stream, "
-                      f"oracle/pac_oracle.py encode_channel, {dt:.1f} s"}
+                      f"{what}, {dt:.1f} s"}
 
 
 def main():
@@ -57,6 +65,9 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="stereo frames per GPU and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mdct-launches", type=int, default=50)
+    ap.add_argument("--workload", choices=["scalar128", "vq128", "vq96"], default="scalar128",
+                    help="scalar128 = BASELINE configs[1] (the headline); vq128 / vq96 = the gain-shape "
+                         "coder of configs[3] (vq96 with SBR) on the same synthetic stream")
     args = ap.parse_args()
 
     import torch
@@ -77,7 +88,10 @@ def main():
     # ---- workload: device-resident before any timing
     n_frames = args.frames
     pcm = A.synth.stream(n_frames, N_CH, seed=A.synth.SEED + rank)
-    enc = A.engine.Encoder(SAMPLE_RATE, KBPS / (SAMPLE_RATE / 1000))
+    vq_kbps = {"scalar128": None, "vq128": 128, "vq96": 96}[args.workload]
+    kbps = vq_kbps or KBPS
+    enc = A.engine.Encoder(SAMPLE_RATE, kbps / (SAMPLE_RATE / 1000), use_vq=bool(vq_kbps),
+                           use_sbr=bool(vq_kbps and vq_kbps < 128))
     planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=dev)
     view = A.engine.PcmView.stream(planar)
     n_cf = view.n_cf
@@ -89,9 +103,16 @@ def main():
     import ctypes
     from audio_codec_amd.engine import _ptr
 
+    vq_out = None
+    if vq_kbps:
+        vq_out = {k: out[k] for k in ("overall", "bit_alloc", "status", "payload", "n_bytes")}
+
     def step():
-        enc.encode(view, None, out)
-        enc.pack(out, N_CH, out)
+        if vq_kbps:
+            enc.encode_vq(view, None, vq_out)
+        else:
+            enc.encode(view, None, out)
+            enc.pack(out, N_CH, out)
         enc._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(out["payload"]), _ptr(out["n_bytes"]),
                   _ptr(body), ctypes.c_int64(cap), _ptr(total), enc._stream())
         if world > 1:
@@ -152,7 +173,9 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "audio channel-frames/s encode (48 kHz, 1024-line long blocks, 128 kb/s/ch)",
+            "metric": "audio channel-frames/s encode (48 kHz, 1024-line long blocks, 128 kb/s/ch)" if not vq_kbps
+                      else f"audio channel-frames/s encode, gain-shape PVQ{' + SBR' if vq_kbps < 128 else ''} "
+                           f"(48 kHz, 1024-line long blocks, {vq_kbps} kb/s/ch)",
             "value": world * n_cf * args.steps / dt,
             "unit": "channel-frames/s",
             "n_gpus": world,
@@ -165,7 +188,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{n_frames} synthetic 48 kHz stereo frames per GPU ({n_cf} channel-frames), "
-                                   "N=1024 long blocks, 128 kb/s/ch, int16 PCM resident in HBM; step = encode + "
+                                   f"N=1024 long blocks, {kbps} kb/s/ch, "
+                                   f"{'gain-shape PVQ' + (' + SBR' if kbps < 128 else '') if vq_kbps else 'scalar mantissas'}, "
+                                   "int16 PCM resident in HBM; step = encode + "
                                    ".pac bit packing + body assembly" + (" + RCCL gather to rank 0" if world > 1 else ""),
                        "stereo_frames_per_s": world * n_frames * args.steps / dt,
                        "sharding": f"{world} x frame-range shards, no data-path collective"},
@@ -179,7 +204,7 @@ def main():
                          "mdct_cf_per_s": n_cf / (mdct_ms * 1e-3)},
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(256, vq_kbps) if vq_kbps else cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
