@@ -437,3 +437,304 @@ def encode_stream_vq(pcm, sample_rate, kbps_per_channel, block_switching=True,
         last_t, cur_t = cur_t, nxt
     emit([np.zeros(hop_n) for _ in range(n_ch)], (False, False, False))
     return b''.join(out)
+
+
+# =========================================================================
+# decode side of the gain-shape / SBR variants
+#   coder/gain_shape_quantize.py:127-176, 259-272, 411-473, 515-541
+#   coder/codec.py:47-92 (useVQ branch), :95-222 (Decode_SBR)
+#   coder/pacfile.py:177-229, 645-668
+# Third-party arithmetic restated here (the reference calls SciPy, no version
+# pinned; checked against scipy 1.15.3 in tests/test_oracle_vq.py):
+#   scipy.ndimage.gaussian_filter1d(x, sigma=200)  -> gaussian_smooth()
+#   scipy.interpolate.interp1d(kind='slinear')     -> slinear()
+# =========================================================================
+def pvq_decode(b, l_total, k_total):
+    """Index -> pyramid vector: the five-step machine of
+    coder/gain_shape_quantize.py:127-176 written as one loop.  At component i
+    with l dimensions and k pulses left and xb the first index of the current
+    group: b == xb ends the walk (the LAST component takes the k pulses left,
+    positive); b below xb + N(l-1,k) is a zero; otherwise the magnitude j
+    is the first whose two sign groups reach past b."""
+    x = np.zeros(l_total, dtype=int)
+    i, xb, k, l = 0, 0, k_total, l_total
+    while True:
+        if b == xb:                                    # step 1 -> step 5
+            x[i] = 0
+            if k > 0:
+                x[l_total - 1] = k - abs(x[i])
+            return x
+        if b < xb + codebook_size(l - 1, k):           # step 2, zero
+            x[i] = 0
+        else:
+            xb += codebook_size(l - 1, k)
+            j = 1
+            restart = False
+            while True:                                # step 3
+                j = min(j, k)
+                if b < xb + 2 * codebook_size(l - 1, max(k - j, 0)):
+                    if b >= xb + codebook_size(l - 1, k - j):
+                        x[i] = -j
+                    elif xb <= b:
+                        x[i] = j
+                    break
+                xb += 2 * codebook_size(l - 1, k - j)
+                if j < k:
+                    j += 1
+                else:
+                    restart = True                     # -> step 1 with the same i
+                    break
+            if restart:
+                continue
+        k -= abs(x[i])                                 # step 4
+        l -= 1
+        i += 1
+        if k <= 0:
+            return x                                   # step 5 with k == 0 does nothing
+
+
+def dequantize_leaf(idx, l, k):
+    """coder/gain_shape_quantize.py:259-272: decoded vector over its L2 norm."""
+    x = pvq_decode(idx, l, k).astype(float)
+    n = np.linalg.norm(x)
+    if n != 0:
+        x = x / np.linalg.norm(x)
+    return x
+
+
+def split_decode(br, num_bits, band_size):
+    """coder/gain_shape_quantize.py:411-473 -> (unit vector, bits read)."""
+    if num_bits <= SPLIT_BITS:
+        k, width = pulses_for_bits(band_size, num_bits)
+        x = dequantize_leaf(br.get(width), band_size, k)
+        n = np.linalg.norm(x)
+        if n != 0:
+            x /= n
+        return x, width
+    half = int(np.ceil(band_size / 2))
+    a_theta, a_rest = gain_shape_alloc(num_bits, half)
+    theta = po.dequantize_uniform(br.get(a_theta), a_theta) * (np.pi / 2)
+    a_mid, a_side = mid_side_alloc(a_rest, theta, half)
+    used = a_theta
+    parts = []
+    for a in (a_mid, a_side):
+        if a > SPLIT_BITS:
+            v, u = split_decode(br, a, half)
+            used += u
+        elif a > 0:
+            k, width = pulses_for_bits(half, a)
+            v = dequantize_leaf(br.get(width), half, k)
+            used += width
+        else:
+            v = np.zeros((half,))
+        parts.append(v)
+    mid, side = parts
+    left = mid * np.cos(theta) + side * np.sin(theta)
+    right = mid * np.cos(theta) - side * np.sin(theta)
+    left /= np.sqrt(2)
+    right /= np.sqrt(2)
+    if half > band_size // 2:
+        left = left[:len(left) - 1]
+    x = np.concatenate([left, right])
+    n = np.linalg.norm(x)
+    if n != 0:
+        x /= n
+    return x, used
+
+
+def inv_mu_law(y, mu=255):
+    """coder/gain_shape_quantize.py:298-299."""
+    return np.sign(y) / mu * ((1 + mu) ** np.abs(y) - 1)
+
+
+def dequantize_gain_shape(br, bit_alloc, l):
+    """coder/gain_shape_quantize.py:515-541."""
+    bits_gain, bits_shape = gain_shape_alloc(bit_alloc, l)
+    if bits_shape != 0:
+        shape, used = split_decode(br, bits_shape, l)
+        bits_gain += bits_shape - used
+    else:
+        shape = np.ones((l,))
+    g = po.dequantize_uniform(br.get(bits_gain), bits_gain)
+    return (inv_mu_law(g) * l) * shape
+
+
+def gaussian_smooth(x, sigma=200, truncate=4.0):
+    """scipy.ndimage.gaussian_filter1d(x, sigma) with its defaults (order 0,
+    mode 'reflect', truncate 4): weights exp(-0.5 (j/sigma)^2) normalised by
+    their sum over j = -r..r, r = int(truncate*sigma + 0.5); the input is
+    extended by mirroring about its edges (d c b a | a b c d | d c b a); each
+    output is centre*w0 followed by the symmetric pairs from the far end
+    inwards (NI_Correlate1D's symmetric branch)."""
+    x = np.asarray(x, dtype=np.float64)
+    r = int(truncate * float(sigma) + 0.5)
+    j = np.arange(-r, r + 1)
+    w = np.exp(-0.5 / (sigma * sigma) * j ** 2)
+    w = w / w.sum()
+    n = len(x)
+    idx = np.arange(-r, n + r)
+    period = 2 * n
+    m = np.mod(idx, period)
+    m = np.where(m >= n, period - 1 - m, m)
+    ext = x[m]
+    out = np.empty(n)
+    for i in range(n):
+        c = i + r
+        acc = ext[c] * w[r]
+        for jj in range(-r, 0):
+            acc += (ext[c + jj] + ext[c - jj]) * w[r + jj]
+        out[i] = acc
+    return out
+
+
+def gaussian_smooth_sparse(x, sigma=200, truncate=4.0):
+    """Same result as gaussian_smooth for inputs that are mostly exact zeros
+    (adding (0+0)*w leaves the accumulator unchanged): only the pairs that
+    touch a non-zero sample are added, in the same far-to-near order."""
+    x = np.asarray(x, dtype=np.float64)
+    r = int(truncate * float(sigma) + 0.5)
+    j = np.arange(-r, r + 1)
+    w = np.exp(-0.5 / (sigma * sigma) * j ** 2)
+    w = w / w.sum()
+    n = len(x)
+    period = 2 * n
+    nz = np.nonzero(x)[0]
+    out = np.zeros(n)
+    for i in range(n):
+        # source positions (in the mirrored extension) holding non-zero samples
+        offs = set()
+        for s in nz:
+            for base in range(-period * ((r // period) + 2), period * ((r // period) + 3), period):
+                for pos in (base + s, base + period - 1 - s):
+                    d = pos - i
+                    if -r <= d <= r:
+                        offs.add(abs(d))
+        acc = x[i] * w[r]
+        for d in sorted(offs, reverse=True):
+            if d == 0:
+                continue
+            def at(p):
+                q = p % period
+                return x[q] if q < n else x[period - 1 - q]
+            acc += (at(i - d) + at(i + d)) * w[r - d]
+        out[i] = acc
+    return out
+
+
+def slinear(xs, ys, xq):
+    """scipy.interpolate.interp1d(xs, ys, kind='slinear')(xq): the order-1
+    B-spline through the points (knots = xs with both ends doubled,
+    coefficients = ys), evaluated by de Boor's recursion: on
+    [xs[j], xs[j+1]]  w = 1/((xs[j+1]-x) + (x-xs[j])),
+    value = ys[j]*(w*(xs[j+1]-x)) + ys[j+1]*(w*(x-xs[j]))."""
+    xs = np.asarray(xs, dtype=np.float64)
+    ys = np.asarray(ys, dtype=np.float64)
+    out = np.empty(len(xq))
+    for i, x in enumerate(xq):
+        j = int(np.searchsorted(xs, x, side='right')) - 1
+        j = min(max(j, 0), len(xs) - 2)
+        xb = xs[j + 1] - x
+        xa = x - xs[j]
+        w = 1.0 / (xb + xa)
+        out[i] = 0.0 + ys[j] * (w * xb) + ys[j + 1] * (w * xa)
+    return out
+
+
+def decode_lines_vq(br, p, alloc, cur_t, sbr):
+    """The line loop of coder/codec.py:59-76 / :117-134 (useVQ)."""
+    bands = p.sfBandsShort if cur_t else p.sfBands
+    lines = np.zeros(p.nMDCTLines, dtype=np.float64)
+    at = 0
+    for b in range(bands.nBands):
+        n = bands.nLines[b]
+        if sbr and b in p.omittedBands:
+            n = 1
+        if alloc[b]:
+            lines[at:at + n] = dequantize_gain_shape(br, int(alloc[b] * n), n)
+        at += n
+    return lines
+
+
+def sbr_reconstruct(lines, p):
+    """coder/codec.py:136-198: the band values sit at the first lines above the
+    cut (one per omitted band, the rest of the 'envelope' is zero), get
+    smoothed, the lower half of the spectrum is transposed up by linear
+    interpolation and each omitted band is scaled to the smoothed envelope
+    over its mean magnitude."""
+    bands = p.sfBands
+    cut = bands.lowerLine[p.omittedBands[0]]
+    n_omit = len(lines) - cut
+    env = np.append(lines[cut:], np.zeros(n_omit))
+    smooth = gaussian_smooth(env) if np.count_nonzero(env) > 8 else gaussian_smooth_sparse(env)
+    up = int(math.floor(len(lines) / n_omit))
+    spacing = p.sampleRate / (2 * p.nMDCTLines)
+    freqs = (np.arange(p.nMDCTLines) + 1 / 2) * spacing
+    ii = np.arange(cut // up - 1, len(lines) // up + 1)
+    lines[cut:] = slinear(freqs[ii], lines[ii], freqs[cut:] / up)
+    for b in p.omittedBands:
+        lo, hi = bands.lowerLine[b], bands.upperLine[b] + 1
+        if np.max(np.abs(lines[lo:hi])) > 0:
+            lines[lo:hi] *= smooth[lo - cut:hi - cut] / np.mean(np.abs(lines[lo:hi]))
+    return lines
+
+
+def decode_block_vq(br, p, last_t, cur_t, next_t):
+    """getDecodedBlock + Decode / Decode_SBR for one (sub-)block of a VQ stream
+    (coder/pacfile.py:177-229, 645-668)."""
+    bands = p.sfBandsShort if cur_t else p.sfBands
+    overall = br.get(p.nScaleBits)
+    alloc = []
+    for b in range(bands.nBands):
+        a = br.get(p.nMantSizeBits)
+        alloc.append(a + 1 if a else 0)
+    sbr = bool(p.useSBR and not cur_t and
+               np.any(np.array(alloc)[np.array(p.omittedBands, dtype=int)] != 0))
+    lines = decode_lines_vq(br, p, alloc, cur_t, sbr)
+    if sbr:
+        lines = sbr_reconstruct(lines, p)
+    lines /= 1. * (1 << overall)
+    half_n = p.nMDCTLines
+    win = po.window_table(po.window_kind(last_t, cur_t, next_t), 2 * half_n)
+    return win * po.mdct_inverse(lines, half_n, half_n)
+
+
+def decode_stream_vq(data, max_blocks=None):
+    """Whole VQ / VQ+SBR .pac -> int16 [n, nCh] (coder/pacfile.py:231-298 +
+    coder/pcmfile.py:127-134), as pac_oracle.decode_stream does for scalar files."""
+    (sr, n_ch, n_samples, n_lines, n_scale, n_mant_size, use_sbr, use_vq) = struct.unpack(
+        '<LHLLHHHH', data[4:4 + struct.calcsize('<LHLLHHHH')])
+    assert data[:4] == b'PAC ' and use_vq and n_lines == 1024
+    pos = 4 + struct.calcsize('<LHLLHHHH')
+    n_bands = struct.unpack('<L', data[pos:pos + 4])[0]
+    pos += 4 + 2 * n_bands
+    p = po.make_params(sr, n_ch, 128, n_lines, n_scale, n_mant_size)
+    p.useVQ, p.useSBR = True, bool(use_sbr)
+    p.omittedBands = list(po.omitted_bands(p.sfBands)) if p.useSBR else []
+    hop = p.nMDCTLines
+    ola = [np.zeros(hop) for _ in range(n_ch)]
+    out = []
+    n_done = 0
+    while pos < len(data) and (max_blocks is None or n_done < max_blocks):
+        hop_out = []
+        for ch in range(n_ch):
+            n_bytes = struct.unpack('<L', data[pos:pos + 4])[0]
+            br = po.BitReader(data[pos + 4:pos + 4 + n_bytes] + b'\0' * 8)
+            pos += 4 + n_bytes
+            last_t, cur_t, next_t = br.get(1), br.get(1), br.get(1)
+            if not cur_t:
+                block = decode_block_vq(br, p, last_t, cur_t, next_t)
+            else:
+                block = np.zeros(2 * hop)
+                p.nMDCTLines = p.nSamplesPerBlock = po.SHORT_LINES
+                try:
+                    pad = hop // 2 - po.SHORT_LINES // 2
+                    for n in range(pad, 2 * hop - po.SHORT_LINES - pad, po.SHORT_LINES):
+                        block[n:n + 2 * po.SHORT_LINES] += decode_block_vq(br, p, last_t, cur_t, next_t)
+                finally:
+                    p.nMDCTLines = p.nSamplesPerBlock = hop
+            hop_out.append(np.add(ola[ch], block[:hop]))
+            ola[ch] = block[hop:]
+        out.append(np.stack([po.fraction_to_pcm16(h) for h in hop_out], axis=1))
+        n_done += 1
+    out.append(np.stack([po.fraction_to_pcm16(o) for o in ola], axis=1))
+    return np.concatenate(out)

@@ -24,6 +24,8 @@ Outputs
                     (gain-shape PVQ, SBR below 128 kb/s) vs the reference's own
                     committed test_decoded_full/*.pac; per-block CRCs
   excerpt_vq_*.npz  (--vq) 24-hop excerpts in the shipped configuration
+  decoded_vq_*.npz  (--vq-decoded) those excerpts through the reference's decoder
+  vqwav.json        (--vq-decoded) hashes of the decoded WAVs the reference committed
 """
 import hashlib
 import io
@@ -449,6 +451,32 @@ def make_decoded():
         np.savez_compressed(os.path.join(HERE, f"decoded_{name}.npz"), **res)
 
 
+def make_vq_decoded():
+    """decoded_vq_<wav>.npz: the VQ excerpt goldens through the reference's own
+    decoder; vqwav.json: sha256 of the PCM in the decoded WAVs the reference
+    committed next to its .pac files (test_decoded_full/<wav>_<rate>.wav)."""
+    sys.setrecursionlimit(12000)
+    for name in ["castanet", "harpsichord", "quar48_1", "spmg"]:
+        ex = np.load(os.path.join(HERE, f"excerpt_vq_{name}.npz"))
+        res = {}
+        for kbps in (128, 96):
+            pac = os.path.join(_work, f"decvq_{name}_{kbps}.pac")
+            open(pac, "wb").write(bytes(ex[f"pac_vq{kbps}"]))
+            res[f"pcm_vq{kbps}"] = ref_decode_file(pac, os.path.join(_work, f"decvq_{name}_{kbps}.wav"))
+            print(name, kbps, res[f"pcm_vq{kbps}"].shape)
+        np.savez_compressed(os.path.join(HERE, f"decoded_vq_{name}.npz"), **res)
+    rec = {}
+    for name in ["castanet", "harpsichord", "quar48_1", "spmg"]:
+        for kbps in (128, 96):
+            raw = open(os.path.join(REF, "test_decoded_full", f"{name}_{kbps}.wav"), "rb").read()
+            at = raw.index(b"data")
+            n = struct.unpack("<L", raw[at + 4:at + 8])[0]
+            pcm = raw[at + 8:at + 8 + n]
+            rec[f"{name}:{kbps}"] = dict(pcm_sha256=hashlib.sha256(pcm).hexdigest(),
+                                        n_samples=len(pcm) // 4)
+    json.dump(rec, open(os.path.join(HERE, "vqwav.json"), "w"), indent=1, sort_keys=True)
+
+
 def _full_one(args):
     name, bs = args
     path = os.path.join(REF, "test_signals", name + ".wav")
@@ -562,6 +590,8 @@ if __name__ == "__main__":
             for n in names}
     if "--decoded" in sys.argv:
         make_decoded()
+    elif "--vq-decoded" in sys.argv:
+        make_vq_decoded()
     elif "--vq" in sys.argv:
         make_vq_excerpts(names)
         make_vq(names)
