@@ -47,6 +47,9 @@ class PacxConfig(ctypes.Structure):
         ("use_sbr", ctypes.c_int32),
         ("half_log2", c_double_p),
         ("log_mu1", ctypes.c_double),
+        ("sbr_gauss", c_double_p),
+        ("sbr_gauss_radius", ctypes.c_int32),
+        ("line_freq_long", c_double_p),
     ]
 
 
@@ -91,6 +94,8 @@ SIGNATURES = {
     "pacx_mantissa": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "pacx_unpack_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pacx_decode_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pacx_decode_vq_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, _P, _P,
+                                            _P, _P, _P, _P, _P]),
     "pacx_transient_flags": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, _P, _P]),
     "pacx_bitalloc_generic": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, ctypes.c_int, _P, _P, _P]),
 }

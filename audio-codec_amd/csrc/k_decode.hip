@@ -126,6 +126,7 @@ __global__ __launch_bounds__(64) void k_imdct_long(PacxTables T, long long n_cf,
                                                   const int32_t *__restrict__ scale_factor,
                                                   const int32_t *__restrict__ bit_alloc,
                                                   const int32_t *__restrict__ mantissa,
+                                                  const double *__restrict__ lines_in,
                                                   double *__restrict__ blocks)
 {
     __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
@@ -138,10 +139,16 @@ __global__ __launch_bounds__(64) void k_imdct_long(PacxTables T, long long n_cf,
     if (fl & 2u)
         return;                                            /* short frame: k_imdct_short */
     const int ov = overall[cf * PACX_SUB];
-    const int32_t *ba = bit_alloc + cf * T.band_stride, *sf = scale_factor + cf * T.band_stride;
-    for (int k = lane; k < PACX_M_LONG; k += 64) {
-        const int b = T.line_band_long[k];
-        buf[k] = dequant_line(mantissa[cf * PACX_M_LONG + k], sf[b], ba[b], T.n_scale_bits, ov);
+    if (lines_in) {                                        /* gain-shape streams: lines come from k_vq_dec */
+        const double rescale = (double)(1 << ov);
+        for (int k = lane; k < PACX_M_LONG; k += 64)
+            buf[k] = lines_in[cf * PACX_M_LONG + k] / rescale;
+    } else {
+        const int32_t *ba = bit_alloc + cf * T.band_stride, *sf = scale_factor + cf * T.band_stride;
+        for (int k = lane; k < PACX_M_LONG; k += 64) {
+            const int b = T.line_band_long[k];
+            buf[k] = dequant_line(mantissa[cf * PACX_M_LONG + k], sf[b], ba[b], T.n_scale_bits, ov);
+        }
     }
     __syncthreads();
     const int M = PACX_M_LONG, Q = M / 2;
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(64) void k_imdct_short(PacxTables T, long long n_cf
                                                    const int32_t *__restrict__ scale_factor,
                                                    const int32_t *__restrict__ bit_alloc,
                                                    const int32_t *__restrict__ mantissa,
+                                                   const double *__restrict__ lines_in,
                                                    double *__restrict__ blocks)
 {
     __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
@@ -195,12 +203,19 @@ __global__ __launch_bounds__(64) void k_imdct_short(PacxTables T, long long n_cf
     const unsigned fl = cf_flags[cf];
     if (!(fl & 2u))
         return;
-    const int32_t *ba = bit_alloc + cf * T.band_stride, *sf = scale_factor + cf * T.band_stride;
-    for (int k = lane; k < PACX_M_LONG; k += 64) {
-        const int s = k / PACX_M_SHORT, kk = k % PACX_M_SHORT;
-        const int b = T.line_band_short[kk];
-        buf[s][kk] = dequant_line(mantissa[cf * PACX_M_LONG + k], sf[s * T.nb_short + b], ba[s * T.nb_short + b],
-                                  T.n_scale_bits, overall[cf * PACX_SUB + s]);
+    if (lines_in) {
+        for (int k = lane; k < PACX_M_LONG; k += 64) {
+            const int s = k / PACX_M_SHORT, kk = k % PACX_M_SHORT;
+            buf[s][kk] = lines_in[cf * PACX_M_LONG + k] / (double)(1 << overall[cf * PACX_SUB + s]);
+        }
+    } else {
+        const int32_t *ba = bit_alloc + cf * T.band_stride, *sf = scale_factor + cf * T.band_stride;
+        for (int k = lane; k < PACX_M_LONG; k += 64) {
+            const int s = k / PACX_M_SHORT, kk = k % PACX_M_SHORT;
+            const int b = T.line_band_short[kk];
+            buf[s][kk] = dequant_line(mantissa[cf * PACX_M_LONG + k], sf[s * T.nb_short + b], ba[s * T.nb_short + b],
+                                      T.n_scale_bits, overall[cf * PACX_SUB + s]);
+        }
     }
     __syncthreads();
     const int g = lane >> 3, r = lane & 7;
@@ -282,14 +297,15 @@ void pacx_launch_unpack(const PacxTables &T, long long n_cf, const uint8_t *payl
 
 void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const uint8_t *cf_flags,
                         const int32_t *overall, const int32_t *scale_factor, const int32_t *bit_alloc,
-                        const int32_t *mantissa, double *blocks, int16_t *pcm, hipStream_t st)
+                        const int32_t *mantissa, const double *lines_in, double *blocks, int16_t *pcm,
+                        hipStream_t st)
 {
     const long long n_cf = n_blocks * n_ch;
     if (n_cf > 0) {
         hipLaunchKernelGGL(k_imdct_long, dim3((unsigned)n_cf), dim3(64), 0, st, T, n_cf, cf_flags, overall,
-                           scale_factor, bit_alloc, mantissa, blocks);
+                           scale_factor, bit_alloc, mantissa, lines_in, blocks);
         hipLaunchKernelGGL(k_imdct_short, dim3((unsigned)n_cf), dim3(64), 0, st, T, n_cf, cf_flags, overall,
-                           scale_factor, bit_alloc, mantissa, blocks);
+                           scale_factor, bit_alloc, mantissa, lines_in, blocks);
     }
     if (pcm) {
         const long long total = (n_blocks + 1) * PACX_M_LONG * n_ch;

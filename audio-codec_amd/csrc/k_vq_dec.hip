@@ -1,0 +1,630 @@
+/*
+ * k_vq_dec.hip -- decode side of the gain-shape / SBR variants (SURVEY.md 8f-4
+ * for VQ streams): channel-block payload -> MDCT lines.
+ *
+ *   k_vq_dec    one workgroup per channel-block.  Header fields first (flags,
+ *               then per (sub-)block the overall scale and the allocations,
+ *               coder/pacfile.py:185-197, 264-266); a coded band occupies
+ *               exactly bitAlloc*nLines bits, so every band's position follows
+ *               from the allocations and the bands are decoded independently,
+ *               by ticket: dequantize_gain_shape
+ *               (coder/gain_shape_quantize.py:515-541) = split_band_decode
+ *               (:411-473) with pyramid-VQ leaves (decode_pvq_vector
+ *               :127-176, dequantize_pvq :259-272) times the mu-law gain.
+ *               Lines land where codec.Decode / Decode_SBR put them
+ *               (coder/codec.py:59-76, 117-134: an omitted band of an SBR long
+ *               block is ONE value, stored at the next line index).
+ *   k_sbr_recon Decode_SBR's reconstruction (coder/codec.py:136-198) for the
+ *               long blocks that carry omitted-band values: Gaussian-smoothed
+ *               envelope (scipy.ndimage.gaussian_filter1d, sigma 200, reflect),
+ *               transposition of the lower half by order-1 spline
+ *               interpolation (scipy interp1d 'slinear'), per-band scaling.
+ *               Both SciPy routines are restated with their summation order
+ *               (the CPU tests check the same restatement against SciPy bit for bit).
+ *
+ * The lines then go through the IMDCT / window / overlap-add kernels of
+ * k_decode.hip, which also divide by 2^overallScale.
+ */
+#include "../../include/pacx.h"
+#include "pacx_dev.h"
+#include "wave_np_sum.h"
+
+#define VQD_WAVES 4
+#define VQD_DEPTH 16
+#define VQD_WORDS 552
+
+struct VqDecView {
+    const uint64_t *n_tab, *p_tab;
+    const int32_t *row_off;
+    const int32_t *k_of;
+    const uint8_t *w_of;
+    const double *half_log2;
+    int l_max;
+    const double *gauss;          /* [2r+1] normalised weights, centre at r   */
+    int gauss_r;
+    const double *line_freq;      /* [1024] (k + 1/2) * sampleRate / 2048      */
+};
+
+__device__ __forceinline__ uint64_t vqd_N(const VqDecView &V, int l, long long k)
+{
+    if (k < 0)
+        return 0;
+    if (l <= 0)
+        return k == 0 ? 1ull : 0ull;
+    if (k == 0)
+        return 1ull;
+    if (l == 1)
+        return 2ull;
+    if (l == 2)
+        return 4ull * (uint64_t)k;
+    return V.n_tab[V.row_off[l] + k];
+}
+
+__device__ __forceinline__ uint64_t vqd_P(const VqDecView &V, int l, long long k)
+{
+    if (k < 0)
+        return 0;
+    if (l <= 0)
+        return 1ull;
+    if (l == 1)
+        return 1ull + 2ull * (uint64_t)k;
+    if (l == 2)
+        return 1ull + 2ull * (uint64_t)k * (uint64_t)(k + 1);
+    return V.p_tab[V.row_off[l] + k];
+}
+
+__device__ __forceinline__ void vqd_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double vqd_wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+/* up to 64 bits from the MSB-first word array */
+__device__ __forceinline__ unsigned long long vqd_get(const unsigned *words, int pos, int width)
+{
+    if (width <= 0)
+        return 0ull;
+    unsigned long long out = 0;
+    int left = width;
+    while (left > 0) {
+        const int w = pos >> 5, o = pos & 31;
+        const int take = (32 - o) < left ? (32 - o) : left;
+        const unsigned chunk = (words[w] >> (32 - o - take)) & (take >= 32 ? 0xFFFFFFFFu : ((1u << take) - 1u));
+        out = (out << take) | chunk;
+        pos += take;
+        left -= take;
+    }
+    return out;
+}
+
+/* decode_pvq_vector: index b -> integer vector y[0..L) (LDS, zeroed here).
+ * Uniform across the wave; lane 0 stores. */
+__device__ __forceinline__ void vqd_pvq(const VqDecView &V, unsigned long long b, int L, int K, double *y,
+                                        int lane, unsigned &flags)
+{
+    for (int i = lane; i < L; i += 64)
+        y[i] = 0.0;
+    vqd_fence();
+    unsigned long long xb = 0;
+    long long k = K;
+    int l = L;
+    for (int i = 0; i < L && k > 0; ++i, --l) {
+        if (b == xb) {                                  /* the rest is zero, the last component takes k */
+            if (lane == 0)
+                y[L - 1] = (double)k;
+            k = 0;
+            break;
+        }
+        const unsigned long long n0 = vqd_N(V, l - 1, k);
+        if (b - xb < n0)
+            continue;                                   /* this component is zero */
+        xb += n0;
+        const unsigned long long r = b - xb;
+        const unsigned long long pk1 = vqd_P(V, l - 1, k - 1);
+        long long lo = 1, hi = k;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            const unsigned long long c = 2ull * (pk1 - vqd_P(V, l - 1, k - mid - 1));
+            if (r < c)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const long long j = lo;
+        if (r >= 2ull * (pk1 - vqd_P(V, l - 1, k - j - 1))) {
+            flags |= PACX_ST_VQ_UNDEFINED;              /* not an index of this codebook */
+            break;
+        }
+        const unsigned long long base = 2ull * (pk1 - vqd_P(V, l - 1, k - j));
+        /* the reference reaches the negative group by walking through the whole
+           positive one at the next component (its step 3 -> step 1 restart) */
+        const unsigned long long group = vqd_N(V, l - 1, k - j);
+        const bool neg = (r - base) >= group;
+        if (lane == 0)
+            y[i] = neg ? -(double)j : (double)j;
+        xb += base + (neg ? group : 0ull);
+        k -= j;
+    }
+    if (k > 0)
+        flags |= PACX_ST_VQ_UNDEFINED;                  /* pulses left over: the reference raises */
+    vqd_fence();
+}
+
+/* x /= ||x|| when the norm is not zero (np.linalg.norm: sqrt of the dot product) */
+__device__ __forceinline__ void vqd_normalize(double *x, int n, int lane)
+{
+    double acc = 0.0;
+    for (int i = lane; i < n; i += 64)
+        acc = fma(x[i], x[i], acc);
+    const double nrm = sqrt(vqd_wave_sum(acc));
+    if (nrm != 0.0)
+        for (int i = lane; i < n; i += 64)
+            x[i] = x[i] / nrm;
+    vqd_fence();
+}
+
+/* one PVQ leaf into out[0..n) */
+__device__ __forceinline__ void vqd_leaf(const VqDecView &V, const unsigned *words, int &pos, double *out, int n,
+                                         int bits, int lane, unsigned &flags)
+{
+    const int K = V.k_of[n * 33 + bits];
+    const int width = V.w_of[n * 33 + bits];
+    if (K < 0) {
+        flags |= PACX_ST_VQ_UNDEFINED;
+        for (int i = lane; i < n; i += 64)
+            out[i] = 0.0;
+        vqd_fence();
+        return;
+    }
+    const unsigned long long idx = vqd_get(words, pos, width);
+    pos += width;
+    vqd_pvq(V, idx, n, K, out, lane, flags);
+    vqd_normalize(out, n, lane);
+}
+
+/* frames of the split tree (per wave, in LDS) */
+struct VqdFrame {
+    double theta;
+    int out, n, half, a_side, reg, state;
+};
+
+/* split_band_decode: unit vector of dimension n0 at scr[out0..], bits0 bits. */
+__device__ __forceinline__ void vqd_shape(const VqDecView &V, const unsigned *words, int &pos, double *scr,
+                                          int out0, int n0, int bits0, int reg0, VqdFrame *fr, int lane,
+                                          unsigned &flags)
+{
+    const double half_pi = 1.5707963267948966;
+    if (bits0 <= PACX_VQ_SPLIT_BITS) {
+        /* the non-split branch normalises a second time (:468-472) */
+        vqd_leaf(V, words, pos, scr + out0, n0, bits0, lane, flags);
+        vqd_normalize(scr + out0, n0, lane);
+        return;
+    }
+    int depth = 0;
+    int cur_out = out0, cur_n = n0, cur_bits = bits0, cur_reg = reg0;
+    int phase = 0;                  /* 0: enter split node, 1: side of frame[depth], 2: combine frame[depth] */
+    for (;;) {
+        if (phase == 0) {
+            if (depth >= VQD_DEPTH) {
+                flags |= PACX_ST_VQ_UNDEFINED;
+                return;
+            }
+            const int half = cur_n - cur_n / 2;
+            int a_theta = (int)floor((double)cur_bits / (double)half + V.half_log2[half]);
+            int a_rest = cur_bits - a_theta;
+            if (a_rest < 0)
+                a_rest = 0;
+            double theta = 0.0;
+            if (a_theta > 0 && a_theta <= 62) {
+                const unsigned long long code = vqd_get(words, pos, a_theta);
+                const unsigned long long mag = code & ((1ull << (a_theta - 1)) - 1ull);
+                const double den = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+                double dq = (double)(2ull * mag) / den;
+                if (code >> (a_theta - 1))
+                    dq = -dq;
+                theta = dq * half_pi;
+            } else if (a_theta > 62) {
+                flags |= PACX_ST_VQ_UNDEFINED;
+            }
+            pos += a_theta > 0 ? a_theta : 0;
+            int a_mid = 0;
+            if (theta != 0.0) {
+                const double v = ((double)a_rest - (double)(half - 1) * log2(tan(fabs(theta)) + PACX_EPS)) / 2.0;
+                const double f = floor(v);
+                a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
+            }
+            VqdFrame &F = fr[depth];
+            if (lane == 0) {
+                F.theta = theta;
+                F.out = cur_out;
+                F.n = cur_n;
+                F.half = half;
+                F.a_side = a_rest - a_mid;
+                F.reg = cur_reg;
+                F.state = 0;
+            }
+            vqd_fence();
+            const int mid_slot = cur_reg;
+            if (a_mid > PACX_VQ_SPLIT_BITS) {
+                depth += 1;
+                cur_out = mid_slot;
+                cur_n = half;
+                cur_bits = a_mid;
+                cur_reg = cur_reg + 2 * half;
+                continue;                                   /* phase 0 on the mid child */
+            }
+            if (a_mid > 0) {
+                vqd_leaf(V, words, pos, scr + mid_slot, half, a_mid, lane, flags);
+            } else {
+                for (int i = lane; i < half; i += 64)
+                    scr[mid_slot + i] = 0.0;
+                vqd_fence();
+            }
+            phase = 1;
+            continue;
+        }
+        if (phase == 1) {
+            const int half = fr[depth].half, a_side = fr[depth].a_side, reg = fr[depth].reg;
+            const int side_slot = reg + half;
+            if (lane == 0)
+                fr[depth].state = 1;
+            vqd_fence();
+            if (a_side > PACX_VQ_SPLIT_BITS) {
+                depth += 1;
+                cur_out = side_slot;
+                cur_n = half;
+                cur_bits = a_side;
+                cur_reg = reg + 2 * half;
+                phase = 0;
+                continue;
+            }
+            if (a_side > 0) {
+                vqd_leaf(V, words, pos, scr + side_slot, half, a_side, lane, flags);
+            } else {
+                for (int i = lane; i < half; i += 64)
+                    scr[side_slot + i] = 0.0;
+                vqd_fence();
+            }
+            phase = 2;
+            continue;
+        }
+        /* phase 2: left/right from mid/side (:455-466) */
+        {
+            const VqdFrame F = fr[depth];
+            const double ct = cos(F.theta), st = sin(F.theta);
+            const double root2 = sqrt(2.0);
+            const int cut = F.n / 2;
+            const double *mid = scr + F.reg, *side = scr + F.reg + F.half;
+            double *out = scr + F.out;
+            for (int i = lane; i < F.half; i += 64) {
+                const double m = mid[i] * ct, s = side[i] * st;
+                const double left = (m + s) / root2;
+                const double right = (m - s) / root2;
+                if (i < cut)
+                    out[i] = left;                          /* an odd band drops the last left value */
+                out[cut + i] = right;
+            }
+            vqd_fence();
+            vqd_normalize(out, F.n, lane);
+        }
+        if (depth == 0)
+            return;
+        depth -= 1;
+        phase = (fr[depth].state == 0) ? 1 : 2;
+    }
+}
+
+struct VqDecArgs {
+    long long n_cf;
+    const uint8_t *payload;
+    int payload_stride;
+    const long long *offsets;
+    const int32_t *n_bytes;
+    uint8_t *cf_flags;
+    int32_t *overall;          /* [cf][8]                                   */
+    int32_t *bit_alloc;        /* [cf][band_stride]                         */
+    double *lines;             /* [cf][1024] before SBR reconstruction and /2^overall */
+    uint8_t *sbr_flag;         /* [cf] 1: Decode_SBR applies                */
+    uint32_t *status;
+    int scr_len;
+};
+
+__global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecView V, VqDecArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *words = (unsigned *)smem;                                  /* VQD_WORDS            */
+    double *lines_s = (double *)(smem + VQD_WORDS * 4);                  /* 1024                 */
+    int *item_pos = (int *)(lines_s + PACX_M_LONG);                      /* [8*32] band bit position */
+    int *item_ba = item_pos + PACX_SUB * PACX_MAX_BANDS;                 /* [8*32]               */
+    int *misc = item_ba + PACX_SUB * PACX_MAX_BANDS;                     /* ticket, n_items, short, sbr */
+    VqdFrame *frames = (VqdFrame *)(misc + 4);                           /* waves * DEPTH        */
+    double *scr_all = (double *)(frames + VQD_WAVES * VQD_DEPTH);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long cf = blockIdx.x;
+    if (cf >= A.n_cf)
+        return;
+    const int nbytes = A.n_bytes[cf];
+    const uint8_t *src = A.payload + (A.offsets ? A.offsets[cf] : cf * (long long)A.payload_stride);
+    const int n_words = (nbytes + 3) >> 2;
+    for (int i = tid; i < VQD_WORDS; i += 64 * VQD_WAVES) {
+        unsigned v = 0;
+        if (i < n_words) {
+            const int b0 = 4 * i;
+            v = ((unsigned)src[b0] << 24) | ((b0 + 1 < nbytes ? (unsigned)src[b0 + 1] : 0u) << 16) |
+                ((b0 + 2 < nbytes ? (unsigned)src[b0 + 2] : 0u) << 8) | (b0 + 3 < nbytes ? (unsigned)src[b0 + 3] : 0u);
+        }
+        words[i] = v;
+    }
+    for (int i = tid; i < PACX_M_LONG; i += 64 * VQD_WAVES)
+        lines_s[i] = 0.0;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned fl = (unsigned)vqd_get(words, 0, 1) | ((unsigned)vqd_get(words, 1, 1) << 1) |
+                            ((unsigned)vqd_get(words, 2, 1) << 2);
+        A.cf_flags[cf] = (uint8_t)fl;
+        const int shrt = (fl >> 1) & 1;
+        const int nb = shrt ? T.nb_short : T.nb_long;
+        const int32_t *cnt = shrt ? T.band_lines_short : T.band_lines_long;
+        int pos = 3;
+        /* Decode_SBR is chosen per block: an SBR file, a long block, and some
+           omitted band with a non-zero allocation (coder/pacfile.py:661-666) */
+        int sbr = 0;
+        if (T.use_sbr && !shrt) {
+            int p2 = pos + T.n_scale_bits;
+            for (int b = 0; b < nb; ++b) {
+                if (b >= T.first_omitted && vqd_get(words, p2, T.n_mant_size_bits) != 0)
+                    sbr = 1;
+                p2 += T.n_mant_size_bits;
+            }
+        }
+        for (int s = 0; s < (shrt ? PACX_SUB : 1); ++s) {
+            A.overall[cf * PACX_SUB + s] = (int)vqd_get(words, pos, T.n_scale_bits);
+            pos += T.n_scale_bits;
+            int body = pos + T.n_mant_size_bits * nb;
+            for (int b = 0; b < nb; ++b) {
+                int a = (int)vqd_get(words, pos, T.n_mant_size_bits);
+                if (a)
+                    a += 1;
+                pos += T.n_mant_size_bits;
+                A.bit_alloc[cf * T.band_stride + s * nb + b] = a;
+                item_pos[s * PACX_MAX_BANDS + b] = body;
+                item_ba[s * PACX_MAX_BANDS + b] = a;
+                body += a * ((sbr && b >= T.first_omitted) ? 1 : cnt[b]);
+            }
+            pos = body;
+        }
+        if (!shrt)
+            for (int s = 1; s < PACX_SUB; ++s)
+                A.overall[cf * PACX_SUB + s] = 0;
+        misc[0] = 0;
+        misc[1] = (shrt ? PACX_SUB : 1) * nb;
+        misc[2] = shrt;
+        misc[3] = sbr;
+        A.sbr_flag[cf] = (uint8_t)sbr;
+    }
+    __syncthreads();
+    const int shrt = misc[2], sbr = misc[3], n_items = misc[1];
+    const int nb = shrt ? T.nb_short : T.nb_long;
+    const int32_t *__restrict__ lower = shrt ? T.band_lower_short : T.band_lower_long;
+    const int32_t *__restrict__ count = shrt ? T.band_lines_short : T.band_lines_long;
+    double *scr = scr_all + (size_t)wave * A.scr_len;
+    VqdFrame *fr = frames + wave * VQD_DEPTH;
+    unsigned raised = 0;
+    for (;;) {
+        int tk = 0;
+        if (lane == 0)
+            tk = atomicAdd(&misc[0], 1);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= n_items)
+            break;
+        const int s = tk / nb, b = nb - 1 - (tk % nb);           /* large bands first */
+        const int ba = item_ba[s * PACX_MAX_BANDS + b];
+        if (!ba)
+            continue;
+        int pos = item_pos[s * PACX_MAX_BANDS + b];
+        /* where the band's lines go: iMant advances by 1 over an omitted band of
+           an SBR block (coder/codec.py:121-134) */
+        int n = count[b], at = lower[b];
+        if (sbr && b >= T.first_omitted) {
+            n = 1;
+            at = lower[T.first_omitted] + (b - T.first_omitted);
+        }
+        const int r_bits = ba * n;
+        int bits_gain = (int)floor((double)r_bits / (double)n + V.half_log2[n]);
+        int bits_shape = r_bits - bits_gain;
+        if (bits_shape < 0)
+            bits_shape = 0;
+        if (bits_shape != 0) {
+            const int before = pos;
+            vqd_shape(V, words, pos, scr, 0, n, bits_shape, n, fr, lane, raised);
+            bits_gain += bits_shape - (pos - before);
+        } else {
+            for (int i = lane; i < n; i += 64)
+                scr[i] = 1.0;
+            vqd_fence();
+        }
+        /* gain: DequantizeUniform then the inverse mu-law, times L (:533-537) */
+        double deq = 0.0;
+        if (bits_gain > 64) {
+            raised |= PACX_ST_VQ_UNDEFINED;
+        } else if (bits_gain > 0) {
+            const unsigned long long code = vqd_get(words, pos, bits_gain);
+            const unsigned long long mag = (bits_gain == 64) ? (code & 0x7FFFFFFFFFFFFFFFull)
+                                                              : (code & ((1ull << (bits_gain - 1)) - 1ull));
+            const double den = (bits_gain <= 53) ? (double)((1ull << bits_gain) - 1ull) : ldexp(1.0, bits_gain);
+            deq = (2.0 * (double)mag) / den;
+            if (code >> (bits_gain - 1))
+                deq = -deq;
+        }
+        const double sgn = (deq > 0.0) ? 1.0 : ((deq < 0.0) ? -1.0 : 0.0);
+        const double gain = (sgn / 255.0 * (pow(256.0, fabs(deq)) - 1.0)) * (double)n;
+        double *dst = lines_s + (shrt ? s * PACX_M_SHORT : 0) + at;
+        for (int i = lane; i < n; i += 64)
+            dst[i] = gain * scr[i];
+        vqd_fence();
+    }
+    if (raised && lane == 0)
+        atomicOr(&A.status[cf], raised);
+    __syncthreads();
+    double *out = A.lines + cf * PACX_M_LONG;
+    for (int i = tid; i < PACX_M_LONG; i += 64 * VQD_WAVES)
+        out[i] = lines_s[i];
+}
+
+/* ------------------------------------------------------- SBR reconstruction */
+#define SBR_THREADS 256
+
+__global__ __launch_bounds__(SBR_THREADS) void k_sbr_recon(PacxTables T, VqDecView V, long long n_cf,
+                                                          const uint8_t *__restrict__ sbr_flag,
+                                                          double *__restrict__ lines)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf || !sbr_flag[cf])
+        return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int M = PACX_M_LONG;
+    const int cut = T.band_lower_long[T.first_omitted];
+    const int n_omit = M - cut;
+    const int r = V.gauss_r;
+    double *ln = (double *)smem;                 /* [M] lines                          */
+    double *ext = ln + M;                        /* [2 n_omit + 2 r] mirrored envelope */
+    double *smooth = ext + 2 * n_omit + 2 * r;   /* [n_omit]                           */
+    double *old = smooth + n_omit;               /* [M/up + 2] interpolation ordinates */
+    double *g = lines + cf * M;
+    for (int i = tid; i < M; i += SBR_THREADS)
+        ln[i] = g[i];
+    __syncthreads();
+    /* envelope = lines[cut:] ++ zeros, extended by reflection (d c b a | a b c d | d c b a) */
+    const int n_env = 2 * n_omit, period = 2 * n_env;
+    for (int p = tid; p < n_env + 2 * r; p += SBR_THREADS) {
+        int m = (p - r) % period;
+        if (m < 0)
+            m += period;
+        if (m >= n_env)
+            m = period - 1 - m;
+        ext[p] = (m < n_omit) ? ln[cut + m] : 0.0;
+    }
+    __syncthreads();
+    /* correlate1d, symmetric kernel: centre first, then the pairs from the far end inwards */
+    const double *__restrict__ w = V.gauss;
+    for (int i = tid; i < n_omit; i += SBR_THREADS) {
+        const int c = i + r;
+        double acc = ext[c] * w[r];
+        for (int jj = -r; jj < 0; ++jj)
+            acc += (ext[c + jj] + ext[c - jj]) * w[r + jj];
+        smooth[i] = acc;
+    }
+    /* transposition: lines[cut + i] = spline1(freq[cut + i] / up) through the points
+       (freq[k], lines[k]), k = cut/up - 1 .. M/up */
+    const int up = M / n_omit;                   /* floor(len / num_omitted) */
+    const int k_lo = cut / up - 1, k_hi = M / up;
+    for (int k = k_lo + tid; k <= k_hi; k += SBR_THREADS)
+        old[k - k_lo] = ln[k];
+    __syncthreads();
+    const double *__restrict__ fq = V.line_freq;
+    for (int i = tid; i < n_omit; i += SBR_THREADS) {
+        const double x = fq[cut + i] / (double)up;
+        /* interval with fq[j] <= x < fq[j+1] (np.searchsorted side='right' - 1), clamped */
+        int j = (2 * (cut + i) + 1 - up) / (2 * up);          /* floor(((cut+i)+1/2)/up - 1/2) */
+        if (j < k_lo) j = k_lo;
+        if (j > k_hi - 1) j = k_hi - 1;
+        while (j > k_lo && x < fq[j])
+            --j;
+        while (j < k_hi - 1 && x >= fq[j + 1])
+            ++j;
+        const double xb = fq[j + 1] - x, xa = x - fq[j];
+        const double ww = 1.0 / (xb + xa);
+        ln[cut + i] = 0.0 + old[j - k_lo] * (ww * xb) + old[j + 1 - k_lo] * (ww * xa);
+    }
+    __syncthreads();
+    /* per omitted band: scale to the smoothed envelope over the mean magnitude */
+    if (tid < 64) {
+        double *mag = ext;                       /* reuse: |lines| of the band for np.mean */
+        for (int b = T.first_omitted; b < T.nb_long; ++b) {
+            const int lo = T.band_lower_long[b], cnt = T.band_lines_long[b];
+            double mx = 0.0;
+            for (int i = lane; i < cnt; i += 64) {
+                const double a = fabs(ln[lo + i]);
+                mag[i] = a;
+                mx = fmax(mx, a);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                mx = fmax(mx, __shfl_xor(mx, off, 64));
+            vqd_fence();
+            if (mx > 0.0) {
+                const double mean = wave_np_sum(mag, cnt, lane) / (double)cnt;
+                for (int i = lane; i < cnt; i += 64)
+                    ln[lo + i] = ln[lo + i] * (smooth[lo - cut + i] / mean);
+            }
+            vqd_fence();
+        }
+    }
+    __syncthreads();
+    for (int i = cut + tid; i < M; i += SBR_THREADS)
+        g[i] = ln[i];
+}
+
+/* ---------------------------------------------------------------- launchers */
+size_t pacx_vqdec_view_size(void) { return sizeof(VqDecView); }
+
+void pacx_vqdec_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
+                          const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
+                          const double *gauss, int gauss_r, const double *line_freq)
+{
+    VqDecView *v = (VqDecView *)dst;
+    v->n_tab = n_tab;
+    v->p_tab = p_tab;
+    v->row_off = row_off;
+    v->k_of = k_of;
+    v->w_of = w_of;
+    v->half_log2 = half_log2;
+    v->l_max = l_max;
+    v->gauss = gauss;
+    v->gauss_r = gauss_r;
+    v->line_freq = line_freq;
+}
+
+void pacx_launch_vq_dec(const PacxTables &T, const void *view, long long n_cf, const uint8_t *payload,
+                        int payload_stride, const long long *offsets, const int32_t *n_bytes,
+                        uint8_t *cf_flags, int32_t *overall, int32_t *bit_alloc, double *lines,
+                        uint8_t *sbr_flag, uint32_t *status, hipStream_t st)
+{
+    if (n_cf <= 0)
+        return;
+    const VqDecView &V = *(const VqDecView *)view;
+    VqDecArgs A;
+    A.n_cf = n_cf;
+    A.payload = payload;
+    A.payload_stride = payload_stride;
+    A.offsets = offsets;
+    A.n_bytes = n_bytes;
+    A.cf_flags = cf_flags;
+    A.overall = overall;
+    A.bit_alloc = bit_alloc;
+    A.lines = lines;
+    A.sbr_flag = sbr_flag;
+    A.status = status;
+    A.scr_len = (3 * V.l_max + 4 * VQD_DEPTH + 1) & ~1;
+    const size_t fixed = VQD_WORDS * 4 + PACX_M_LONG * 8 + (2 * PACX_SUB * PACX_MAX_BANDS + 4) * 4 +
+                         VQD_WAVES * VQD_DEPTH * sizeof(VqdFrame);
+    const size_t smem = fixed + (size_t)VQD_WAVES * A.scr_len * 8;
+    hipLaunchKernelGGL(k_vq_dec, dim3((unsigned)n_cf), dim3(64 * VQD_WAVES), smem, st, T, V, A);
+    if (T.use_sbr) {
+        const int cut = 0;   /* sizes below use the worst case n_omit = 1024 */
+        (void)cut;
+        const size_t s2 = (size_t)(PACX_M_LONG + (2 * PACX_M_LONG + 2 * V.gauss_r) + PACX_M_LONG + PACX_M_LONG + 2) * 8;
+        hipLaunchKernelGGL(k_sbr_recon, dim3((unsigned)n_cf), dim3(SBR_THREADS), s2, st, T, V, n_cf, sbr_flag, lines);
+    }
+}

@@ -60,7 +60,17 @@ void pacx_launch_unpack(const PacxTables &T, long long n_cf, const uint8_t *payl
                         int32_t *scale_factor, int32_t *bit_alloc, int32_t *mantissa, hipStream_t st);
 void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const uint8_t *cf_flags,
                         const int32_t *overall, const int32_t *scale_factor, const int32_t *bit_alloc,
-                        const int32_t *mantissa, double *blocks, int16_t *pcm, hipStream_t st);
+                        const int32_t *mantissa, const double *lines_in, double *blocks, int16_t *pcm,
+                        hipStream_t st);
+/* k_vq_dec.hip */
+size_t pacx_vqdec_view_size(void);
+void pacx_vqdec_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
+                          const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
+                          const double *gauss, int gauss_r, const double *line_freq);
+void pacx_launch_vq_dec(const PacxTables &T, const void *view, long long n_cf, const uint8_t *payload,
+                        int payload_stride, const long long *offsets, const int32_t *n_bytes,
+                        uint8_t *cf_flags, int32_t *overall, int32_t *bit_alloc, double *lines,
+                        uint8_t *sbr_flag, uint32_t *status, hipStream_t st);
 
 /* k_vq.hip */
 void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *flags, int n_ch, long long n_cf,
@@ -96,6 +106,10 @@ struct pacx_handle {
     double *ws_blocks;                /* [cf][2048] blocks before overlap-add   */
     /* gain-shape coder (use_vq) */
     std::vector<char> vq_view;        /* VqView of k_vq.hip (device pointers)   */
+    std::vector<char> vqdec_view;     /* VqDecView of k_vq_dec.hip              */
+    long long ws_dec_cf;              /* capacity of the VQ decode buffers      */
+    double *ws_dec_lines;             /* [cf][1024]                             */
+    uint8_t *ws_dec_sbr;              /* [cf]                                   */
     double *ws_sbr_mean;              /* [ws_cf][8] omitted-band means           */
     long long ws_vq_cf;               /* capacity of the short-frame buffers    */
     unsigned *ws_unit_words;          /* [ws_vq_cf*8][548]                      */
@@ -211,6 +225,9 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->ws_blocks_cf = 0;
     h->ws_blocks = nullptr;
     h->ws_sbr_mean = nullptr;
+    h->ws_dec_cf = 0;
+    h->ws_dec_lines = nullptr;
+    h->ws_dec_sbr = nullptr;
     h->ws_vq_cf = 0;
     h->ws_unit_words = nullptr;
     h->ws_unit_bits = nullptr;
@@ -397,6 +414,33 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         pacx_vq_view_fill(h->vq_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max,
                           cfg->log_mu1 != 0.0 ? cfg->log_mu1 : log(256.0), sizes_long.data(), T.nb_long,
                           cfg->band_lines_short, T.nb_short);
+        /* decode side: Gaussian weights of gaussian_filter1d(sigma=200) (radius
+           int(4*200 + 0.5)) and the MDCT line frequencies of Decode_SBR */
+        const int gr = cfg->sbr_gauss ? cfg->sbr_gauss_radius : 800;
+        if (gr < 1 || gr > 4096) {
+            g_create_err = "pacx_create: sbr_gauss_radius out of range";
+            pacx_destroy(h);
+            return PACX_E_ARG;
+        }
+        std::vector<double> gw(2 * gr + 1), lf(ML);
+        if (cfg->sbr_gauss) {
+            memcpy(gw.data(), cfg->sbr_gauss, sizeof(double) * gw.size());
+        } else {
+            double sum = 0;
+            for (int j = -gr; j <= gr; ++j) {
+                gw[j + gr] = exp(-0.5 / (200.0 * 200.0) * (double)(j * j));
+                sum += gw[j + gr];
+            }
+            for (double &v : gw)
+                v /= sum;
+        }
+        for (int k = 0; k < ML; ++k)
+            lf[k] = cfg->line_freq_long ? cfg->line_freq_long[k] : (k + 0.5) * (sr / (2 * ML));
+        const double *d_gw, *d_lf;
+        TRY(upload(h, gw.data(), gw.size(), &d_gw));
+        TRY(upload(h, lf.data(), lf.size(), &d_lf));
+        h->vqdec_view.resize(pacx_vqdec_view_size());
+        pacx_vqdec_view_fill(h->vqdec_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max, d_gw, gr, d_lf);
     }
 #undef TRY
     *out = h;
@@ -428,6 +472,10 @@ extern "C" void pacx_destroy(pacx_handle *h)
         (void)hipFree(h->ws_unit_words);
     if (h->ws_unit_bits)
         (void)hipFree(h->ws_unit_bits);
+    if (h->ws_dec_lines)
+        (void)hipFree(h->ws_dec_lines);
+    if (h->ws_dec_sbr)
+        (void)hipFree(h->ws_dec_sbr);
     for (void *p : h->owned)
         (void)hipFree(p);
     delete h;
@@ -871,6 +919,59 @@ extern "C" int pacx_decode_batch(pacx_handle *h, int64_t n_blocks, int n_channel
         work = h->ws_blocks;
     }
     pacx_launch_decode(h->T, n_blocks, n_channels, cf_flags, overall_scale, scale_factor, bit_alloc, mantissa,
-                       work, pcm, (hipStream_t)stream);
+                       nullptr, work, pcm, (hipStream_t)stream);
     return post_launch(h, "pacx_decode_batch");
+}
+
+extern "C" int pacx_decode_vq_batch(pacx_handle *h, int64_t n_blocks, int n_channels, const uint8_t *payload,
+                                    int payload_stride, const int64_t *offsets, const int32_t *n_bytes,
+                                    uint8_t *cf_flags, int32_t *overall_scale, int32_t *bit_alloc,
+                                    double *lines, double *blocks, int16_t *pcm, uint32_t *status,
+                                    void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_blocks < 0 || n_channels < 1 ||
+        (n_blocks > 0 && (!payload || !n_bytes || !cf_flags || !overall_scale || !bit_alloc || !status ||
+                          (!offsets && payload_stride <= 0))))
+        return fail(h, PACX_E_ARG, "pacx_decode_vq_batch: bad argument");
+    if (!h->T.use_vq)
+        return fail(h, PACX_E_UNSUPPORTED, "pacx_decode_vq_batch: handle was created without use_vq");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const long long n_cf = n_blocks * n_channels;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_cf > h->ws_dec_cf) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        if (h->ws_dec_lines) (void)hipFree(h->ws_dec_lines);
+        if (h->ws_dec_sbr) (void)hipFree(h->ws_dec_sbr);
+        h->ws_dec_lines = nullptr;
+        h->ws_dec_sbr = nullptr;
+        h->ws_dec_cf = 0;
+        HIP_TRY(h, hipMalloc((void **)&h->ws_dec_lines, (size_t)n_cf * PACX_M_LONG * sizeof(double)));
+        HIP_TRY(h, hipMalloc((void **)&h->ws_dec_sbr, (size_t)n_cf));
+        h->ws_dec_cf = n_cf;
+    }
+    double *ln = lines ? lines : h->ws_dec_lines;
+    double *work = blocks;
+    if (!work && pcm && n_cf > 0) {
+        if (n_cf > h->ws_blocks_cf) {
+            HIP_TRY(h, hipDeviceSynchronize());
+            if (h->ws_blocks)
+                (void)hipFree(h->ws_blocks);
+            h->ws_blocks = nullptr;
+            h->ws_blocks_cf = 0;
+            HIP_TRY(h, hipMalloc((void **)&h->ws_blocks, (size_t)n_cf * PACX_N_LONG * sizeof(double)));
+            h->ws_blocks_cf = n_cf;
+        }
+        work = h->ws_blocks;
+    }
+    if (n_cf > 0) {
+        HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
+        pacx_launch_vq_dec(h->T, h->vqdec_view.data(), n_cf, payload, payload_stride, (const long long *)offsets,
+                           n_bytes, cf_flags, overall_scale, bit_alloc, ln, h->ws_dec_sbr, status, st);
+    }
+    if (work || pcm)
+        pacx_launch_decode(h->T, n_blocks, n_channels, cf_flags, overall_scale, nullptr, nullptr, nullptr, ln,
+                           work, pcm, st);
+    return post_launch(h, "pacx_decode_vq_batch");
 }

@@ -113,6 +113,9 @@ class Encoder:
         l_max = int(max(np.max(self.sfBands.nLines), np.max(self.sfBandsShort.nLines)))
         cfg.half_log2 = f64("hl2", tables.half_log2(l_max))
         cfg.log_mu1 = tables.log_mu1()
+        gw, gr = tables.sbr_gauss()
+        cfg.sbr_gauss, cfg.sbr_gauss_radius = f64("gw", gw), gr
+        cfg.line_freq_long = f64("lf", (np.arange(N_LONG) + 1 / 2) * (sr / (2 * N_LONG)))
         h = ctypes.c_void_p()
         rc = self.lib.pacx_create(ctypes.byref(cfg), ctypes.byref(h))
         _lib.check(self.lib, None, rc, "pacx_create")
@@ -324,6 +327,29 @@ class Encoder:
                    _ptr(codes["overall"]), _ptr(codes["scale_factor"]), _ptr(codes["bit_alloc"]),
                    _ptr(codes["mantissa"]), _ptr(blocks), _ptr(pcm), self._stream())
         return (blocks, pcm) if want_blocks and want_pcm else (blocks if want_blocks else pcm)
+
+    def decode_vq(self, payload, n_bytes, n_channels, offsets=None, want_lines=False, want_blocks=False,
+                  want_pcm=True):
+        """Gain-shape coded channel-blocks (slot layout, or byte stream + int64
+        offsets) -> dict: flags, overall, bit_alloc, status and, as requested,
+        lines [n_cf,1024], blocks [n_cf,2048], pcm int16 [(n_blocks+1)*1024, nCh]."""
+        n_cf = n_bytes.shape[0]
+        n_blocks = n_cf // n_channels
+        out = {
+            "flags": self._empty((n_cf,), torch.uint8),
+            "overall": self._empty((n_cf, _lib.SUB), torch.int32),
+            "bit_alloc": torch.zeros((n_cf, self.band_stride), dtype=torch.int32, device=self.device),
+            "status": self._empty((n_cf,), torch.int32),
+            "lines": self._empty((n_cf, N_LONG), torch.float64) if want_lines else None,
+            "blocks": self._empty((n_cf, 2 * N_LONG), torch.float64) if want_blocks else None,
+            "pcm": self._empty(((n_blocks + 1) * N_LONG, n_channels), torch.int16) if want_pcm else None,
+        }
+        stride = 0 if offsets is not None else int(payload.shape[1])
+        self._call("pacx_decode_vq_batch", ctypes.c_int64(n_blocks), int(n_channels), _ptr(payload), stride,
+                   _ptr(offsets), _ptr(n_bytes), _ptr(out["flags"]), _ptr(out["overall"]),
+                   _ptr(out["bit_alloc"]), _ptr(out["lines"]), _ptr(out["blocks"]), _ptr(out["pcm"]),
+                   _ptr(out["status"]), self._stream())
+        return out
 
     # ------------------------------------------- function-level entry points
     def window(self, kind, x):

@@ -222,12 +222,12 @@ def parse_header(data):
 
 
 def decode_stream(data):
-    """Whole scalar-path .pac (bytes) -> int16 [n, nCh], batched on the GPU: what
+    """Whole .pac (bytes; scalar, gain-shape or gain-shape + SBR) -> int16 [n, nCh], batched on the GPU: what
     the reference's decode loop (coder/pacfile.py:745-757) writes as PCM."""
     import torch
     cp, pos = parse_header(data)
-    if cp.useVQ or cp.useSBR:
-        raise NotImplementedError("the GPU decoder handles scalar-mantissa streams (useVQ/useSBR False)")
+    if cp.useSBR and not cp.useVQ:
+        raise NotImplementedError("scalar-mantissa SBR streams are not produced by the reference's driver")
     enc = context.encoder_for_params(cp)
     offs, sizes = [], []
     while pos < len(data):                                # the '<L nBytes' chain is sequential by nature
@@ -238,6 +238,9 @@ def decode_stream(data):
     if len(offs) % cp.nChannels:
         raise RuntimeError("Only read a partial block of coded PACFile data")
     body = torch.frombuffer(bytearray(data) + bytearray(8), dtype=torch.uint8).to(enc.device)
-    codes = enc.unpack(body, torch.tensor(sizes, dtype=torch.int32, device=enc.device),
-                       torch.tensor(offs, dtype=torch.int64, device=enc.device))
+    sizes_t = torch.tensor(sizes, dtype=torch.int32, device=enc.device)
+    offs_t = torch.tensor(offs, dtype=torch.int64, device=enc.device)
+    if cp.useVQ:
+        return enc.decode_vq(body, sizes_t, cp.nChannels, offsets=offs_t)["pcm"].cpu().numpy()
+    codes = enc.unpack(body, sizes_t, offs_t)
     return enc.decode(codes, cp.nChannels).cpu().numpy()

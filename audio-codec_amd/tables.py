@@ -98,3 +98,12 @@ def half_log2(l_max):
 def log_mu1(mu=255):
     """np.log(1 + mu) of mu_law_fn, coder/gain_shape_quantize.py:294-295."""
     return float(np.log(1 + mu))
+
+
+def sbr_gauss(sigma=200, truncate=4.0):
+    """Weights of scipy.ndimage.gaussian_filter1d(x, sigma) as Decode_SBR calls it
+    (coder/codec.py:147): exp(-0.5 (j/sigma)^2), j = -r..r, over their sum."""
+    r = int(truncate * float(sigma) + 0.5)
+    j = np.arange(-r, r + 1)
+    w = np.exp(-0.5 / (sigma * sigma) * j ** 2)
+    return w / w.sum(), r

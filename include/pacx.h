@@ -132,6 +132,10 @@ typedef struct pacx_config {
     int32_t use_sbr;
     const double *half_log2;        /* optional [max band lines + 1]: 0.5*np.log2(L) */
     double log_mu1;                 /* np.log(256.0) of mu_law_fn; 0 = compute       */
+    /* decode side of an SBR file (coder/codec.py:147, 163-164), optional: */
+    const double *sbr_gauss;        /* [2r+1] normalised weights of gaussian_filter1d(sigma=200) */
+    int32_t sbr_gauss_radius;       /* r = int(4*200 + 0.5) = 800                    */
+    const double *line_freq_long;   /* [n_lines_long] (k + 1/2) * sampleRate/(2*n_lines_long)   */
 } pacx_config;
 
 /* one written field of a gain-shape coded band (see pacx_encode_vq_batch) */
@@ -364,6 +368,28 @@ int pacx_decode_batch(pacx_handle *h, int64_t n_blocks, int n_channels, const ui
                       const int32_t *overall_scale, const int32_t *scale_factor,
                       const int32_t *bit_alloc, const int32_t *mantissa, double *blocks,
                       int16_t *pcm, void *stream);
+
+/*
+ * Decode of gain-shape coded channel-blocks (handle created with use_vq), from
+ * payload to PCM:
+ *   PACFile.ReadDataBlock / getDecodedBlock   coder/pacfile.py:177-298 (useVQ branch)
+ *   PACFile.Decode routing                    coder/pacfile.py:645-668
+ *   codec.Decode with useVQ                   coder/codec.py:47-92
+ *   codec.Decode_SBR                          coder/codec.py:95-222 (incl. the SciPy
+ *                                             gaussian_filter1d / interp1d calls)
+ *   dequantize_gain_shape, split_band_decode, dequantize_pvq,
+ *   decode_pvq_vector, inv_mu_law_fn          coder/gain_shape_quantize.py:127-176, 259-272,
+ *                                             298-299, 411-473, 515-541
+ * Payload addressing as pacx_unpack_batch.  Outputs: cf_flags uint8 [n_cf],
+ * overall_scale int32 [n_cf][8], bit_alloc int32 [n_cf][band_stride], status
+ * uint32 [n_cf]; optional lines float64 [n_cf][n_lines_long] (the MDCT lines
+ * after SBR reconstruction, BEFORE the division by 2^overallScale), blocks and
+ * pcm as pacx_decode_batch.
+ */
+int pacx_decode_vq_batch(pacx_handle *h, int64_t n_blocks, int n_channels, const uint8_t *payload,
+                         int payload_stride, const int64_t *offsets, const int32_t *n_bytes,
+                         uint8_t *cf_flags, int32_t *overall_scale, int32_t *bit_alloc, double *lines,
+                         double *blocks, int16_t *pcm, uint32_t *status, void *stream);
 
 #ifdef __cplusplus
 }

@@ -123,3 +123,77 @@ def test_whole_file(A, key):
            if zlib.crc32(struct.pack("<L", len(b)) + b) != int(crcs[i])]
     allowed = set(rec["blocks_differing_from_committed"])
     assert set(bad) <= allowed, f"{len(bad)} blocks differ: {bad[:12]}"
+
+
+# ------------------------------------------------------------------ decode side
+@pytest.mark.parametrize("name", EXCERPTS)
+@pytest.mark.parametrize("kbps", [128, 96])
+def test_decode_excerpt_vs_reference_decoder(A, name, kbps):
+    """pacx_decode_vq_batch on the reference's .pac bytes against the PCM the
+    reference's own decoder produced from them (bit-exact int16)."""
+    gold = np.load(os.path.join(GOLDEN, f"excerpt_vq_{name}.npz"))
+    want = np.load(os.path.join(GOLDEN, f"decoded_vq_{name}.npz"))[f"pcm_vq{kbps}"]
+    got = A.pacfile.decode_stream(bytes(gold[f"pac_vq{kbps}"]))
+    assert got.shape == want.shape
+    bad = np.nonzero(np.any(got != want, axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} samples differ, first at {bad[:5]}, max |d| " \
+                          f"{np.max(np.abs(got.astype(int) - want.astype(int)))}"
+
+
+def test_decode_lines_vs_oracle(A):
+    """MDCT lines out of k_vq_dec / k_sbr_recon against the oracle's, block by block."""
+    import struct as st
+    import torch
+    from oracle import pac_oracle as po, pac_oracle_vq as pv
+    gold = np.load(os.path.join(GOLDEN, "excerpt_vq_harpsichord.npz"))
+    for kbps in (128, 96):
+        data = bytes(gold[f"pac_vq{kbps}"])
+        cp, pos = A.pacfile.parse_header(data)
+        enc = A.context.encoder_for_params(cp)
+        offs, sizes = [], []
+        while pos < len(data):
+            n = int.from_bytes(data[pos:pos + 4], "little")
+            offs.append(pos + 4)
+            sizes.append(n)
+            pos += 4 + n
+        body = torch.frombuffer(bytearray(data) + bytearray(8), dtype=torch.uint8).to(enc.device)
+        out = enc.decode_vq(body, torch.tensor(sizes, dtype=torch.int32, device=enc.device), cp.nChannels,
+                            offsets=torch.tensor(offs, dtype=torch.int64, device=enc.device),
+                            want_lines=True, want_pcm=False)
+        assert not np.any(out["status"].cpu().numpy() & A._lib.ST_VQ_UNDEFINED)
+        lines = out["lines"].cpu().numpy()
+        fl = out["flags"].cpu().numpy()
+        p = po.make_params(cp.sampleRate, cp.nChannels, 128)
+        p.useVQ, p.useSBR = True, bool(cp.useSBR)
+        p.omittedBands = list(po.omitted_bands(p.sfBands)) if p.useSBR else []
+        checked = 0
+        for i in range(0, len(offs), 3):
+            if fl[i] & 2:
+                continue
+            br = po.BitReader(data[offs[i]:offs[i] + sizes[i]] + b"\0" * 8)
+            br.get(3)
+            overall = br.get(4)
+            alloc = [a + 1 if a else 0 for a in (br.get(12) for _ in range(p.sfBands.nBands))]
+            sbr = bool(p.useSBR and np.any(np.array(alloc)[np.array(p.omittedBands, dtype=int)] != 0))
+            want = pv.decode_lines_vq(br, p, alloc, False, sbr)
+            if sbr:
+                want = pv.sbr_reconstruct(want, p)
+            scale = max(np.max(np.abs(want)), 1e-300)
+            assert np.max(np.abs(lines[i] - want)) <= 1e-12 * scale, (kbps, i)
+            checked += 1
+        assert checked >= 10
+
+
+@pytest.mark.parametrize("key", ["castanet:128", "castanet:96", "harpsichord:128", "harpsichord:96",
+                                 "spmg:128", "spmg:96"])
+def test_whole_file_round_trip_matches_committed_wav(A, key):
+    """GPU encode -> GPU decode of a whole test WAV in the shipped configuration
+    gives the PCM of the decoded WAV the reference's author committed
+    (test_decoded_full/<wav>_<rate>.wav)."""
+    name, kbps = key.split(":")
+    rec = json.load(open(os.path.join(GOLDEN, "vqwav.json")))[key]
+    full = np.load(os.path.join(GOLDEN, f"full_{name}.npz"))
+    pac = A.pacfile.encode_stream(full["pcm"], int(full["sr"]), int(kbps), block_switching=True,
+                                  header_samples=int(full["declared"]), use_vq=True, use_sbr=int(kbps) < 128)
+    pcm = A.pacfile.decode_stream(pac)[:rec["n_samples"]]
+    assert hashlib.sha256(np.ascontiguousarray(pcm).astype("<i2").tobytes()).hexdigest() == rec["pcm_sha256"]
