@@ -1,7 +1,8 @@
-"""codec.py mirror: Encode / EncodeSingleChannel / getCorrectWindow with the
-reference's signatures and return types (coder/codec.py:30-44, 225-380), the
-arithmetic done by pacx_encode_batch on the GPU.  Scalar-mantissa path
-(useVQ False, useSBR False)."""
+"""codec.py mirror: Encode / Encode_SBR / EncodeSingleChannel / getCorrectWindow /
+Decode with the reference's signatures and return types (coder/codec.py:30-44,
+225-555), the arithmetic done on the GPU: pacx_encode_batch for scalar
+mantissas, pacx_encode_vq_batch for the gain-shape coder (codingParams.useVQ),
+Encode_SBR for the long blocks of an SBR file."""
 import numpy as np
 
 from . import _lib, context, window
@@ -54,8 +55,10 @@ def Encode(data, codingParams, lastTrans=False, curTrans=False, nextTrans=False)
     2*nMDCTLines samples.  Returns (scaleFactor, bitAlloc, mantissa,
     overallScaleFactor), each a list over channels."""
     import torch
-    if getattr(codingParams, "useVQ", False) or getattr(codingParams, "useSBR", False):
-        raise NotImplementedError("the GPU path covers the scalar-mantissa coder (useVQ/useSBR False)")
+    if getattr(codingParams, "useVQ", False):
+        return _encode_vq(data, codingParams, lastTrans, curTrans, nextTrans, sbr=False)
+    if getattr(codingParams, "useSBR", False):
+        raise NotImplementedError("scalar-mantissa SBR is not produced by the reference's driver")
     enc = context.encoder_for_params(codingParams)
     n_ch = codingParams.nChannels
     n = 2 * codingParams.nMDCTLines
@@ -81,6 +84,74 @@ def Encode(data, codingParams, lastTrans=False, curTrans=False, nextTrans=False)
     return res
 
 
+def _frame_block(data, n_ch, n, curTrans):
+    blk = np.zeros((1, n_ch, 2048))
+    if curTrans:
+        if n != 256:
+            raise ValueError("a short block is 256 samples (nMDCTLines 128)")
+        for ch in range(n_ch):
+            blk[0, ch, 448:448 + 256] = data[ch]
+    else:
+        if n != 2048:
+            raise NotImplementedError("long blocks are 2048 samples (nMDCTLines 1024)")
+        for ch in range(n_ch):
+            blk[0, ch] = data[ch]
+    return blk
+
+
+def _encode_vq(data, codingParams, lastTrans, curTrans, nextTrans, sbr):
+    """useVQ flavour: (bitAlloc, indices, idx_bits, overallScale), each a list
+    over channels; indices / idx_bits hold one list per coded band
+    (coder/codec.py:239-246, 330-360; Encode_SBR :395-410, 493-531)."""
+    import torch
+    cp = codingParams
+    enc = context.encoder(cp.sampleRate, cp.targetBitsPerSample, cp.nScaleBits, cp.nMantSizeBits,
+                          getattr(cp, "sfBands", None), getattr(cp, "sfBandsShort", None),
+                          use_vq=True, use_sbr=bool(sbr))
+    n_ch = cp.nChannels
+    blk = _frame_block(data, n_ch, 2 * cp.nMDCTLines, curTrans)
+    pcm = PcmView.frames(torch.as_tensor(blk, device=enc.device))
+    out = enc.encode_vq(pcm, [(bool(lastTrans), bool(curTrans), bool(nextTrans))], want_entries=True)
+    if int(out["status"].max().item()) & _lib.ST_VQ_UNDEFINED:
+        raise RuntimeError("gain-shape coder reached a case the reference cannot code either")
+    ba_all = out["bit_alloc"].cpu().numpy()
+    ov = out["overall"].cpu().numpy()
+    ent = out["entries"].cpu().numpy()
+    cnt = out["entry_count"].cpu().numpy()
+    nb = (enc.sfBandsShort if curTrans else enc.sfBands).nBands
+    res = ([], [], [], [])
+    for ch in range(n_ch):
+        ba = ba_all[ch, :nb].astype(np.int64)
+        idx, bits = [], []
+        for b in range(nb):
+            if not ba[b]:
+                continue
+            n = int(cnt[ch, 0, b])
+            if n > ent.shape[3]:
+                raise RuntimeError("more gain-shape fields in a band than the entry buffer holds")
+            words = ent[ch, 0, b, :n]
+            widths = (words[:, 1] & 0xFFFFFFFF).astype(np.int64)
+            if np.any(widths > 64):
+                raise NotImplementedError("gain index wider than 64 bits")
+            idx.append([int(np.uint64(v)) for v in words[:, 0].astype(np.uint64)])
+            bits.append([int(w) for w in widths])
+        for dst, v in zip(res, (ba, idx, bits, int(ov[ch, 0]))):
+            dst.append(v)
+    return res
+
+
+def Encode_SBR(data, codingParams, lastTrans=False, curTrans=False, nextTrans=False):
+    """coder/codec.py:383-423 (useVQ): long blocks of an SBR file.  Unlike the
+    reference this does not modify codingParams.sfBands.nLines (BitAlloc_SBR's
+    in-place write, coder/bitalloc.py:141-143): the handle counts the omitted
+    bands as one line itself."""
+    if not getattr(codingParams, "useVQ", False):
+        raise NotImplementedError("scalar-mantissa SBR is not produced by the reference's driver")
+    if curTrans:
+        raise ValueError("Encode_SBR codes long blocks (coder/pacfile.py:639-643)")
+    return _encode_vq(data, codingParams, lastTrans, curTrans, nextTrans, sbr=True)
+
+
 def EncodeSingleChannel(data, codingParams, lastTrans=False, curTrans=False, nextTrans=False):
     """coder/codec.py:266-380 for one channel."""
     one = type("P", (), {})()
@@ -97,7 +168,8 @@ def Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams
     `mantissa` is line-indexed, as PACFile.getDecodedBlock builds it."""
     import torch
     if getattr(codingParams, "useVQ", False):
-        raise NotImplementedError("the GPU decoder handles scalar-mantissa streams (useVQ False)")
+        raise NotImplementedError("gain-shape blocks are decoded from their payload: use "
+                                  "PACFile.ReadDataBlock / pacfile.decode_stream (pacx_decode_vq_batch)")
     enc = context.encoder_for_params(codingParams)
     n_lines = codingParams.nMDCTLines
     if n_lines not in (1024, 128) or bool(curTrans) != (n_lines == 128):

@@ -1,5 +1,6 @@
 """pacfile.py mirror (coder/pacfile.py): the .pac block API in front of the GPU
-path, scalar-mantissa coder (useVQ False, useSBR False).
+path: scalar mantissas, or the gain-shape coder with or without SBR
+(codingParams.useVQ / useSBR, the reference driver's own settings).
 
   PACFile.WriteFileHeader / WriteDataBlock / Close / Encode keep the
   reference's signatures and write the same bytes (one GPU call per block:
@@ -22,7 +23,7 @@ BYTESIZE = 8
 
 
 def omitted_bands(sfBands, factor=2):
-    """coder/sbr.py:6-9 (only recorded in codingParams; SBR itself is not accelerated)."""
+    """coder/sbr.py:6-9."""
     return np.where(sfBands.lowerLine >= sfBands.upperLine[-1] // factor)[0]
 
 
@@ -45,8 +46,8 @@ class PACFile(AudioFile):
     tag = b"PAC "
 
     def WriteFileHeader(self, codingParams):
-        if getattr(codingParams, "useVQ", False) or getattr(codingParams, "useSBR", False):
-            raise NotImplementedError("the GPU path writes scalar-mantissa .pac files (useVQ/useSBR False)")
+        if getattr(codingParams, "useSBR", False) and not getattr(codingParams, "useVQ", False):
+            raise NotImplementedError("scalar-mantissa SBR is not produced by the reference's driver")
         self.fp.write(header_bytes(codingParams))
         codingParams.priorBlock = [np.zeros(codingParams.nMDCTLines, dtype=np.float64)
                                    for _ in range(codingParams.nChannels)]
@@ -60,8 +61,12 @@ class PACFile(AudioFile):
         cp.priorBlock = data
         pcm = PcmView.frames(torch.as_tensor(blk[None], device=enc.device))
         flags = [(bool(lastTrans), bool(curTrans), bool(nextTrans))]
-        out = enc.encode(pcm, flags)
-        payload, n_bytes = enc.pack(out, cp.nChannels)
+        if getattr(cp, "useVQ", False):
+            out = enc.encode_vq(pcm, flags)
+            payload, n_bytes = out["payload"], out["n_bytes"]
+        else:
+            out = enc.encode(pcm, flags)
+            payload, n_bytes = enc.pack(out, cp.nChannels)
         n_bytes = n_bytes.cpu().numpy()
         if not n_bytes.any():
             return                                  # hop dropped (coder/pacfile.py:530-533)
@@ -79,6 +84,8 @@ class PACFile(AudioFile):
 
     def Encode(self, data, codingParams, lastTrans=False, curTrans=False, nextTrans=False):
         """coder/pacfile.py:627-643."""
+        if getattr(codingParams, "useSBR", False) and not curTrans:
+            return codec.Encode_SBR(data, codingParams, lastTrans, curTrans, nextTrans)
         return codec.Encode(data, codingParams, lastTrans, curTrans, nextTrans)
 
     def Decode(self, scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,
@@ -93,7 +100,7 @@ class PACFile(AudioFile):
         n_bands = int.from_bytes(head[-4:], "little")
         head += self.fp.read(2 * n_bands)
         cp, _ = parse_header(head)
-        cp.omittedBands = []
+        cp.omittedBands = omitted_bands(cp.sfBands) if cp.useSBR else []
         cp.overlapAndAdd = [np.zeros(cp.nMDCTLines, dtype=np.float64) for _ in range(cp.nChannels)]
         return cp
 
@@ -121,9 +128,13 @@ class PACFile(AudioFile):
         buf = np.zeros((cp.nChannels, slot), dtype=np.uint8)
         for ch, blob in enumerate(payloads):
             buf[ch, :len(blob)] = np.frombuffer(blob, dtype=np.uint8)
-        codes = enc.unpack(torch.as_tensor(buf, device=enc.device),
-                           torch.tensor([len(b) for b in payloads], dtype=torch.int32, device=enc.device))
-        blocks = enc.decode(codes, cp.nChannels, want_blocks=True, want_pcm=False).cpu().numpy()
+        sizes = torch.tensor([len(b) for b in payloads], dtype=torch.int32, device=enc.device)
+        if getattr(cp, "useVQ", False):
+            blocks = enc.decode_vq(torch.as_tensor(buf, device=enc.device), sizes, cp.nChannels,
+                                   want_blocks=True, want_pcm=False)["blocks"].cpu().numpy()
+        else:
+            codes = enc.unpack(torch.as_tensor(buf, device=enc.device), sizes)
+            blocks = enc.decode(codes, cp.nChannels, want_blocks=True, want_pcm=False).cpu().numpy()
         data = []
         for ch in range(cp.nChannels):
             data.append(np.add(cp.overlapAndAdd[ch], blocks[ch][:cp.nMDCTLines]))

@@ -197,3 +197,65 @@ def test_whole_file_round_trip_matches_committed_wav(A, key):
                                   header_samples=int(full["declared"]), use_vq=True, use_sbr=int(kbps) < 128)
     pcm = A.pacfile.decode_stream(pac)[:rec["n_samples"]]
     assert hashlib.sha256(np.ascontiguousarray(pcm).astype("<i2").tobytes()).hexdigest() == rec["pcm_sha256"]
+
+
+# ----------------------------------------------------------- reference-style API
+def test_codec_encode_vq_mirror_vs_oracle(A):
+    """codec.Encode / Encode_SBR with useVQ: (bitAlloc, indices, idx_bits,
+    overallScale) lists as the reference returns them."""
+    from oracle import pac_oracle as po, pac_oracle_vq as pv
+    ex = np.load(os.path.join(GOLDEN, "excerpt_harpsichord.npz"))
+    sr = int(ex["sr"])
+    pcm = ex["pcm"][:3 * 1024]
+    data = [po.pcm16_to_fraction(pcm[1024:3 * 1024, ch]) for ch in range(2)]
+    for kbps, fn_name in ((128, "Encode"), (96, "Encode_SBR")):
+        p = pv.make_params_vq(sr, 2, kbps)
+        cp = A.audiofile.CodingParams()
+        cp.sampleRate, cp.nChannels, cp.nMDCTLines = sr, 2, 1024
+        cp.nScaleBits, cp.nMantSizeBits = 4, 12
+        cp.targetBitsPerSample = kbps / (sr / 1000)
+        cp.useVQ, cp.useSBR = True, kbps < 128
+        ba, idx, bits, ov = getattr(A.codec, fn_name)(data, cp)
+        for ch in range(2):
+            want = (pv.encode_channel_sbr_vq if p.useSBR else pv.encode_channel_vq)(data[ch].copy(), p)
+            assert np.array_equal(ba[ch], want[0])
+            assert idx[ch] == [[int(v) for v in band] for band in want[1]]
+            assert bits[ch] == [[int(v) for v in band] for band in want[2]]
+            assert ov[ch] == want[3]
+
+
+def test_pacfile_block_api_vq_round_trip(A, tmp_path):
+    """PACFile.WriteDataBlock / ReadDataBlock with useVQ + useSBR, block by block,
+    against the batched stream encode and the reference decoder's PCM."""
+    ex = np.load(os.path.join(GOLDEN, "excerpt_spmg.npz"))
+    gold = np.load(os.path.join(GOLDEN, "excerpt_vq_spmg.npz"))
+    sr, hops = int(ex["sr"]), int(gold["hops"])
+    pcm = ex["pcm"][:hops * 1024]
+    flags = gold["flags_vq96"]
+    path = str(tmp_path / "out.pac")
+    cp = A.audiofile.CodingParams()
+    cp.sampleRate, cp.nChannels, cp.numSamples = sr, 2, len(pcm)
+    cp.nMDCTLines = cp.nSamplesPerBlock = 1024
+    cp.nScaleBits, cp.nMantSizeBits = 4, 12
+    cp.targetBitsPerSample = 96 / (sr / 1000)
+    cp.useVQ, cp.useSBR = True, True
+    f = A.pacfile.PACFile(path)
+    f.OpenForWriting(cp)
+    for h in range(hops + 1):                     # the driver writes the last hop twice
+        hh = min(h, hops - 1)
+        data = [A.pcmfile.codes_to_fraction(pcm[hh * 1024:(hh + 1) * 1024, ch]) for ch in range(2)]
+        f.WriteDataBlock(data, cp, *[bool(v) for v in flags[h]])
+    f.Close(cp)
+    got = open(path, "rb").read()
+    assert got == bytes(gold["pac_vq96"]), describe_diff(got, bytes(gold["pac_vq96"]))
+    want_pcm = np.load(os.path.join(GOLDEN, "decoded_vq_spmg.npz"))["pcm_vq96"]
+    g = A.pacfile.PACFile(path)
+    cp2 = g.OpenForReading()
+    out = []
+    while True:
+        d = g.ReadDataBlock(cp2)
+        if not d:
+            break
+        out.append(np.stack([A.pcmfile.fraction_to_codes(c) for c in d], axis=1))
+    g.Close(cp2)
+    assert np.array_equal(np.concatenate(out), want_pcm)
