@@ -75,35 +75,32 @@ __device__ __forceinline__ PacxPeak make_peak(double left, double centre, int f,
 }
 
 /* ------------------------------------------------------------------ long */
+/* LDS of one wave: raw (until the FFT inputs are in registers) then inten share
+ * one region; the FFT exchange tile then the packed spectrum Z share another */
+template <int DT> struct SideLongLds {
+    typedef typename PcmStage<DT>::elem E;
+    static constexpr int RAW_BYTES = (int)sizeof(E) * PACX_N_LONG;
+    static constexpr int B_BYTES = RAW_BYTES > 1032 * 8 ? RAW_BYTES : 1032 * 8;
+    static constexpr int BYTES = 1024 * (int)sizeof(cplx) + B_BYTES;
+};
+
+/* one long channel-frame by one wave; every barrier is wave-local (the wave
+ * owns its LDS slice), so waves of a persistent workgroup run independently */
 template <int DT, bool FAST>
-__global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
-                                                 const uint8_t *__restrict__ flags, long long n_cf,
-                                                 int skip_cur, PacxPeak *__restrict__ peaks,
-                                                 int32_t *__restrict__ n_peaks,
-                                                 int32_t *__restrict__ n_kept_out,
-                                                 double *__restrict__ sbr_mean,
-                                                 int32_t *__restrict__ sbr_overall)
+__device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcmView &in, long long cf,
+                                              cplx *Z, char *regB, int lane,
+                                              PacxPeak *__restrict__ peaks, int32_t *__restrict__ n_peaks,
+                                              int32_t *__restrict__ n_kept_out,
+                                              double *__restrict__ sbr_mean,
+                                              int32_t *__restrict__ sbr_overall)
 {
     typedef typename PcmStage<DT>::elem E;
-    /* LDS lifetimes: raw (until the FFT inputs are in registers) then inten share
-       one region; the FFT exchange tile then the packed spectrum Z share another */
-    constexpr int RAW_BYTES = (int)sizeof(E) * PACX_N_LONG;
-    constexpr int B_BYTES = RAW_BYTES > 1032 * 8 ? RAW_BYTES : 1032 * 8;
-    __shared__ __attribute__((aligned(16))) cplx Z[1024];
-    __shared__ __attribute__((aligned(16))) char regB[B_BYTES];
     cplx *tile = Z;
     double *inten = (double *)regB;
     E *raw = (E *)regB;
-    const int lane = threadIdx.x;
-    const long long cf = blockIdx.x;
-    if (cf >= n_cf)
-        return;
-    const unsigned fl = flags ? flags[cf / in.n_ch] : 0u;
-    if (skip_cur && (fl & 2u))
-        return;
 
     stage_samples<DT, FAST>(raw, in, cf, 0, PACX_N_LONG, lane);
-    __syncthreads();
+    wave_lds_fence();
 
     const double *__restrict__ hw = T.hann_long, *__restrict__ hwp = T.hann_long_pcm;
     cplx ev[8], od[8];
@@ -113,10 +110,10 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
         ev[n1] = make_double2(hann_sample<DT>(raw, i, hw, hwp), hann_sample<DT>(raw, i + 1, hw, hwp));
         od[n1] = make_double2(hann_sample<DT>(raw, i + 2, hw, hwp), hann_sample<DT>(raw, i + 3, hw, hwp));
     }
-    __syncthreads();                  /* raw fully consumed before anything reuses LDS */
+    wave_lds_fence();                  /* raw fully consumed before anything reuses LDS */
     fft512(ev, tile, T.w512, lane);
     fft512(od, tile, T.w512, lane);
-    __syncthreads();                  /* tile dead: Z takes its place */
+    wave_lds_fence();                  /* tile dead: Z takes its place */
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) {
         const int k = fft512_out_index(lane, k3);
@@ -124,15 +121,15 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
         Z[k] = c_add(ev[k3], t);
         Z[k + 512] = c_sub(ev[k3], t);
     }
-    __syncthreads();
+    wave_lds_fence();
     for (int i = lane; i <= 1024; i += 64)
         inten[i] = bin_intensity(Z, i, 1024, T.w2048[i], T.norm_long);
-    __syncthreads();
+    wave_lds_fence();
 
     /* pass 1: strict local maxima (coder/psychoac.py:312-317), their bin numbers
        compacted in ascending order into LDS (ballot + prefix popcount) */
     unsigned short *idx = (unsigned short *)Z;          /* Z is dead once inten is complete */
-    __syncthreads();
+    wave_lds_fence();
     int count = 0;
     for (int base = 0; base <= 1024; base += 64) {
         const int i = base + lane;
@@ -146,7 +143,7 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
             idx[count + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
         count += __popcll(m);
     }
-    __syncthreads();
+    wave_lds_fence();
     /* pass 2: one masker per lane, 64 at a time (log10 + two atan each); Bark and
        SPL go to LDS for the pruning scans */
     double *zs = (double *)Z + 256;                       /* [512] after the index list */
@@ -157,7 +154,7 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
         zs[p] = q.z;
         ss[p] = q.spl;
     }
-    __syncthreads();
+    wave_lds_fence();
     /* pass 3: drop maskers that cannot matter.  A masker p with S_p <= 40 dB has
        the 27 dB/Bark tent S_p - 16 - 27 max(|z - z_p| - 0.5, 0); any other masker q
        has a tent at least that steep-sided or shallower, so q >= p EVERYWHERE as
@@ -245,17 +242,17 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
        sf(max of both); magnitudes come back from the intensities
        (|X| = sqrt(I/norm), two roundings away from np.abs). */
     if (sbr_mean) {
-        __syncthreads();
+        wave_lds_fence();
         double mx = 0.0;
         for (int i = lane; i <= 1024; i += 64)
             mx = fmax(mx, inten[i]);
         mx = wave_max(mx);
         const int first = T.first_omitted;
         const int lo_all = T.band_lower_long[first];
-        __syncthreads();
+        wave_lds_fence();
         for (int i = lo_all + lane; i < PACX_M_LONG; i += 64)
             inten[i] = sqrt(inten[i] / T.norm_long) / (double)PACX_M_LONG;
-        __syncthreads();
+        wave_lds_fence();
         for (int b = first; b < T.nb_long; ++b) {
             const int cnt = T.band_lines_long[b];
             const double mean = wave_np_sum(inten + T.band_lower_long[b], cnt, lane) / (double)cnt;
@@ -268,6 +265,26 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
                 sbr_overall[cf * PACX_SUB] = sf;
         }
     }
+}
+
+template <int DT, bool FAST>
+__global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
+                                                 const uint8_t *__restrict__ flags, long long n_cf,
+                                                 int skip_cur, PacxPeak *__restrict__ peaks,
+                                                 int32_t *__restrict__ n_peaks,
+                                                 int32_t *__restrict__ n_kept_out,
+                                                 double *__restrict__ sbr_mean,
+                                                 int32_t *__restrict__ sbr_overall)
+{
+    __shared__ __attribute__((aligned(16))) cplx Z[1024];
+    __shared__ __attribute__((aligned(16))) char regB[SideLongLds<DT>::B_BYTES];
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf)
+        return;
+    const unsigned fl = flags ? flags[cf / in.n_ch] : 0u;
+    if (skip_cur && (fl & 2u))
+        return;
+    side_long_one<DT, FAST>(T, in, cf, Z, regB, threadIdx.x, peaks, n_peaks, n_kept_out, sbr_mean, sbr_overall);
 }
 
 /* ----------------------------------------------------------------- short */
@@ -538,8 +555,8 @@ static void launch_side(const PacxTables &T, const PacxPcmView &in, const uint8_
 {
     const dim3 grid((unsigned)n_cf), block(64);
     if (!short_blocks || mixed)
-        hipLaunchKernelGGL((k_side_long<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks, n_peaks,
-                           n_kept, sbr_mean, sbr_overall);
+        hipLaunchKernelGGL((k_side_long<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks,
+                           n_peaks, n_kept, sbr_mean, sbr_overall);
     if (short_blocks || mixed)
         hipLaunchKernelGGL((k_side_short<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks, n_peaks, n_kept);
 }

@@ -105,6 +105,9 @@ struct pacx_handle {
     long long ws_blocks_cf;           /* decode: capacity of ws_blocks          */
     double *ws_blocks;                /* [cf][2048] blocks before overlap-add   */
     /* gain-shape coder (use_vq) */
+    /* fork-join: the side chain (VALU/latency bound) runs beside the MDCT (HBM bound) */
+    hipStream_t side_stream;
+    hipEvent_t ev_fork, ev_join;
     std::vector<char> vq_view;        /* VqView of k_vq.hip (device pointers)   */
     std::vector<char> vqdec_view;     /* VqDecView of k_vq_dec.hip              */
     long long ws_dec_cf;              /* capacity of the VQ decode buffers      */
@@ -225,6 +228,9 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->ws_blocks_cf = 0;
     h->ws_blocks = nullptr;
     h->ws_sbr_mean = nullptr;
+    h->side_stream = nullptr;
+    h->ev_fork = nullptr;
+    h->ev_join = nullptr;
     h->ws_dec_cf = 0;
     h->ws_dec_lines = nullptr;
     h->ws_dec_sbr = nullptr;
@@ -243,6 +249,13 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
             delete h;
             return PACX_E_HIP;
         }
+    }
+    if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        g_create_err = "pacx_create: could not create the side stream / events";
+        pacx_destroy(h);
+        return PACX_E_HIP;
     }
     {
         hipDeviceProp_t prop;
@@ -465,6 +478,14 @@ extern "C" void pacx_destroy(pacx_handle *h)
     if (!h)
         return;
     (void)hipSetDevice(h->device);
+    if (h->side_stream) {
+        (void)hipStreamSynchronize(h->side_stream);
+        (void)hipStreamDestroy(h->side_stream);
+    }
+    if (h->ev_fork)
+        (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join)
+        (void)hipEventDestroy(h->ev_join);
     free_ws(h);
     if (h->ws_blocks)
         (void)hipFree(h->ws_blocks);
@@ -661,6 +682,12 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
     const int n_ch = in->n_channels;
     HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
     HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
+    /* fork: the side chain only reads the PCM, so it runs on its own stream next to the MDCT */
+    HIP_TRY(h, hipEventRecord(h->ev_fork, st));
+    HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+    pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
+                     nullptr, nullptr, h->side_stream);
+    HIP_TRY(h, hipEventRecord(h->ev_join, h->side_stream));
     if (fast) {
         /* long frames: persistent roofline kernel; short (CUR) frames: k_mdct_short */
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, h->n_cu, st);
@@ -671,8 +698,7 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
         pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
                          PACX_SUB, status, st);
     }
-    pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
-                     nullptr, nullptr, st);
+    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));       /* join */
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
                      nullptr, h->n_cu, st);
     pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_smr, bit_alloc, status, st);
