@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="stereo frames per GPU and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mdct-launches", type=int, default=50)
+    ap.add_argument("--graph", action="store_true",
+                    help="replay a captured hipGraph of the step instead of launching its kernels one by one "
+                         "(measured slower on ROCm 7.2: 0.408 vs 0.397 ms/step -- the queue is GPU-bound)")
     ap.add_argument("--workload", choices=["scalar128", "vq128", "vq96"], default="scalar128",
                     help="scalar128 = BASELINE configs[1] (the headline); vq128 / vq96 = the gain-shape "
                          "coder of configs[3] (vq96 with SBR) on the same synthetic stream")
@@ -107,7 +110,7 @@ def main():
     if vq_kbps:
         vq_out = {k: out[k] for k in ("overall", "bit_alloc", "status", "payload", "n_bytes")}
 
-    def step():
+    def device_step():
         if vq_kbps:
             enc.encode_vq(view, None, vq_out)
         else:
@@ -115,6 +118,27 @@ def main():
             enc.pack(out, N_CH, out)
         enc._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(out["payload"]), _ptr(out["n_bytes"]),
                   _ptr(body), ctypes.c_int64(cap), _ptr(total), enc._stream())
+
+    # optional: the ~15 kernel launches of a step captured once into a hipGraph and replayed
+    graph = None
+    if args.graph:
+        device_step()
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                device_step()
+            graph = g
+        except Exception as e:                      # capture not possible: plain launches
+            print(f"bench: hipGraph capture failed ({e}); launching kernels directly", file=sys.stderr)
+            graph = None
+        torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            device_step()
         if world > 1:
             A.dist.gather_bitstream(body, total.item())
 
@@ -193,6 +217,7 @@ def main():
                                    "int16 PCM resident in HBM; step = encode + "
                                    ".pac bit packing + body assembly" + (" + RCCL gather to rank 0" if world > 1 else ""),
                        "stereo_frames_per_s": world * n_frames * args.steps / dt,
+                       "launch": "hipGraph replay of the captured step" if graph is not None else "direct launches",
                        "sharding": f"{world} x frame-range shards, no data-path collective"},
             "roofline": {"kernel": "k_mdct_long_v2 (window + MDCT, int16 in, float64 lines out)",
                          "bound": "hbm", "achieved": mdct_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
