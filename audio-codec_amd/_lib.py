@@ -84,6 +84,7 @@ SIGNATURES = {
     "pacx_bitalloc_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, _P]),
     "pacx_quantize_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int, _P, _P, _P]),
     "pacx_encode_batch": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, _P, _P, _P, _P, _P, _P]),
+    "pacx_encode_pack_batch": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pacx_encode_vq_batch": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, _P, _P, _P, _P, _P, _P, _P,
                                             ctypes.c_int32, _P]),
     "pacx_pack_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

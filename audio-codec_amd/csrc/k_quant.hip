@@ -37,40 +37,14 @@ __device__ __forceinline__ int half_sum_i(int v)
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
-                                                long long n_cf, int short_blocks, int mixed,
-                                                const double *__restrict__ smr,
-                                                int32_t *__restrict__ bit_alloc,
-                                                uint32_t *__restrict__ status)
+/* BitAlloc of one (sub-)block on one 32-lane half wave (lane l = band l).  Both
+ * halves of the wave must call this together (a half without work passes
+ * alive = false). */
+__device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, int nl, double budget,
+                                              int max_mant, double *c, int half, int l, int &bits_out,
+                                              int &cap_out)
 {
-    __shared__ double cp[2][32];
-    const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
-    const bool dense = !short_blocks && !(mixed && flags);
-    const long long unit = (long long)blockIdx.x * 2 + half;
-    const long long cf = dense ? unit : unit / PACX_SUB;
-    const int sb = dense ? 0 : (int)(unit % PACX_SUB);
-    bool alive = cf < n_cf;
-    const unsigned fl = (alive && flags) ? flags[cf / n_ch] : 0u;
-    const bool is_short = mixed ? ((fl & 2u) != 0) : (short_blocks != 0);
-    if (!is_short && sb != 0)
-        alive = false;
-    const int nb = is_short ? T.nb_short : T.nb_long;
-    /* an SBR file counts every omitted band of a long block as one line
-       (BitAlloc_SBR, coder/bitalloc.py:141-143) */
-    const int32_t *__restrict__ n_lines = is_short ? T.band_lines_short
-                                                   : (T.use_sbr ? T.band_lines_long_alloc : T.band_lines_long);
-    const double budget = pacx_bit_budget(T.target_bps, is_short ? PACX_M_SHORT : PACX_M_LONG,
-                                          is_short ? 1 : 0, (fl & 5u) != 0, T.n_scale_bits,
-                                          T.n_mant_size_bits, nb, T.use_vq, T.use_sbr && !is_short);
-    int max_mant = 1 << T.n_mant_size_bits;
-    if (max_mant > 16)
-        max_mant = 16;
-    const long long off = cf * T.band_stride + (is_short ? sb * nb : 0);
-    const bool has = alive && l < nb;
-    const double s = has ? smr[off + l] : 0.0;
-    const int nl = has ? n_lines[l] : 0;
     const unsigned lt_mask = (1u << l) - 1u;
-    double *c = cp[half];
 
     int bits = 0, n_flip = 0, passes = 0, cap = 0;
     unsigned dropped = 0;
@@ -191,6 +165,44 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
             }
         }
     }
+    bits_out = bits;
+    cap_out = cap;
+}
+
+__global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
+                                                long long n_cf, int short_blocks, int mixed, int skip_long,
+                                                const double *__restrict__ smr,
+                                                int32_t *__restrict__ bit_alloc,
+                                                uint32_t *__restrict__ status)
+{
+    __shared__ double cp[2][32];
+    const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
+    const bool dense = !short_blocks && !(mixed && flags);
+    const long long unit = (long long)blockIdx.x * 2 + half;
+    const long long cf = dense ? unit : unit / PACX_SUB;
+    const int sb = dense ? 0 : (int)(unit % PACX_SUB);
+    bool alive = cf < n_cf;
+    const unsigned fl = (alive && flags) ? flags[cf / n_ch] : 0u;
+    const bool is_short = mixed ? ((fl & 2u) != 0) : (short_blocks != 0);
+    if (!is_short && (sb != 0 || skip_long))
+        alive = false;                                   /* long frames may belong to k_tail_long */
+    const int nb = is_short ? T.nb_short : T.nb_long;
+    /* an SBR file counts every omitted band of a long block as one line
+       (BitAlloc_SBR, coder/bitalloc.py:141-143) */
+    const int32_t *__restrict__ n_lines = is_short ? T.band_lines_short
+                                                   : (T.use_sbr ? T.band_lines_long_alloc : T.band_lines_long);
+    const double budget = pacx_bit_budget(T.target_bps, is_short ? PACX_M_SHORT : PACX_M_LONG,
+                                          is_short ? 1 : 0, (fl & 5u) != 0, T.n_scale_bits,
+                                          T.n_mant_size_bits, nb, T.use_vq, T.use_sbr && !is_short);
+    int max_mant = 1 << T.n_mant_size_bits;
+    if (max_mant > 16)
+        max_mant = 16;
+    const long long off = cf * T.band_stride + (is_short ? sb * nb : 0);
+    const bool has = alive && l < nb;
+    const double s = has ? smr[off + l] : 0.0;
+    const int nl = has ? n_lines[l] : 0;
+    int bits = 0, cap = 0;
+    bitalloc_half(alive, has, s, nl, budget, max_mant, cp[half], half, l, bits, cap);
     if (has)
         bit_alloc[off + l] = bits;
     if (alive && cap && status && l == 0)
@@ -203,6 +215,92 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
  * pattern of |x| (non-negative doubles order like integers), so no per-band
  * loop and no dependent global loads; lanes < nBands then turn the maxima into
  * scale factors in parallel. */
+/* Long block: scale factors and mantissas of the 16 consecutive lines each lane
+ * owns.  ba_s[nb] must be filled (and visible) by the caller; on return sf_s[nb]
+ * holds the scale factors, x / band / mant this lane's lines. */
+__device__ __forceinline__ void quantize_long_core(const PacxTables &T, const double *__restrict__ lin,
+                                                   double up, unsigned long long *bmax, const int *ba_s,
+                                                   int *sf_s, int lane, double (&x)[16], uint8_t (&band)[16],
+                                                   int32_t (&mant)[16])
+{
+    constexpr int PER = 16;
+    const int nb = T.nb_long;
+    const int k0 = PER * lane;
+    if (lane < PACX_MAX_BANDS)
+        bmax[lane] = 0ull;
+#pragma unroll
+    for (int j = 0; j < PER; j += 2) {
+        const double2 v = *(const double2 *)(lin + k0 + j);
+        x[j] = v.x * up;
+        x[j + 1] = v.y * up;
+    }
+    {
+        const uint4 b16 = *(const uint4 *)(T.line_band_long + k0);
+        const unsigned w[4] = {b16.x, b16.y, b16.z, b16.w};
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            band[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+    }
+    __syncthreads();
+    /* Each lane owns runs of consecutive lines of one band.  The band maximum of
+       |x| is taken on the bit pattern (non-negative doubles order like unsigned
+       integers) with 32-bit LDS atomics in two rounds -- high words, then low
+       words among the lanes that hold the winning high word.  (64-bit ds_max_u64
+       gave wrong maxima on gfx950 / ROCm 7.2 once in ~1500 bands when several
+       lanes hit one address; 32-bit LDS atomics are used everywhere else too.) */
+    unsigned *hi_w = (unsigned *)bmax;                 /* [nb] high words, then [nb] low words */
+    unsigned *lo_w = hi_w + PACX_MAX_BANDS;
+    {
+        int cur = band[0];
+        double m = 0.0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (band[j] != cur) {
+                atomicMax(&hi_w[cur], (unsigned)__double2hiint(m));
+                cur = band[j];
+                m = 0.0;
+            }
+            m = fmax(m, fabs(x[j]));
+        }
+        atomicMax(&hi_w[cur], (unsigned)__double2hiint(m));
+    }
+    __syncthreads();
+    {
+        int cur = band[0];
+        double m = 0.0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (band[j] != cur) {
+                if ((unsigned)__double2hiint(m) == hi_w[cur])
+                    atomicMax(&lo_w[cur], (unsigned)__double2loint(m));
+                cur = band[j];
+                m = 0.0;
+            }
+            m = fmax(m, fabs(x[j]));
+        }
+        if ((unsigned)__double2hiint(m) == hi_w[cur])
+            atomicMax(&lo_w[cur], (unsigned)__double2loint(m));
+    }
+    __syncthreads();
+    unsigned hw = 0, lw = 0;
+    if (lane < nb) {
+        hw = hi_w[lane];
+        lw = lo_w[lane];
+    }
+    __syncthreads();
+    if (lane < nb) {
+        const double mx = __longlong_as_double((long long)(((unsigned long long)hw << 32) | lw));
+        sf_s[lane] = pacx_scale_factor(mx, T.n_scale_bits, ba_s[lane]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = band[j];
+        const int ba = ba_s[b];
+        mant[j] = ba ? pacx_mantissa(x[j], sf_s[b], T.n_scale_bits, ba) : 0;
+    }
+}
+
 template <int M>
 __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
                                                 long long n_units, int mixed,
@@ -233,6 +331,20 @@ __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__
     const long long loff = cf * PACX_M_LONG + sb * PACX_M_SHORT;
     const int ov = overall[SHORT ? (cf * overall_stride + (overall_stride == 1 ? 0 : sb)) : cf * overall_stride];
     const double up = (double)(1 << ov);            /* mdctLines *= (1 << overallScale) */
+    if constexpr (!SHORT) {
+        if (lane < nb)
+            ba_s[lane] = bit_alloc[boff + lane];
+        double xl[16];
+        uint8_t bandl[16];
+        int32_t mantl[16];
+        quantize_long_core(T, lines + loff, up, bmax, ba_s, sf_s, lane, xl, bandl, mantl);
+        if (lane < nb)
+            scale_factor[boff + lane] = sf_s[lane];
+#pragma unroll
+        for (int j = 0; j < 16; j += 4)
+            *(int4 *)(mantissa + loff + 16 * lane + j) = make_int4(mantl[j], mantl[j + 1], mantl[j + 2], mantl[j + 3]);
+        return;
+    }
     if (lane < PACX_MAX_BANDS)
         bmax[lane] = 0ull;
     if (lane < nb)
@@ -441,7 +553,7 @@ __global__ __launch_bounds__(64) void k_pack(PacxTables T, const uint8_t *__rest
                                             const int32_t *__restrict__ mantissa,
                                             const uint32_t *__restrict__ status,
                                             uint8_t *__restrict__ payload, int payload_stride,
-                                            int32_t *__restrict__ n_bytes)
+                                            int32_t *__restrict__ n_bytes, int only_short)
 {
     __shared__ unsigned words[PACX_PACK_WORDS];
     __shared__ int offs[PACX_MAX_BANDS + 1], ba_s[PACX_MAX_BANDS], lower_s[PACX_MAX_BANDS];
@@ -452,6 +564,8 @@ __global__ __launch_bounds__(64) void k_pack(PacxTables T, const uint8_t *__rest
     const long long f = cf / n_ch;
     const unsigned fl = flags ? flags[f] : 0u;
     const bool is_short = (fl & 2u) != 0;
+    if (only_short && !is_short)
+        return;                                          /* long frames were packed by k_tail_long */
     /* the reference drops the hop for every channel when any channel holds an
        all-zero short sub-block (coder/pacfile.py:530-533) */
     unsigned st = 0;
@@ -486,6 +600,120 @@ __global__ __launch_bounds__(64) void k_pack(PacxTables T, const uint8_t *__rest
     /* size rule of coder/pacfile.py:552-565: body bits + 4, rounded up */
     const int bits = (pos - 3) + 4;
     const int nbytes = (bits + 7) >> 3;
+    unsigned *dst = (unsigned *)(payload + cf * (long long)payload_stride);
+    for (int i = lane; i < (nbytes + 3) / 4; i += 64)
+        dst[i] = __builtin_bswap32(words[i]);
+    if (lane == 0)
+        n_bytes[cf] = nbytes;
+}
+
+/* ------------------------------------------------- fused tail, long blocks */
+/* BitAlloc -> scale factors + mantissas -> payload of one LONG channel-frame in
+ * one wave: the three stages above back to back, the lines read once and the
+ * mantissas packed straight from registers (same arithmetic, same helpers).
+ * Short frames keep the separate kernels. */
+__global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
+                                                 long long n_cf, int mixed, const double *__restrict__ smr,
+                                                 const double *__restrict__ lines,
+                                                 const int32_t *__restrict__ overall,
+                                                 int32_t *__restrict__ bit_alloc,
+                                                 int32_t *__restrict__ scale_factor,
+                                                 int32_t *__restrict__ mantissa, uint32_t *__restrict__ status,
+                                                 uint8_t *__restrict__ payload, int payload_stride,
+                                                 int32_t *__restrict__ n_bytes)
+{
+    __shared__ unsigned words[PACX_PACK_WORDS];
+    __shared__ double cp[2][32];
+    __shared__ unsigned long long bmax[PACX_MAX_BANDS];
+    __shared__ int ba_s[PACX_MAX_BANDS], sf_s[PACX_MAX_BANDS], offs[PACX_MAX_BANDS + 1], lower_s[PACX_MAX_BANDS];
+    const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf)
+        return;
+    const unsigned fl = flags ? flags[cf / n_ch] : 0u;
+    if (mixed && (fl & 2u))
+        return;
+    const int nb = T.nb_long;
+    const long long boff = cf * T.band_stride;
+    /* 1. BitAlloc on the first half wave */
+    {
+        const int32_t *__restrict__ n_lines = T.use_sbr ? T.band_lines_long_alloc : T.band_lines_long;
+        const double budget = pacx_bit_budget(T.target_bps, PACX_M_LONG, 0, (fl & 5u) != 0, T.n_scale_bits,
+                                              T.n_mant_size_bits, nb, T.use_vq, T.use_sbr);
+        int max_mant = 1 << T.n_mant_size_bits;
+        if (max_mant > 16)
+            max_mant = 16;
+        const bool alive = (half == 0);
+        const bool has = alive && l < nb;
+        const double sv = has ? smr[boff + l] : 0.0;
+        const int nl = has ? n_lines[l] : 0;
+        int bits = 0, cap = 0;
+        bitalloc_half(alive, has, sv, nl, budget, max_mant, cp[half], half, l, bits, cap);
+        if (has) {
+            bit_alloc[boff + l] = bits;
+            ba_s[l] = bits;
+        }
+        if (alive && cap && status && l == 0)
+            atomicOr(&status[cf], 4u);
+    }
+    if (payload)
+        for (int i = lane; i < PACX_PACK_WORDS; i += 64)
+            words[i] = 0u;
+    __syncthreads();
+    /* 2. scale factors + mantissas */
+    const int ov = overall[cf * PACX_SUB];
+    double x[16];
+    uint8_t band[16];
+    int32_t mant[16];
+    quantize_long_core(T, lines + cf * PACX_M_LONG, (double)(1 << ov), bmax, ba_s, sf_s, lane, x, band, mant);
+    if (lane < nb)
+        scale_factor[boff + lane] = sf_s[lane];
+    const int k0 = 16 * lane;
+    if (mantissa) {
+#pragma unroll
+        for (int j = 0; j < 16; j += 4)
+            *(int4 *)(mantissa + cf * PACX_M_LONG + k0 + j) = make_int4(mant[j], mant[j + 1], mant[j + 2], mant[j + 3]);
+    }
+    if (!payload)
+        return;
+    /* 3. payload (layout of pack_body) */
+    const int a_mine = (lane < nb) ? ba_s[lane] : 0;
+    const int width = (lane < nb) ? T.n_mant_size_bits + T.n_scale_bits + a_mine * T.band_lines_long[lane] : 0;
+    int incl = width;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off)
+            incl += t;
+    }
+    const int my_off = 3 + T.n_scale_bits + incl - width;
+    if (lane < nb) {
+        offs[lane] = my_off + T.n_mant_size_bits + T.n_scale_bits;
+        lower_s[lane] = T.band_lower_long[lane];
+    }
+    if (lane == nb - 1)
+        offs[nb] = my_off + width;
+    if (lane == 0) {
+        put_bits(words, 0, fl & 1u, 1);
+        put_bits(words, 1, (fl >> 1) & 1u, 1);
+        put_bits(words, 2, (fl >> 2) & 1u, 1);
+        put_bits(words, 3, (unsigned)ov, T.n_scale_bits);
+    }
+    if (lane < nb) {
+        put_bits(words, my_off, (unsigned)(a_mine ? a_mine - 1 : 0), T.n_mant_size_bits);
+        put_bits(words, my_off + T.n_mant_size_bits, (unsigned)sf_s[lane], T.n_scale_bits);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int b = band[j];
+        const int a = ba_s[b];
+        if (a)
+            put_bits(words, offs[b] + (k0 + j - lower_s[b]) * a, (unsigned)mant[j], a);
+    }
+    const int end = offs[nb];
+    __syncthreads();
+    const int nbytes = ((end - 3) + 4 + 7) >> 3;
     unsigned *dst = (unsigned *)(payload + cf * (long long)payload_stride);
     for (int i = lane; i < (nbytes + 3) / 4; i += 64)
         dst[i] = __builtin_bswap32(words[i]);
@@ -603,7 +831,7 @@ void pacx_launch_bitalloc(const PacxTables &T, const uint8_t *flags, int n_ch, l
     const bool dense = !short_blocks && !(mixed && flags);
     const long long units = dense ? n_cf : n_cf * PACX_SUB;       /* two units per wave */
     hipLaunchKernelGGL(k_bitalloc, dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st, T, flags, n_ch,
-                       n_cf, short_blocks, mixed, smr, bit_alloc, status);
+                       n_cf, short_blocks, mixed, 0, smr, bit_alloc, status);
 }
 
 void pacx_launch_quantize(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
@@ -630,7 +858,32 @@ void pacx_launch_pack(const PacxTables &T, const uint8_t *flags, int n_ch, long 
     if (n_cf <= 0)
         return;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch, n_cf, overall,
-                       scale_factor, bit_alloc, mantissa, status, payload, payload_stride, n_bytes);
+                       scale_factor, bit_alloc, mantissa, status, payload, payload_stride, n_bytes, 0);
+}
+
+/* BitAlloc + quantize (+ pack when payload != NULL) of a whole batch: long frames
+ * through the fused kernel, short frames (flags with CUR) through the separate ones. */
+void pacx_launch_tail(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf, const double *smr,
+                      const double *lines, const int32_t *overall, int32_t *bit_alloc, int32_t *scale_factor,
+                      int32_t *mantissa, uint32_t *status, uint8_t *payload, int payload_stride,
+                      int32_t *n_bytes, hipStream_t st)
+{
+    if (n_cf <= 0)
+        return;
+    const int mixed = flags ? 1 : 0;
+    hipLaunchKernelGGL(k_tail_long, dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch, n_cf, mixed, smr,
+                       lines, overall, bit_alloc, scale_factor, mantissa, status, payload, payload_stride,
+                       n_bytes);
+    if (mixed) {
+        const long long units = n_cf * PACX_SUB;
+        hipLaunchKernelGGL(k_bitalloc, dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st, T, flags, n_ch, n_cf,
+                           0, 1, 1, smr, bit_alloc, status);
+        hipLaunchKernelGGL((k_quantize<PACX_M_SHORT>), dim3((unsigned)units), dim3(64), 0, st, T, flags, n_ch,
+                           units, 1, lines, overall, PACX_SUB, bit_alloc, scale_factor, mantissa);
+        if (payload)
+            hipLaunchKernelGGL(k_pack, dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch, n_cf, overall,
+                               scale_factor, bit_alloc, mantissa, status, payload, payload_stride, n_bytes, 1);
+    }
 }
 
 void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stride,

@@ -41,6 +41,10 @@ void pacx_launch_pack(const PacxTables &T, const uint8_t *flags, int n_ch, long 
                       const int32_t *overall, const int32_t *scale_factor, const int32_t *bit_alloc,
                       const int32_t *mantissa, const uint32_t *status, uint8_t *payload,
                       int payload_stride, int32_t *n_bytes, hipStream_t st);
+void pacx_launch_tail(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf, const double *smr,
+                      const double *lines, const int32_t *overall, int32_t *bit_alloc, int32_t *scale_factor,
+                      int32_t *mantissa, uint32_t *status, uint8_t *payload, int payload_stride,
+                      int32_t *n_bytes, hipStream_t st);
 void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stride,
                         const int32_t *n_bytes, long long *chunk_buf, long long *offs_buf, uint8_t *body,
                         long long capacity, long long *total, hipStream_t st);
@@ -110,6 +114,8 @@ struct pacx_handle {
     hipEvent_t ev_fork, ev_join;
     std::vector<char> vq_view;        /* VqView of k_vq.hip (device pointers)   */
     std::vector<char> vqdec_view;     /* VqDecView of k_vq_dec.hip              */
+    long long ws_mant_cf;             /* capacity of ws_mant                    */
+    int32_t *ws_mant;                 /* [cf][1024] mantissas of short frames when the caller wants none */
     long long ws_dec_cf;              /* capacity of the VQ decode buffers      */
     double *ws_dec_lines;             /* [cf][1024]                             */
     uint8_t *ws_dec_sbr;              /* [cf]                                   */
@@ -231,6 +237,8 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->side_stream = nullptr;
     h->ev_fork = nullptr;
     h->ev_join = nullptr;
+    h->ws_mant_cf = 0;
+    h->ws_mant = nullptr;
     h->ws_dec_cf = 0;
     h->ws_dec_lines = nullptr;
     h->ws_dec_sbr = nullptr;
@@ -493,6 +501,8 @@ extern "C" void pacx_destroy(pacx_handle *h)
         (void)hipFree(h->ws_unit_words);
     if (h->ws_unit_bits)
         (void)hipFree(h->ws_unit_bits);
+    if (h->ws_mant)
+        (void)hipFree(h->ws_mant);
     if (h->ws_dec_lines)
         (void)hipFree(h->ws_dec_lines);
     if (h->ws_dec_sbr)
@@ -654,9 +664,10 @@ extern "C" int pacx_quantize_batch(pacx_handle *h, int64_t n_cf, const double *l
     return post_launch(h, "pacx_quantize_batch");
 }
 
-extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
-                                 int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,
-                                 int32_t *mantissa, uint32_t *status, void *stream)
+static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
+                         int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,
+                         int32_t *mantissa, uint32_t *status, uint8_t *payload, int32_t *n_bytes,
+                         void *stream, const char *what)
 {
     if (!h)
         return PACX_E_ARG;
@@ -668,11 +679,12 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
         return rc;
     if (n_cf == 0)
         return PACX_OK;
-    if (!overall_scale || !scale_factor || !bit_alloc || !mantissa || !status)
-        return fail(h, PACX_E_ARG, "pacx_encode_batch: null output pointer");
+    if (!overall_scale || !scale_factor || !bit_alloc || !status || (!payload && !mantissa) ||
+        (payload && !n_bytes))
+        return fail(h, PACX_E_ARG, std::string(what) + ": null output pointer");
     if (h->T.use_vq)
-        return fail(h, PACX_E_UNSUPPORTED, "pacx_encode_batch: handle was created with use_vq "
-                                           "(call pacx_encode_vq_batch)");
+        return fail(h, PACX_E_UNSUPPORTED, std::string(what) + ": handle was created with use_vq "
+                                                                "(call pacx_encode_vq_batch)");
     HIP_TRY(h, hipSetDevice(h->device));
     if ((rc = pacx_reserve(h, n_cf)))
         return rc;
@@ -680,6 +692,18 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
     const PacxTables &T = h->T;
     const int mixed = frame_flags ? 1 : 0;     /* without flags every frame is a long sine block */
     const int n_ch = in->n_channels;
+    if (!mantissa && mixed) {                  /* short frames pack from a mantissa buffer */
+        if (n_cf > h->ws_mant_cf) {
+            HIP_TRY(h, hipDeviceSynchronize());
+            if (h->ws_mant)
+                (void)hipFree(h->ws_mant);
+            h->ws_mant = nullptr;
+            h->ws_mant_cf = 0;
+            HIP_TRY(h, hipMalloc((void **)&h->ws_mant, (size_t)n_cf * PACX_M_LONG * sizeof(int32_t)));
+            h->ws_mant_cf = n_cf;
+        }
+        mantissa = h->ws_mant;
+    }
     HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
     HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
     /* fork: the side chain only reads the PCM, so it runs on its own stream next to the MDCT */
@@ -701,10 +725,29 @@ extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8
     HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));       /* join */
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
                      nullptr, h->n_cu, st);
-    pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_smr, bit_alloc, status, st);
-    pacx_launch_quantize(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_lines, overall_scale, PACX_SUB, bit_alloc,
-                         scale_factor, mantissa, st);
-    return post_launch(h, "pacx_encode_batch");
+    /* BitAlloc + scale factors/mantissas (+ payload): one fused kernel for long frames */
+    pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
+                     mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, st);
+    return post_launch(h, what);
+}
+
+extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
+                                 int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,
+                                 int32_t *mantissa, uint32_t *status, void *stream)
+{
+    return encode_scalar(h, in, frame_flags, overall_scale, scale_factor, bit_alloc, mantissa, status, nullptr,
+                         nullptr, stream, "pacx_encode_batch");
+}
+
+extern "C" int pacx_encode_pack_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
+                                      int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,
+                                      int32_t *mantissa, uint32_t *status, uint8_t *payload, int32_t *n_bytes,
+                                      void *stream)
+{
+    if (h && in && in->n_frames > 0 && (!payload || !n_bytes))
+        return fail(h, PACX_E_ARG, "pacx_encode_pack_batch: payload and n_bytes are required");
+    return encode_scalar(h, in, frame_flags, overall_scale, scale_factor, bit_alloc, mantissa, status, payload,
+                         n_bytes, stream, "pacx_encode_pack_batch");
 }
 
 extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,

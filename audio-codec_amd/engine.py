@@ -228,6 +228,20 @@ class Encoder:
         out["flags"] = fl
         return out
 
+    def encode_pack(self, pcm, flags=None, out=None, want_mantissa=False):
+        """encode() + pack() in one call (long frames: one fused kernel after the
+        masking stage).  `out` as alloc_outputs(n_cf, with_payload=True)."""
+        n_cf = pcm.n_cf
+        fl = self.flags_tensor(flags, pcm.n_frames)
+        if out is None:
+            out = self.alloc_outputs(n_cf, with_payload=True)
+        self._call("pacx_encode_pack_batch", ctypes.byref(pcm.c), _ptr(fl), _ptr(out["overall"]),
+                   _ptr(out["scale_factor"]), _ptr(out["bit_alloc"]),
+                   _ptr(out["mantissa"]) if want_mantissa else None, _ptr(out["status"]),
+                   _ptr(out["payload"]), _ptr(out["n_bytes"]), self._stream())
+        out["flags"] = fl
+        return out
+
     def encode_vq(self, pcm, flags=None, out=None, want_entries=False, entries_per_band=160):
         """The shipped configuration (gain-shape PVQ, SBR if the handle has it) from
         PCM to finished payloads.  Returns dict: overall [n_cf,8], bit_alloc

@@ -203,8 +203,8 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, hea
         out = enc.encode_vq(view, flags)
         payload, n_bytes = out["payload"], out["n_bytes"]
     else:
-        out = enc.encode(view, flags)
-        payload, n_bytes = enc.pack(out, cp.nChannels)
+        out = enc.encode_pack(view, flags)
+        payload, n_bytes = out["payload"], out["n_bytes"]
     body, total = enc.gather_body(payload, n_bytes)
     n = int(total.item())
     return head + body[:n].cpu().numpy().tobytes()

@@ -114,8 +114,7 @@ def main():
         if vq_kbps:
             enc.encode_vq(view, None, vq_out)
         else:
-            enc.encode(view, None, out)
-            enc.pack(out, N_CH, out)
+            enc.encode_pack(view, None, out)
         enc._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(out["payload"]), _ptr(out["n_bytes"]),
                   _ptr(body), ctypes.c_int64(cap), _ptr(total), enc._stream())
 

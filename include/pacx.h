@@ -257,6 +257,18 @@ int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_f
                       void *stream);
 
 /*
+ * pacx_encode_batch followed by pacx_pack_batch in one call (what a file writer
+ * wants: codec.Encode + PACFile.writeEncodedBits for every block,
+ * coder/pacfile.py:466-482, 552-608).  Long frames run BitAlloc, quantisation
+ * and packing in one kernel.  `mantissa` may be NULL when the line-indexed
+ * mantissas are not wanted; the other outputs are as in the two calls above.
+ */
+int pacx_encode_pack_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
+                           int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,
+                           int32_t *mantissa, uint32_t *status, uint8_t *payload, int32_t *n_bytes,
+                           void *stream);
+
+/*
  * The shipped configuration of the reference (coder/pacfile.py:699-707: useVQ
  * always, useSBR below 128 kb/s) for a batch, from PCM to finished payloads:
  *   codec.Encode / EncodeSingleChannel with useVQ   coder/codec.py:239-246, 292-294, 330-360
