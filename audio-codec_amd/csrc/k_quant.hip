@@ -786,6 +786,38 @@ __global__ __launch_bounds__(256) void k_scan_offsets(const int32_t *__restrict_
         offs[i] = chunk_off[blockIdx.x] + buf[t] - v;
 }
 
+/* small batches: the whole exclusive scan in one 1024-thread block (each thread
+ * owns a run of consecutive records) instead of three launches */
+#define SCAN_SMALL_MAX 32768
+__global__ __launch_bounds__(1024) void k_scan_small(const int32_t *__restrict__ n_bytes, long long n,
+                                                    long long *__restrict__ offs, long long *total)
+{
+    __shared__ long long part[1024];
+    const int t = threadIdx.x;
+    const int per = (int)((n + 1023) / 1024);
+    const long long first = (long long)t * per;
+    long long sum = 0;
+    for (int i = 0; i < per; ++i)
+        if (first + i < n)
+            sum += rec_len(n_bytes[first + i]);
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long add = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    long long run = part[t] - sum;
+    for (int i = 0; i < per; ++i)
+        if (first + i < n) {
+            offs[first + i] = run;
+            run += rec_len(n_bytes[first + i]);
+        }
+    if (total && t == 1023)
+        *total = part[1023];
+}
+
 /* one wave per record: "<L nBytes" then the payload bytes */
 __global__ __launch_bounds__(64) void k_copy_body(const int32_t *__restrict__ n_bytes, long long n,
                                                  const long long *__restrict__ offs,
@@ -892,6 +924,12 @@ void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stri
 {
     if (n_cf <= 0)
         return;
+    if (n_cf <= SCAN_SMALL_MAX) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, n_bytes, n_cf, offs_buf, total);
+        hipLaunchKernelGGL(k_copy_body, dim3((unsigned)n_cf), dim3(64), 0, st, n_bytes, n_cf, offs_buf, payload,
+                           payload_stride, body, capacity);
+        return;
+    }
     const long long n_chunks = (n_cf + SCAN_CHUNK - 1) / SCAN_CHUNK;
     hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)n_chunks), dim3(256), 0, st, n_bytes, n_cf, chunk_buf);
     hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(64), 0, st, chunk_buf, n_chunks, total);

@@ -597,3 +597,22 @@ def test_full_size_properties(A, torch):
         assert int.from_bytes(body[off:off + 4].tobytes(), "little") == n_bytes[i]
         assert body[off + 4:off + 4 + n_bytes[i]].tobytes() == payload[i, :n_bytes[i]].tobytes()
         off += 4 + n_bytes[i]
+
+
+def test_gather_body_small_and_large_paths(A):
+    """pacx_gather_body: the single-block scan (<= 32768 records) and the chunked
+    scan give the '<L nBytes' + payload stream NumPy builds, dropped hops
+    (n_bytes 0) leaving no trace."""
+    import torch
+    enc = A.engine.Encoder(48000, 128 / 48.0)
+    rng = np.random.default_rng(3)
+    for n in (1, 777, 32768, 40001):
+        nb = rng.integers(0, 700, size=n).astype(np.int32)
+        nb[rng.integers(0, n, size=max(1, n // 50))] = 0
+        pay = rng.integers(0, 256, size=(n, enc.payload_stride), dtype=np.uint8)
+        body, total = enc.gather_body(torch.as_tensor(pay, device=enc.device),
+                                      torch.as_tensor(nb, device=enc.device))
+        want = b"".join(int(k).to_bytes(4, "little") + pay[i, :k].tobytes()
+                        for i, k in enumerate(nb) if k > 0)
+        assert int(total.item()) == len(want)
+        assert body[:len(want)].cpu().numpy().tobytes() == want
