@@ -792,30 +792,39 @@ __global__ __launch_bounds__(256) void k_scan_offsets(const int32_t *__restrict_
 __global__ __launch_bounds__(1024) void k_scan_small(const int32_t *__restrict__ n_bytes, long long n,
                                                     long long *__restrict__ offs, long long *total)
 {
-    __shared__ long long part[1024];
-    const int t = threadIdx.x;
+    __shared__ long long wave_tot[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int per = (int)((n + 1023) / 1024);
     const long long first = (long long)t * per;
     long long sum = 0;
     for (int i = 0; i < per; ++i)
         if (first + i < n)
             sum += rec_len(n_bytes[first + i]);
-    part[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const long long add = (t >= off) ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += add;
-        __syncthreads();
+    long long incl = sum;                                  /* inclusive scan inside the wave */
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long v = __shfl_up(incl, off, 64);
+        if (lane >= off)
+            incl += v;
     }
-    long long run = part[t] - sum;
+    if (lane == 63)
+        wave_tot[wv] = incl;
+    __syncthreads();
+    long long base = 0, all = 0;
+    for (int w = 0; w < 16; ++w) {
+        const long long v = wave_tot[w];
+        if (w < wv)
+            base += v;
+        all += v;
+    }
+    long long run = base + incl - sum;
     for (int i = 0; i < per; ++i)
         if (first + i < n) {
             offs[first + i] = run;
             run += rec_len(n_bytes[first + i]);
         }
-    if (total && t == 1023)
-        *total = part[1023];
+    if (total && t == 0)
+        *total = all;
 }
 
 /* one wave per record: "<L nBytes" then the payload bytes */
