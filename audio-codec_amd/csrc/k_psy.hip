@@ -77,25 +77,81 @@ __device__ __forceinline__ PacxPeak make_peak(double left, double centre, int f,
 /* ------------------------------------------------------------------ long */
 /* LDS of one wave: raw (until the FFT inputs are in registers) then inten share
  * one region; the FFT exchange tile then the packed spectrum Z share another */
+/* LDS of one wave (17.5 KB for int16 input -> 9 waves per CU):
+ *   region A (9 KB): the FFT exchange tile, later the peak lists (idx, zs, ss)
+ *   region B (8.06 KB, 16 KB for float64 input): raw samples, later the intensities
+ * The packed spectrum Z never goes to LDS: the real-FFT split needs Z[k] with
+ * Z[N/2-k], and with natural-order FFT output (wave_fft.h fft512n) that
+ * partner sits in the mirrored lane's mirrored register, one ds_bpermute away. */
 template <int DT> struct SideLongLds {
     typedef typename PcmStage<DT>::elem E;
     static constexpr int RAW_BYTES = (int)sizeof(E) * PACX_N_LONG;
+    static constexpr int A_BYTES = 1024 + 2 * PACX_MAX_PEAKS * 8;             /* >= 512 * sizeof(cplx) */
     static constexpr int B_BYTES = RAW_BYTES > 1032 * 8 ? RAW_BYTES : 1032 * 8;
-    static constexpr int BYTES = 1024 * (int)sizeof(cplx) + B_BYTES;
+    static constexpr int BYTES = A_BYTES + B_BYTES;
 };
 
+/* natural-order 512-point FFT with the per-lane twiddles read from the global
+ * W512 table (L1/L2 resident) */
+__device__ __forceinline__ void fft512n_g(cplx v[8], cplx *tile, const cplx *__restrict__ w512, int lane)
+{
+    const int g = lane >> 3, r = lane & 7;
+    dft8(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1)
+        v[k1] = c_mul(v[k1], w512[(lane * k1) & 511]);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1)
+        tile[64 * k1 + (lane ^ (8 * k1))] = v[k1];
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2)
+        v[n2] = tile[64 * g + 8 * (n2 ^ g) + r];
+    wave_lds_fence();
+    dft8(v);
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2)
+        v[k2] = c_mul(v[k2], w512[(8 * r * k2) & 511]);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2)
+        tile[64 * g + 8 * k2 + (r ^ g)] = v[k2];
+    wave_lds_fence();
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3)
+        v[n3] = tile[64 * r + 8 * g + (n3 ^ r)];
+    wave_lds_fence();
+    dft8(v);
+}
+
+__device__ __forceinline__ double bperm_f64(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+/* intensity of real-FFT bin i from a = Z[i mod N/2'] and b = Z[(N/2' - i) mod N/2'] */
+__device__ __forceinline__ double pair_intensity(cplx a, cplx bz, cplx w, double norm)
+{
+    const cplx s = make_double2(a.x + bz.x, a.y - bz.y);      /* a + conj(b) */
+    const cplx d = make_double2(a.x - bz.x, a.y + bz.y);      /* a - conj(b) */
+    const cplx wd = c_mul(w, d);
+    const double xr = 0.5 * (s.x + wd.y), xi = 0.5 * (s.y - wd.x);
+    return norm * fma(xr, xr, xi * xi);
+}
+
 /* one long channel-frame by one wave; every barrier is wave-local (the wave
- * owns its LDS slice), so waves of a persistent workgroup run independently */
+ * owns its LDS slice) */
 template <int DT, bool FAST>
 __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcmView &in, long long cf,
-                                              cplx *Z, char *regB, int lane,
+                                              char *regA, char *regB, int lane,
                                               PacxPeak *__restrict__ peaks, int32_t *__restrict__ n_peaks,
                                               int32_t *__restrict__ n_kept_out,
                                               double *__restrict__ sbr_mean,
                                               int32_t *__restrict__ sbr_overall)
 {
     typedef typename PcmStage<DT>::elem E;
-    cplx *tile = Z;
+    cplx *tile = (cplx *)regA;
     double *inten = (double *)regB;
     E *raw = (E *)regB;
 
@@ -110,21 +166,43 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
         ev[n1] = make_double2(hann_sample<DT>(raw, i, hw, hwp), hann_sample<DT>(raw, i + 1, hw, hwp));
         od[n1] = make_double2(hann_sample<DT>(raw, i + 2, hw, hwp), hann_sample<DT>(raw, i + 3, hw, hwp));
     }
-    wave_lds_fence();                  /* raw fully consumed before anything reuses LDS */
-    fft512(ev, tile, T.w512, lane);
-    fft512(od, tile, T.w512, lane);
-    wave_lds_fence();                  /* tile dead: Z takes its place */
+    wave_lds_fence();                  /* raw fully consumed: region B becomes inten */
+    fft512n_g(ev, tile, T.w512, lane);
+    fft512n_g(od, tile, T.w512, lane);
+    /* ev[k3] = E[k], od[k3] = O[k], k = lane + 64 k3.  Z[k] = E[k] + W1024^k O[k],
+       Z[k+512] = E[k] - W1024^k O[k].  Bins k and k+512 pair with Z[1024-k] and
+       Z[512-k]: both are made of E[m], O[m], m = 512 - k, which lane 64-lane holds
+       in register 7-k3 (lane 0: its own register 8-k3; k = 0 pairs with itself). */
+    const int mirror = (64 - lane) & 63;
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) {
-        const int k = fft512_out_index(lane, k3);
+        const int k = lane + 64 * k3;
         const cplx t = c_mul(T.w1024[k], od[k3]);
-        Z[k] = c_add(ev[k3], t);
-        Z[k + 512] = c_sub(ev[k3], t);
+        const cplx zk = c_add(ev[k3], t), zk5 = c_sub(ev[k3], t);
+        /* partner E[m], O[m] */
+        cplx pe, po;
+        pe.x = bperm_f64(ev[7 - k3].x, mirror);
+        pe.y = bperm_f64(ev[7 - k3].y, mirror);
+        po.x = bperm_f64(od[7 - k3].x, mirror);
+        po.y = bperm_f64(od[7 - k3].y, mirror);
+        if (lane == 0) {
+            pe = ev[(8 - k3) & 7];
+            po = od[(8 - k3) & 7];
+        }
+        const int m = (512 - k) & 511;
+        const cplx tm = c_mul(T.w1024[m], po);
+        cplx zm = c_add(pe, tm), zm5 = c_sub(pe, tm);       /* Z[m], Z[m+512] */
+        if (k == 0) {                                       /* bins 0 and 512 pair with themselves */
+            zm5 = zk;
+            zm = zk5;
+        }
+        inten[k] = pair_intensity(zk, zm5, T.w2048[k], T.norm_long);
+        inten[k + 512] = pair_intensity(zk5, zm, T.w2048[k + 512], T.norm_long);
+        if (k == 0)
+            inten[1024] = pair_intensity(zk, zk, T.w2048[1024], T.norm_long);
     }
     wave_lds_fence();
-    for (int i = lane; i <= 1024; i += 64)
-        inten[i] = bin_intensity(Z, i, 1024, T.w2048[i], T.norm_long);
-    wave_lds_fence();
+    cplx *Z = (cplx *)regA;            /* region A from here on: idx, zs, ss */
 
     /* pass 1: strict local maxima (coder/psychoac.py:312-317), their bin numbers
        compacted in ascending order into LDS (ballot + prefix popcount) */
@@ -146,7 +224,7 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
     wave_lds_fence();
     /* pass 2: one masker per lane, 64 at a time (log10 + two atan each); Bark and
        SPL go to LDS for the pruning scans */
-    double *zs = (double *)Z + 256;                       /* [512] after the index list */
+    double *zs = (double *)Z + 128;                       /* [512] after the 1 KB index list */
     double *ss = zs + PACX_MAX_PEAKS;                     /* [512]                      */
     for (int p = lane; p < count; p += 64) {
         const int i = idx[p];
@@ -276,7 +354,7 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
                                                  double *__restrict__ sbr_mean,
                                                  int32_t *__restrict__ sbr_overall)
 {
-    __shared__ __attribute__((aligned(16))) cplx Z[1024];
+    __shared__ __attribute__((aligned(16))) char regA[SideLongLds<DT>::A_BYTES];
     __shared__ __attribute__((aligned(16))) char regB[SideLongLds<DT>::B_BYTES];
     const long long cf = blockIdx.x;
     if (cf >= n_cf)
@@ -284,7 +362,7 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
     const unsigned fl = flags ? flags[cf / in.n_ch] : 0u;
     if (skip_cur && (fl & 2u))
         return;
-    side_long_one<DT, FAST>(T, in, cf, Z, regB, threadIdx.x, peaks, n_peaks, n_kept_out, sbr_mean, sbr_overall);
+    side_long_one<DT, FAST>(T, in, cf, regA, regB, threadIdx.x, peaks, n_peaks, n_kept_out, sbr_mean, sbr_overall);
 }
 
 /* ----------------------------------------------------------------- short */
