@@ -143,6 +143,7 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
         }
         wave_lds_fence();                 /* raw samples consumed: their LDS may be overwritten */
         if (DBUF) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (cf + stride < total)
                 stage(cf + stride);
             younger = 0;
@@ -150,7 +151,11 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
         fft512n(v, tile, w1, 64, w2, 8, lane);
         if (!DBUF) {
             /* the tile is free again: start the next frame's PCM on its way now, it
-               lands during the epilogue and the other waves' work */
+               lands during the epilogue and the other waves' work.  The DMA writes
+               LDS from the vector-memory side and is not ordered with this wave's
+               own ds_reads, so the FFT's last tile reads must have returned first
+               (a wavefront-scope fence does not wait for them). */
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (cf + stride < total)
                 stage(cf + stride);
         }

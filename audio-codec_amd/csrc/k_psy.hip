@@ -459,10 +459,15 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
  * SPL/Intensity round trip adds at most 1.2e-5 dB at levels >= the lowest
  * threshold in quiet (-5 dB).
  */
-#define MASK_WAVES 8
+#ifndef MASK_WAVES
+#define MASK_WAVES 4
+#endif
+#ifndef MASK_OCC
+#define MASK_OCC 3                 /* waves per SIMD the register budget is set for */
+#endif
 
 template <int M>
-__global__ __launch_bounds__(64 * MASK_WAVES, 4) void k_mask(PacxTables T, const uint8_t *__restrict__ flags,
+__global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T, const uint8_t *__restrict__ flags,
                                                          int n_ch, long long n_units, int mixed,
                                                          const PacxPeak *__restrict__ peaks,
                                                          const int32_t *__restrict__ n_peaks,
@@ -476,7 +481,6 @@ __global__ __launch_bounds__(64 * MASK_WAVES, 4) void k_mask(PacxTables T, const
     __shared__ __attribute__((aligned(16))) double quiet_s[M];
     __shared__ __attribute__((aligned(16))) double chunk_c[PER][4];        /* zlo-0.5, zhi+0.5, qmin-0.01 */
     __shared__ __attribute__((aligned(16))) double bufs[MASK_WAVES][M];    /* best, then mdct_spl - thr */
-    __shared__ __attribute__((aligned(16))) double xbufs[MASK_WAVES][M];   /* this unit's MDCT lines     */
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const double *__restrict__ bark = SHORT ? T.bark_short : T.bark_long;
@@ -501,7 +505,6 @@ __global__ __launch_bounds__(64 * MASK_WAVES, 4) void k_mask(PacxTables T, const
     __syncthreads();
 
     double *buf = bufs[wv];
-    double *xbuf = xbufs[wv];
     const int nb = SHORT ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
@@ -519,18 +522,14 @@ __global__ __launch_bounds__(64 * MASK_WAVES, 4) void k_mask(PacxTables T, const
         const int np = n_peaks[cf * PACX_SUB + sb];
         const long long loff = cf * PACX_M_LONG + sb * PACX_M_SHORT;
 
-        /* all global loads of this unit are issued up front (lines -> LDS for the
-           per-line loop, first masker batch -> registers); later ones are
-           software-pipelined one batch ahead, so no loop iteration waits on HBM */
-        double z[PER], best[PER];
+        /* the running maximum of every line lives in LDS (read-modify-write by its
+           own lane, once per masker batch and chunk) and the Bark value of a line is
+           read from the LDS table when its chunk is live: neither array occupies
+           registers, which is what lets three waves share a SIMD.  Masker batches
+           are software-pipelined one ahead, so no loop iteration waits on HBM */
 #pragma unroll
         for (int j = 0; j < PER; ++j)
-            xbuf[lane + 64 * j] = lines[loff + lane + 64 * j];
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            z[j] = bark_s[lane + 64 * j];
-            best[j] = -INFINITY;
-        }
+            buf[lane + 64 * j] = -INFINITY;
         PacxPeak qn;
         qn.z = 0.0; qn.spl = -1000.0; qn.slope = 0.0;             /* padding lanes never survive */
         if (lane < np)
@@ -575,6 +574,10 @@ __global__ __launch_bounds__(64 * MASK_WAVES, 4) void k_mask(PacxTables T, const
                 const double ub = q.slope * fmax(lo_edge - q.z, 0.0) + -27.0 * fmax(q.z - hi_edge, 0.0);
                 const bool live = (q.slope > 0.0 && q.spl > -1000.0) || (lvl + ub > need);
                 unsigned long long todo = __ballot(live);
+                if (!todo)
+                    continue;
+                const double zj = bark_s[lane + 64 * j];
+                double bj = buf[lane + 64 * j];
                 while (todo) {
                     const int b = __builtin_ctzll(todo);
                     todo &= todo - 1;
@@ -585,28 +588,30 @@ __global__ __launch_bounds__(64 * MASK_WAVES, 4) void k_mask(PacxTables T, const
                        (a = |dz| - 0.5): select the slope by the sign of dz and clamp a
                        at 0 -- same products as the reference's masked assignments
                        (coder/psychoac.py:92-94), no divergent branches */
-                    const double dz = z[j] - pz;
+                    const double dz = zj - pz;
                     const double a = fmax(fabs(dz) - 0.5, 0.0);
                     const double gain = (dz < 0.0 ? -27.0 : pu) * a;
-                    best[j] = fmax(best[j], (ps + gain) - 16.0);
+                    bj = fmax(bj, (ps + gain) - 16.0);
                 }
+                buf[lane + 64 * j] = bj;
             }
         }
-#pragma unroll
-        for (int j = 0; j < PER; ++j)
-            buf[lane + 64 * j] = best[j];
         wave_lds_fence();
-        /* per line: round trip of the winner, max with quiet, SMR term */
+        /* per line: round trip of the winner, max with quiet, SMR term; the MDCT
+           line is fetched one iteration ahead */
+        double v_next = lines[loff + lane];
 #pragma unroll 1
         for (int j = 0; j < PER; ++j) {
             const int k = lane + 64 * j;
+            const double v = v_next;
+            if (j + 1 < PER)
+                v_next = lines[loff + k + 64];
             const double bst = buf[k];
             double thr = quiet_s[k];
             if (bst > -INFINITY)
                 thr = fmax(thr, pacx_spl_of_intensity_of(bst));
             if (thr_out)
                 thr_out[loff + k] = thr;
-            const double v = xbuf[k];
             buf[k] = pacx_spl_array((v * v) * 4.0) - thr;
         }
         wave_lds_fence();
@@ -663,19 +668,20 @@ void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long 
 {
     if (n_cf <= 0)
         return;
-    /* persistent grids: two 8-wave workgroups per CU for the long kernel (80 KB LDS each) */
+    /* persistent grids: 4 waves x 8 KB + 16.5 KB of tables = 48.5 KB per workgroup, three
+       workgroups (12 waves) per CU for the long kernel */
     if (!short_blocks || mixed) {
         long long blocks = (n_cf + MASK_WAVES - 1) / MASK_WAVES;
-        if (blocks > 2LL * n_cu)
-            blocks = 2LL * n_cu;
+        if (blocks > (12LL / MASK_WAVES) * n_cu)
+            blocks = (12LL / MASK_WAVES) * n_cu;
         hipLaunchKernelGGL((k_mask<PACX_M_LONG>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T, flags,
                            n_ch, n_cf, mixed, peaks, n_peaks, lines, smr, thr_out);
     }
     if (short_blocks || mixed) {
         const long long units = n_cf * PACX_SUB;
         long long blocks = (units + MASK_WAVES - 1) / MASK_WAVES;
-        if (blocks > 4LL * n_cu)
-            blocks = 4LL * n_cu;
+        if (blocks > (32LL / MASK_WAVES) * n_cu)
+            blocks = (32LL / MASK_WAVES) * n_cu;
         hipLaunchKernelGGL((k_mask<PACX_M_SHORT>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T, flags,
                            n_ch, units, mixed, peaks, n_peaks, lines, smr, thr_out);
     }
