@@ -30,7 +30,8 @@
 template <int MDCT2_WAVES, int MINW, bool DBUF>
 __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
     PacxTables T, PacxPcmView in, const uint8_t *__restrict__ flags, long long n_cf, int skip_cur,
-    double *__restrict__ lines, int32_t *__restrict__ scale_out, int scale_stride)
+    double *__restrict__ lines, int32_t *__restrict__ scale_out, int scale_stride,
+    uint32_t *__restrict__ status_init)
 {
     __shared__ __attribute__((aligned(16))) cplx tiles[MDCT2_WAVES][WFFT_TILE_N];
     /* DBUF: PCM has a landing buffer of its own, so the next frame's DMA starts
@@ -86,12 +87,22 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
         /* frames this kernel leaves to others: short-coded (CUR) ones when asked
            to, and long frames with a transition window (k_mdct_long takes them) */
         const bool mine = !(skip_cur && (fl & 2u)) && pacx_window_kind(fl) == 0;
+        /* output initialisation the whole-path entry points would otherwise spend two
+           memset launches on: status word 0 and the 7 unused overall-scale slots of a
+           long frame 0, for EVERY frame (kernels that follow on the stream overwrite /
+           OR into them for the frames they own) */
+        if (status_init) {
+            if (lane == 0)
+                status_init[cf] = 0u;
+            if (lane >= 1 && lane < PACX_SUB)
+                scale_out[(long long)cf * PACX_SUB + lane] = 0;
+        }
         /* this frame's PCM must have landed in LDS.  vmcnt counts loads, stores and
            LDS-DMA together in issue order: with DBUF the DMA is older than the
            previous frame's 8 (+1) line stores, so only they may stay in flight */
-        if (DBUF && younger == 9)
+        if (DBUF && !status_init && younger == 9)
             asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else if (DBUF && younger == 8)
+        else if (DBUF && !status_init && younger == 8)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -188,11 +199,13 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
 }
 
 void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8_t *flags, long long n_cf,
-                         int skip_cur, double *lines, int32_t *scale_out, int scale_stride, int n_cu,
-                         hipStream_t st)
+                         int skip_cur, double *lines, int32_t *scale_out, int scale_stride,
+                         uint32_t *status_init, int n_cu, hipStream_t st)
 {
     if (n_cf <= 0)
         return;
+    if (status_init && (!scale_out || scale_stride != PACX_SUB))
+        status_init = nullptr;                 /* the caller keeps its memsets */
     /* geometry variants (PACX_MDCT_VARIANT, for experiments; default 0) */
     static int variant = -1;
     if (variant < 0) {
@@ -206,7 +219,7 @@ void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8
         if (blocks > cap)                                                                             \
             blocks = cap;                                                                             \
         hipLaunchKernelGGL((k_mdct_long_v2<W, MW, DB>), dim3((unsigned)blocks), dim3(64 * (W)), 0, st, T, \
-                           in, flags, n_cf, skip_cur, lines, scale_out, scale_stride);                \
+                           in, flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init);   \
     } while (0)
     switch (variant) {
     case 1: LAUNCH(6, 3, 2, false); break;   /* 12 waves/CU in two workgroups                 */

@@ -465,6 +465,12 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 #ifndef MASK_OCC
 #define MASK_OCC 3                 /* waves per SIMD the register budget is set for */
 #endif
+#ifndef MASK_LDS_TABLES
+#define MASK_LDS_TABLES 3          /* bit 0: Bark table in LDS, bit 1: threshold-in-quiet in LDS */
+#endif
+#ifndef MASK_WG_PER_CU
+#define MASK_WG_PER_CU 3
+#endif
 
 template <int M>
 __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T, const uint8_t *__restrict__ flags,
@@ -477,20 +483,23 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
 {
     constexpr bool SHORT = (M == PACX_M_SHORT);
     constexpr int PER = M / 64;
-    __shared__ __attribute__((aligned(16))) double bark_s[M];
-    __shared__ __attribute__((aligned(16))) double quiet_s[M];
+    constexpr bool BARK_LDS = (MASK_LDS_TABLES & 1) != 0, QUIET_LDS = (MASK_LDS_TABLES & 2) != 0;
+    __shared__ __attribute__((aligned(16))) double bark_l[BARK_LDS ? M : 1];
+    __shared__ __attribute__((aligned(16))) double quiet_l[QUIET_LDS ? M : 1];
     __shared__ __attribute__((aligned(16))) double chunk_c[PER][4];        /* zlo-0.5, zhi+0.5, qmin-0.01 */
     __shared__ __attribute__((aligned(16))) double bufs[MASK_WAVES][M];    /* best, then mdct_spl - thr */
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    {
-        const double *__restrict__ bark = SHORT ? T.bark_short : T.bark_long;
-        const double *__restrict__ quiet = SHORT ? T.thresh_short : T.thresh_long;
-        for (int i = tid; i < M; i += 64 * MASK_WAVES) {
-            bark_s[i] = bark[i];
-            quiet_s[i] = quiet[i];
-        }
+    const double *__restrict__ bark_g = SHORT ? T.bark_short : T.bark_long;
+    const double *__restrict__ quiet_g = SHORT ? T.thresh_short : T.thresh_long;
+    for (int i = tid; i < M; i += 64 * MASK_WAVES) {
+        if (BARK_LDS)
+            bark_l[i] = bark_g[i];
+        if (QUIET_LDS)
+            quiet_l[i] = quiet_g[i];
     }
     __syncthreads();
+    const double *bark_s = BARK_LDS ? (const double *)bark_l : bark_g;
+    const double *quiet_s = QUIET_LDS ? (const double *)quiet_l : quiet_g;
     for (int j = wv; j < PER; j += MASK_WAVES) {
         double qm = quiet_s[64 * j + lane];
 #pragma unroll
@@ -668,12 +677,12 @@ void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long 
 {
     if (n_cf <= 0)
         return;
-    /* persistent grids: 4 waves x 8 KB + 16.5 KB of tables = 48.5 KB per workgroup, three
-       workgroups (12 waves) per CU for the long kernel */
+    /* persistent grids: MASK_WAVES x 8 KB of running maxima + the LDS tables per workgroup,
+       MASK_WG_PER_CU workgroups per CU for the long kernel */
     if (!short_blocks || mixed) {
         long long blocks = (n_cf + MASK_WAVES - 1) / MASK_WAVES;
-        if (blocks > (12LL / MASK_WAVES) * n_cu)
-            blocks = (12LL / MASK_WAVES) * n_cu;
+        if (blocks > (long long)MASK_WG_PER_CU * n_cu)
+            blocks = (long long)MASK_WG_PER_CU * n_cu;
         hipLaunchKernelGGL((k_mask<PACX_M_LONG>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T, flags,
                            n_ch, n_cf, mixed, peaks, n_peaks, lines, smr, thr_out);
     }

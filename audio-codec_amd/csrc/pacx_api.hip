@@ -21,8 +21,8 @@ void pacx_launch_mdct(const PacxTables &T, const PacxPcmView &in, int dtype, int
                       double *lines, int32_t *scale_out, int scale_stride, uint32_t *status,
                       hipStream_t st);
 void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8_t *flags, long long n_cf,
-                         int skip_cur, double *lines, int32_t *scale_out, int scale_stride, int n_cu,
-                         hipStream_t st);
+                         int skip_cur, double *lines, int32_t *scale_out, int scale_stride,
+                         uint32_t *status_init, int n_cu, hipStream_t st);
 void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
                       const uint8_t *flags, long long n_cf, int short_blocks, int mixed,
                       PacxPeak *peaks, int32_t *n_peaks, int32_t *n_kept, double *sbr_mean,
@@ -585,7 +585,8 @@ extern "C" int pacx_mdct_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t
     HIP_TRY(h, hipSetDevice(h->device));
     const int short_blocks = (mode & PACX_MDCT_SHORT) ? 1 : 0;
     if (fast && !short_blocks && !(mode & PACX_MDCT_PREWINDOWED)) {
-        pacx_launch_mdct_v2(h->T, v, frame_flags, n_cf, 0, lines, max_scale, 1, h->n_cu, (hipStream_t)stream);
+        pacx_launch_mdct_v2(h->T, v, frame_flags, n_cf, 0, lines, max_scale, 1, nullptr, h->n_cu,
+                            (hipStream_t)stream);
         if (frame_flags)       /* frames with a start/stop/start-stop window */
             pacx_launch_mdct(h->T, v, in->dtype, fast, frame_flags, n_cf, 0, 2, 0, lines, max_scale, 1, nullptr,
                              (hipStream_t)stream);
@@ -704,8 +705,10 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         }
         mantissa = h->ws_mant;
     }
-    HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
-    HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
+    if (!fast) {                               /* fast path: k_mdct_long_v2 initialises both itself */
+        HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
+        HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
+    }
     /* fork: the side chain only reads the PCM, so it runs on its own stream next to the MDCT */
     HIP_TRY(h, hipEventRecord(h->ev_fork, st));
     HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
@@ -714,7 +717,8 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
     HIP_TRY(h, hipEventRecord(h->ev_join, h->side_stream));
     if (fast) {
         /* long frames: persistent roofline kernel; short (CUR) frames: k_mdct_short */
-        pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, h->n_cu, st);
+        pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
+                            h->n_cu, st);
         if (mixed)
             pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 3, 0, h->ws_lines, overall_scale,
                              PACX_SUB, status, st);
@@ -790,11 +794,14 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
         HIP_TRY(h, hipMalloc((void **)&h->ws_unit_bits, (size_t)n_cf * PACX_SUB * 2 * sizeof(int32_t)));
         h->ws_vq_cf = n_cf;
     }
-    HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
-    HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
+    if (!fast) {
+        HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
+        HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
+    }
     HIP_TRY(h, hipMemsetAsync(n_bytes, 0, (size_t)n_cf * sizeof(int32_t), st));
     if (fast) {
-        pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, h->n_cu, st);
+        pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
+                            h->n_cu, st);
         if (mixed)
             pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 3, 0, h->ws_lines, overall_scale,
                              PACX_SUB, status, st);
