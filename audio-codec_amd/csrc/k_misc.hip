@@ -137,6 +137,53 @@ __global__ void k_stream_flags(const uint8_t *__restrict__ transient, long long 
     flags[f] = (uint8_t)v;
 }
 
+/* Mixed streams: channel-frame indices of the long-coded and of the short-coded
+ * frames, compacted (any order) so that persistent kernels can walk only the
+ * frames they own and stay balanced.  counts[0] = long cf, counts[1] = short cf;
+ * both must be zero on entry. */
+__global__ __launch_bounds__(256) void k_frame_lists(const uint8_t *__restrict__ flags, long long n_frames,
+                                                    int n_ch, int32_t *__restrict__ list_long,
+                                                    int32_t *__restrict__ list_short,
+                                                    int32_t *__restrict__ counts)
+{
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool in_range = f < n_frames;
+    const bool is_short = in_range && (flags[f] & 2u);
+    const bool is_long = in_range && !is_short;
+    const unsigned long long ms = __ballot(is_short), ml = __ballot(is_long);
+    int base_s = 0, base_l = 0;
+    if (lane == 0) {
+        if (ms)
+            base_s = atomicAdd(&counts[1], __popcll(ms) * n_ch);
+        if (ml)
+            base_l = atomicAdd(&counts[0], __popcll(ml) * n_ch);
+    }
+    base_s = __shfl(base_s, 0, 64);
+    base_l = __shfl(base_l, 0, 64);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (is_short) {
+        const int at = base_s + __popcll(ms & below) * n_ch;
+        for (int c = 0; c < n_ch; ++c)
+            list_short[at + c] = (int32_t)(f * n_ch + c);
+    }
+    if (is_long) {
+        const int at = base_l + __popcll(ml & below) * n_ch;
+        for (int c = 0; c < n_ch; ++c)
+            list_long[at + c] = (int32_t)(f * n_ch + c);
+    }
+}
+
+void pacx_launch_frame_lists(const uint8_t *flags, long long n_frames, int n_ch, int32_t *list_long,
+                             int32_t *list_short, int32_t *counts, hipStream_t st)
+{
+    if (n_frames <= 0)
+        return;
+    (void)hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_frame_lists, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, flags, n_frames,
+                       n_ch, list_long, list_short, counts);
+}
+
 void pacx_launch_transient(const PacxPcmView &in, long long n_hops, int hop, uint8_t *transient,
                            uint8_t *flags, hipStream_t st)
 {

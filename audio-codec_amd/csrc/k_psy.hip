@@ -479,7 +479,9 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                                                          const int32_t *__restrict__ n_peaks,
                                                          const double *__restrict__ lines,
                                                          double *__restrict__ smr,
-                                                         double *__restrict__ thr_out)
+                                                         double *__restrict__ thr_out,
+                                                         const int32_t *__restrict__ cf_list,
+                                                         const int32_t *__restrict__ cf_count)
 {
     constexpr bool SHORT = (M == PACX_M_SHORT);
     constexpr int PER = M / 64;
@@ -518,11 +520,17 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
 
+    /* mixed streams: walk the compacted list of the frames this kernel owns, so the
+       static striding stays balanced whatever the pattern of long and short frames */
+    if (cf_list)
+        n_units = SHORT ? (long long)(*cf_count) * PACX_SUB : (long long)(*cf_count);
     for (long long unit = (long long)blockIdx.x * MASK_WAVES + wv; unit < n_units;
          unit += (long long)gridDim.x * MASK_WAVES) {
-        const long long cf = SHORT ? unit / PACX_SUB : unit;
+        long long cf = SHORT ? unit / PACX_SUB : unit;
         const int sb = SHORT ? (int)(unit % PACX_SUB) : 0;
-        if (mixed) {
+        if (cf_list) {
+            cf = cf_list[cf];
+        } else if (mixed) {
             const unsigned fl = flags ? flags[cf / n_ch] : 0u;
             if (SHORT != ((fl & 2u) != 0))
                 continue;
@@ -673,7 +681,9 @@ void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int
 
 void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
                       int short_blocks, int mixed, const PacxPeak *peaks, const int32_t *n_peaks,
-                      const double *lines, double *smr, double *thr_out, int n_cu, hipStream_t st)
+                      const double *lines, double *smr, double *thr_out, int n_cu,
+                      const int32_t *list_long, const int32_t *list_short, const int32_t *counts,
+                      hipStream_t st)
 {
     if (n_cf <= 0)
         return;
@@ -684,7 +694,8 @@ void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long 
         if (blocks > (long long)MASK_WG_PER_CU * n_cu)
             blocks = (long long)MASK_WG_PER_CU * n_cu;
         hipLaunchKernelGGL((k_mask<PACX_M_LONG>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T, flags,
-                           n_ch, n_cf, mixed, peaks, n_peaks, lines, smr, thr_out);
+                           n_ch, n_cf, mixed, peaks, n_peaks, lines, smr, thr_out, mixed ? list_long : nullptr,
+                           counts);
     }
     if (short_blocks || mixed) {
         const long long units = n_cf * PACX_SUB;
@@ -692,6 +703,7 @@ void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long 
         if (blocks > (32LL / MASK_WAVES) * n_cu)
             blocks = (32LL / MASK_WAVES) * n_cu;
         hipLaunchKernelGGL((k_mask<PACX_M_SHORT>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T, flags,
-                           n_ch, units, mixed, peaks, n_peaks, lines, smr, thr_out);
+                           n_ch, units, mixed, peaks, n_peaks, lines, smr, thr_out, mixed ? list_short : nullptr,
+                           counts ? counts + 1 : nullptr);
     }
 }

@@ -29,7 +29,11 @@ void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int
                       int32_t *sbr_overall, hipStream_t st);
 void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
                       int short_blocks, int mixed, const PacxPeak *peaks, const int32_t *n_peaks,
-                      const double *lines, double *smr, double *thr_out, int n_cu, hipStream_t st);
+                      const double *lines, double *smr, double *thr_out, int n_cu,
+                      const int32_t *list_long, const int32_t *list_short, const int32_t *counts,
+                      hipStream_t st);
+void pacx_launch_frame_lists(const uint8_t *flags, long long n_frames, int n_ch, int32_t *list_long,
+                             int32_t *list_short, int32_t *counts, hipStream_t st);
 void pacx_launch_bitalloc(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
                           int short_blocks, int mixed, const double *smr, int32_t *bit_alloc,
                           uint32_t *status, hipStream_t st);
@@ -106,6 +110,7 @@ struct pacx_handle {
     int32_t *ws_overall;              /* [ws_cf][8]                             */
     long long *ws_chunks;             /* [ws_cf/256 + 2]                        */
     long long *ws_offs;               /* [ws_cf]                                */
+    int32_t *ws_lists;                /* [2*ws_cf + 2] long cf list, short cf list, counts */
     long long ws_blocks_cf;           /* decode: capacity of ws_blocks          */
     double *ws_blocks;                /* [cf][2048] blocks before overlap-add   */
     /* gain-shape coder (use_vq) */
@@ -247,6 +252,7 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->ws_unit_bits = nullptr;
     h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
     h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr; h->ws_nkept = nullptr;
+    h->ws_lists = nullptr;
     memset(&h->T, 0, sizeof(h->T));
     int rc = PACX_OK;
 #define TRY(x) do { rc = (x); if (rc) { g_create_err = h->err; pacx_destroy(h); return rc; } } while (0)
@@ -471,11 +477,12 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
 static void free_ws(pacx_handle *h)
 {
     void *p[] = {h->ws_lines, h->ws_smr, h->ws_peaks, h->ws_npeaks, h->ws_overall, h->ws_chunks, h->ws_offs,
-                 h->ws_nkept, h->ws_sbr_mean};
+                 h->ws_nkept, h->ws_sbr_mean, h->ws_lists};
     for (void *q : p)
         if (q)
             (void)hipFree(q);
     h->ws_sbr_mean = nullptr;
+    h->ws_lists = nullptr;
     h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
     h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr; h->ws_nkept = nullptr;
     h->ws_cf = 0;
@@ -530,6 +537,7 @@ extern "C" int pacx_reserve(pacx_handle *h, int64_t n_cf)
     HIP_TRY(h, hipMalloc((void **)&h->ws_overall, n * PACX_SUB * sizeof(int32_t)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_chunks, (n / 256 + 2) * sizeof(long long)));
     HIP_TRY(h, hipMalloc((void **)&h->ws_offs, (n + 1) * sizeof(long long)));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_lists, (2 * n + 2) * sizeof(int32_t)));
     if (h->T.use_sbr)
         HIP_TRY(h, hipMalloc((void **)&h->ws_sbr_mean, n * PACX_SUB * sizeof(double)));
     h->ws_cf = n_cf;
@@ -621,7 +629,7 @@ extern "C" int pacx_smr_batch(pacx_handle *h, const pacx_pcm *in, const double *
     pacx_launch_side(h->T, v, in->dtype, fast, nullptr, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
                      nullptr, nullptr, st);
     pacx_launch_mask(h->T, nullptr, in->n_channels, n_cf, sb, 0, h->ws_peaks, h->ws_nkept, lines, smr,
-                     threshold, h->n_cu, st);
+                     threshold, h->n_cu, nullptr, nullptr, nullptr, st);
     if (n_peaks) {
         if (sb)
             HIP_TRY(h, hipMemcpyAsync(n_peaks, h->ws_npeaks, (size_t)n_cf * PACX_SUB * sizeof(int32_t),
@@ -727,8 +735,11 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
                          PACX_SUB, status, st);
     }
     HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));       /* join */
+    if (mixed)
+        pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,
+                                h->ws_lists + 2 * n_cf, st);
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
-                     nullptr, h->n_cu, st);
+                     nullptr, h->n_cu, h->ws_lists, h->ws_lists + n_cf, h->ws_lists + 2 * n_cf, st);
     /* BitAlloc + scale factors/mantissas (+ payload): one fused kernel for long frames */
     pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
                      mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, st);
@@ -812,8 +823,11 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
     /* the side chain also folds max|FFT| into the overall scale of SBR long blocks */
     pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
                      T.use_sbr ? h->ws_sbr_mean : nullptr, T.use_sbr ? overall_scale : nullptr, st);
+    if (mixed)
+        pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,
+                                h->ws_lists + 2 * n_cf, st);
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
-                     nullptr, h->n_cu, st);
+                     nullptr, h->n_cu, h->ws_lists, h->ws_lists + n_cf, h->ws_lists + 2 * n_cf, st);
     pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_smr, bit_alloc, status, st);
     pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
                    h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,

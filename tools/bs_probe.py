@@ -17,8 +17,7 @@ enc.reserve(view.n_cf)
 out = enc.alloc_outputs(view.n_cf, with_payload=True)
 def step():
     tr, fl = enc.transient_flags(planar, n_hops)
-    enc.encode(view, fl, out)
-    enc.pack(out, 2, out)
+    enc.encode_pack(view, fl, out)
     return fl
 for _ in range(3):
     fl = step()
