@@ -375,10 +375,18 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 {
     typedef typename PcmStage<DT>::elem E;
     const int SPAN = PACX_N_SHORT + (PACX_SUB - 1) * PACX_M_SHORT;
+    /* LDS: the FFT exchange tile, and one region that holds the raw samples and
+       then the intensities.  As in the long kernel the packed spectra never go to
+       LDS: sub-block g lives in lanes 8g..8g+7, lane r holds bins r + 8 k3, and
+       the partner bin 64 - k of the real-FFT split sits in lane 8g + (8-r)%8. */
+    constexpr int RAW_BYTES = (int)sizeof(E) * SPAN;
+    constexpr int B_BYTES = RAW_BYTES > PACX_SUB * 130 * 8 ? RAW_BYTES : PACX_SUB * 130 * 8;
     __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
-    __shared__ __attribute__((aligned(16))) cplx Z[PACX_SUB * 128];
-    __shared__ __attribute__((aligned(16))) double inten[PACX_SUB * 130];
-    __shared__ __attribute__((aligned(16))) E raw[SPAN];
+    __shared__ __attribute__((aligned(16))) char regB[B_BYTES];
+    __shared__ unsigned char pk_idx[PACX_SUB][64];
+    __shared__ int pk_cnt[PACX_SUB];
+    double *inten = (double *)regB;
+    E *raw = (E *)regB;
     const int lane = threadIdx.x;
     const long long cf = blockIdx.x;
     if (cf >= n_cf)
@@ -400,43 +408,79 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
         ev[n1] = make_double2(hann_sample<DT>(sub, i, hw, hwp), hann_sample<DT>(sub, i + 1, hw, hwp));
         od[n1] = make_double2(hann_sample<DT>(sub, i + 2, hw, hwp), hann_sample<DT>(sub, i + 3, hw, hwp));
     }
+    __syncthreads();                  /* raw consumed: region B becomes inten */
     fft64x8(ev, tile, T.w512, lane);
     fft64x8(od, tile, T.w512, lane);
-    cplx *Zg = Z + g * 128;
+    /* ev[k3] = E[k], od[k3] = O[k], k = r + 8 k3 (64-point spectra of the even / odd
+       samples).  Z[k] = E[k] + W128^k O[k], Z[k+64] = E[k] - W128^k O[k]; bins k and
+       k + 64 pair with Z[128-k] and Z[64-k], both made of E[m], O[m], m = 64 - k */
+    double *ig = inten + g * 130;
+    const int mirror = 8 * g + ((8 - r) & 7);
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) {
-        const int k = fft64_out_index(lane, k3);
+        const int k = r + 8 * k3;
         const cplx t = c_mul(T.w128[k], od[k3]);
-        Zg[k] = c_add(ev[k3], t);
-        Zg[k + 64] = c_sub(ev[k3], t);
+        const cplx zk = c_add(ev[k3], t), zk5 = c_sub(ev[k3], t);
+        cplx pe, po;
+        pe.x = bperm_f64(ev[7 - k3].x, mirror);
+        pe.y = bperm_f64(ev[7 - k3].y, mirror);
+        po.x = bperm_f64(od[7 - k3].x, mirror);
+        po.y = bperm_f64(od[7 - k3].y, mirror);
+        if (r == 0) {
+            pe = ev[(8 - k3) & 7];
+            po = od[(8 - k3) & 7];
+        }
+        const int m = (64 - k) & 63;
+        const cplx tm = c_mul(T.w128[m], po);
+        cplx zm = c_add(pe, tm), zm5 = c_sub(pe, tm);       /* Z[m], Z[m+64] */
+        if (k == 0) {
+            zm5 = zk;
+            zm = zk5;
+        }
+        ig[k] = pair_intensity(zk, zm5, T.w256[k], T.norm_short);
+        ig[k + 64] = pair_intensity(zk5, zm, T.w256[k + 64], T.norm_short);
+        if (k == 0)
+            ig[128] = pair_intensity(zk, zk, T.w256[128], T.norm_short);
     }
     __syncthreads();
-    double *ig = inten + g * 130;
-    for (int i = r; i <= 128; i += 8)
-        ig[i] = bin_intensity(Zg, i, 128, T.w256[i], T.norm_short);
-    __syncthreads();
 
-    PacxPeak *__restrict__ out = peaks + cf * PACX_MAX_PEAKS + g * 64;
+    /* strict local maxima of every sub-block, compacted per sub-block (bin numbers
+       in ascending order), then one masker per lane over the concatenated lists:
+       the log10 / atan work runs on full waves instead of once per scan step */
     int count = 0;
     for (int base = 0; base <= 128; base += 8) {
         const int i = base + r;
         bool pk = false;
-        double c = 0.0, l = 0.0;
         if (i >= 1 && i <= 128) {
-            c = ig[i];
-            l = ig[i - 1];
-            pk = (c > l) && (i == 128 || c > ig[i + 1]);
+            const double c = ig[i];
+            pk = (c > ig[i - 1]) && (i == 128 || c > ig[i + 1]);
         }
         const unsigned m = (unsigned)((__ballot(pk) >> (8 * g)) & 0xFFull);
-        if (pk) {
-            const int pos = count + __popc(m & ((1u << r) - 1u));
-            out[pos] = make_peak(l, c, i, T.fstep_short);
-        }
+        if (pk)
+            pk_idx[g][count + __popc(m & ((1u << r) - 1u))] = (unsigned char)i;
         count += __popc(m);
     }
     if (r == 0) {
+        pk_cnt[g] = count;
         n_peaks[cf * PACX_SUB + g] = count;
         n_kept_out[cf * PACX_SUB + g] = count;               /* short blocks: no pruning (<= 64 maskers) */
+    }
+    __syncthreads();
+    int start[PACX_SUB + 1];
+    start[0] = 0;
+#pragma unroll
+    for (int q = 0; q < PACX_SUB; ++q)
+        start[q + 1] = start[q] + pk_cnt[q];
+    const int total = start[PACX_SUB];
+    for (int t = lane; t < total; t += 64) {
+        int q = 0;
+#pragma unroll
+        for (int u = 1; u < PACX_SUB; ++u)
+            q += (t >= start[u]);
+        const int p = t - start[q];
+        const int i = pk_idx[q][p];
+        const double *iq = inten + q * 130;
+        peaks[cf * PACX_MAX_PEAKS + q * 64 + p] = make_peak(iq[i - 1], iq[i], i, T.fstep_short);
     }
 }
 
