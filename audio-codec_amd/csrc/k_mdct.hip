@@ -178,9 +178,16 @@ static void launch_mdct(const PacxTables &T, const PacxPcmView &in, const uint8_
                         int32_t *scale_out, int scale_stride, uint32_t *status, hipStream_t st)
 {
     const dim3 grid((unsigned)n_cf), block(64);
-    /* mixed = 2 / 3: the sine-window long frames were done by k_mdct_long_v2;
-       here the long kernel only takes transition-window frames (3: and skips
-       CUR frames), the short kernel only CUR frames (3) */
+    /* mixed = 4: every long frame was done by k_mdct_long_v2, only the CUR frames
+       are left (short kernel) */
+    if (mixed == 4) {
+        hipLaunchKernelGGL((k_mdct_short<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, 1, prewin, lines,
+                           scale_out, status);
+        return;
+    }
+    /* mixed = 2 / 3 (kept for callers that run v2 on sine-window frames only): the
+       long kernel takes the transition-window frames (3: and skips CUR frames),
+       the short kernel only CUR frames (3) */
     if (mixed == 2 || mixed == 3) {
         hipLaunchKernelGGL((k_mdct_long<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf,
                            mixed == 3 ? 3 : 2, prewin, lines, scale_out, scale_stride);

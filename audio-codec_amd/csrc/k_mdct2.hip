@@ -27,7 +27,7 @@
 
 /* WAVES waves per workgroup (8 KB tile each + 17 KB of tables), MINW = waves per
    SIMD the register allocator has to leave room for */
-template <int MDCT2_WAVES, int MINW, bool DBUF>
+template <int MDCT2_WAVES, int MINW, bool DBUF, bool ANYWIN>
 __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
     PacxTables T, PacxPcmView in, const uint8_t *__restrict__ flags, long long n_cf, int skip_cur,
     double *__restrict__ lines, int32_t *__restrict__ scale_out, int scale_stride,
@@ -84,9 +84,13 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
     int younger = -1;                /* vector-memory ops issued after the DMA being waited for */
     for (; cf < total; cf += stride) {
         const unsigned fl = flags ? flags[cf / n_ch] : 0u;
-        /* frames this kernel leaves to others: short-coded (CUR) ones when asked
-           to, and long frames with a transition window (k_mdct_long takes them) */
-        const bool mine = !(skip_cur && (fl & 2u)) && pacx_window_kind(fl) == 0;
+        /* frames this kernel leaves to k_mdct_short: short-coded (CUR) ones when asked to */
+        const bool mine = !(skip_cur && (fl & 2u));
+        /* transition windows (start / stop / start-stop) are not symmetric: their four
+           values per fold element come from the global table (L2 resident), scaled
+           like wsin */
+        const int kind = ANYWIN ? pacx_window_kind(fl) : 0;   /* !ANYWIN: launched without flags */
+        const double *__restrict__ gw = T.win_long + kind * PACX_N_LONG;
         /* output initialisation the whole-path entry points would otherwise spend two
            memset launches on: status word 0 and the 7 unused overall-scale slots of a
            long frame 0, for EVERY frame (kernels that follow on the stream overwrite /
@@ -127,15 +131,25 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
                 double re, im;
                 if (n1 < 4) {
                     const int i0 = 3 * Q - 1 - 2 * n, i1 = 3 * Q + 2 * n, i2 = Q - 1 - 2 * n, i3 = Q + 2 * n;
-                    const double wa = wsin[i3], wb = wsin[i2];       /* = w[i0], w[i1] */
-                    re = -fma(wb, code(i1), wa * code(i0));
-                    im = fma(wb, code(i2), -(wa * code(i3)));
+                    if (!ANYWIN || kind == 0) {
+                        const double wa = wsin[i3], wb = wsin[i2];       /* = w[i0], w[i1] */
+                        re = -fma(wb, code(i1), wa * code(i0));
+                        im = fma(wb, code(i2), -(wa * code(i3)));
+                    } else {
+                        re = -fma(gw[i1] * kscale, code(i1), (gw[i0] * kscale) * code(i0));
+                        im = fma(gw[i2] * kscale, code(i2), -((gw[i3] * kscale) * code(i3)));
+                    }
                 } else {
                     const int m = 2 * n - Q;
                     const int i0 = m, i1 = M - 1 - m, i2 = 2 * Q + m, i3 = 4 * Q - 1 - m;
-                    const double wa = wsin[i0], wb = wsin[i1];       /* = w[i3], w[i2] */
-                    re = fma(wa, code(i0), -(wb * code(i1)));
-                    im = -fma(wb, code(i2), wa * code(i3));
+                    if (!ANYWIN || kind == 0) {
+                        const double wa = wsin[i0], wb = wsin[i1];       /* = w[i3], w[i2] */
+                        re = fma(wa, code(i0), -(wb * code(i1)));
+                        im = -fma(wb, code(i2), wa * code(i3));
+                    } else {
+                        re = fma(gw[i0] * kscale, code(i0), -((gw[i1] * kscale) * code(i1)));
+                        im = -fma(gw[i2] * kscale, code(i2), (gw[i3] * kscale) * code(i3));
+                    }
                 }
                 v[n1] = c_mul(make_double2(re, im), twl[n]);
             }
@@ -218,8 +232,12 @@ void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8
         const long long cap = (long long)n_cu * (PER_CU);                                             \
         if (blocks > cap)                                                                             \
             blocks = cap;                                                                             \
-        hipLaunchKernelGGL((k_mdct_long_v2<W, MW, DB>), dim3((unsigned)blocks), dim3(64 * (W)), 0, st, T, \
-                           in, flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init);   \
+        if (flags)                                                                                    \
+            hipLaunchKernelGGL((k_mdct_long_v2<W, MW, DB, true>), dim3((unsigned)blocks), dim3(64 * (W)), 0, st, \
+                               T, in, flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init); \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_mdct_long_v2<W, MW, DB, false>), dim3((unsigned)blocks), dim3(64 * (W)), 0, st, \
+                               T, in, flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init); \
     } while (0)
     switch (variant) {
     case 1: LAUNCH(6, 3, 2, false); break;   /* 12 waves/CU in two workgroups                 */

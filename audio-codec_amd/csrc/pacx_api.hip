@@ -595,10 +595,7 @@ extern "C" int pacx_mdct_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t
     if (fast && !short_blocks && !(mode & PACX_MDCT_PREWINDOWED)) {
         pacx_launch_mdct_v2(h->T, v, frame_flags, n_cf, 0, lines, max_scale, 1, nullptr, h->n_cu,
                             (hipStream_t)stream);
-        if (frame_flags)       /* frames with a start/stop/start-stop window */
-            pacx_launch_mdct(h->T, v, in->dtype, fast, frame_flags, n_cf, 0, 2, 0, lines, max_scale, 1, nullptr,
-                             (hipStream_t)stream);
-        return post_launch(h, "pacx_mdct_batch");
+        return post_launch(h, "pacx_mdct_batch");     /* v2 handles all four long windows */
     }
     pacx_launch_mdct(h->T, v, in->dtype, fast, frame_flags, n_cf, short_blocks, 0,
                      (mode & PACX_MDCT_PREWINDOWED) ? 1 : 0, lines, max_scale,
@@ -728,7 +725,7 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
                             h->n_cu, st);
         if (mixed)
-            pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 3, 0, h->ws_lines, overall_scale,
+            pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale,
                              PACX_SUB, status, st);
     } else {
         pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
@@ -814,7 +811,7 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
                             h->n_cu, st);
         if (mixed)
-            pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 3, 0, h->ws_lines, overall_scale,
+            pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale,
                              PACX_SUB, status, st);
     } else {
         pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
