@@ -721,6 +721,161 @@ __global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *_
         n_bytes[cf] = nbytes;
 }
 
+/* ------------------------------------------------ fused tail, short frames */
+/* One workgroup of four waves per short-coded channel-frame: wave w owns
+ * sub-blocks 2w and 2w+1.  BitAlloc of both at once (one per half wave), then
+ * per sub-block the scale factors and mantissas (2 lines per lane, band maxima by
+ * masked wave reductions), then the payload: sub-block bit lengths meet in LDS,
+ * every wave ORs its two bodies into the frame's bit buffer at their offsets.
+ * Same helpers and arithmetic as k_bitalloc / k_quantize<128> / k_pack. */
+__global__ __launch_bounds__(256) void k_tail_short(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
+                                                   const int32_t *__restrict__ cf_list,
+                                                   const int32_t *__restrict__ cf_count,
+                                                   const double *__restrict__ smr,
+                                                   const double *__restrict__ lines,
+                                                   const int32_t *__restrict__ overall,
+                                                   int32_t *__restrict__ bit_alloc,
+                                                   int32_t *__restrict__ scale_factor,
+                                                   int32_t *__restrict__ mantissa, uint32_t *__restrict__ status,
+                                                   uint8_t *__restrict__ payload, int payload_stride,
+                                                   int32_t *__restrict__ n_bytes)
+{
+    __shared__ unsigned words[PACX_PACK_WORDS];
+    __shared__ double cp[4][2][32];
+    __shared__ int ba_s[PACX_SUB][8], sf_s[PACX_SUB][8], len_s[PACX_SUB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, l = lane & 31;
+    if ((long long)blockIdx.x >= (long long)*cf_count)
+        return;
+    const long long cf = cf_list[blockIdx.x];
+    const long long frame = cf / n_ch;
+    const unsigned fl = flags[frame];
+    const int nb = T.nb_short;
+    /* 1. BitAlloc: sub-block 2 wv + half on each half wave */
+    {
+        const int sb = 2 * wv + half;
+        const double budget = pacx_bit_budget(T.target_bps, PACX_M_SHORT, 1, (fl & 5u) != 0, T.n_scale_bits,
+                                              T.n_mant_size_bits, nb, T.use_vq, 0);
+        int max_mant = 1 << T.n_mant_size_bits;
+        if (max_mant > 16)
+            max_mant = 16;
+        const bool has = l < nb;
+        const long long off = cf * T.band_stride + sb * nb;
+        const double sv = has ? smr[off + l] : 0.0;
+        const int nl = has ? T.band_lines_short[l] : 0;
+        int bits = 0, cap = 0;
+        bitalloc_half(true, has, sv, nl, budget, max_mant, cp[wv][half], half, l, bits, cap);
+        if (has) {
+            bit_alloc[off + l] = bits;
+            ba_s[sb][l] = bits;
+        }
+        if (cap && status && l == 0)
+            atomicOr(&status[cf], 4u);
+    }
+    for (int i = tid; i < PACX_PACK_WORDS; i += 256)
+        words[i] = 0u;
+    __syncthreads();
+    /* 2. scale factors + mantissas of the wave's two sub-blocks */
+    const uchar2 b2 = *(const uchar2 *)(T.line_band_short + 2 * lane);
+    const int band0 = b2.x, band1 = b2.y;
+    int32_t mant[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sb = 2 * wv + q;
+        const int ov = overall[cf * PACX_SUB + sb];
+        const double up = (double)(1 << ov);
+        const long long loff = cf * PACX_M_LONG + sb * PACX_M_SHORT;
+        const double2 v = *(const double2 *)(lines + loff + 2 * lane);
+        const double x0 = v.x * up, x1 = v.y * up;
+        for (int b = 0; b < nb; ++b) {
+            double m = 0.0;
+            if (band0 == b)
+                m = fmax(m, fabs(x0));
+            if (band1 == b)
+                m = fmax(m, fabs(x1));
+            m = wave_max(m);
+            if (lane == b)
+                sf_s[sb][b] = pacx_scale_factor(m, T.n_scale_bits, ba_s[sb][b]);
+        }
+        wave_lds_fence();
+        const int a0 = ba_s[sb][band0], a1 = ba_s[sb][band1];
+        mant[q][0] = a0 ? pacx_mantissa(x0, sf_s[sb][band0], T.n_scale_bits, a0) : 0;
+        mant[q][1] = a1 ? pacx_mantissa(x1, sf_s[sb][band1], T.n_scale_bits, a1) : 0;
+        if (lane < nb)
+            scale_factor[cf * T.band_stride + sb * nb + lane] = sf_s[sb][lane];
+        if (mantissa)
+            *(int2 *)(mantissa + loff + 2 * lane) = make_int2(mant[q][0], mant[q][1]);
+        if (lane == 0) {
+            int len = T.n_scale_bits;
+            for (int b = 0; b < nb; ++b)
+                len += T.n_mant_size_bits + T.n_scale_bits + ba_s[sb][b] * T.band_lines_short[b];
+            len_s[sb] = len;
+        }
+    }
+    if (!payload)
+        return;
+    /* the reference drops the hop for every channel when any channel holds an
+       all-zero short sub-block (coder/pacfile.py:530-533) */
+    unsigned st = 0;
+    if (status)
+        for (int c = 0; c < n_ch; ++c)
+            st |= status[frame * n_ch + c];
+    if (st & 2u) {
+        if (tid == 0)
+            n_bytes[cf] = 0;
+        return;
+    }
+    __syncthreads();
+    /* 3. payload: flags, then the eight bodies back to back */
+    if (tid == 0) {
+        put_bits(words, 0, fl & 1u, 1);
+        put_bits(words, 1, (fl >> 1) & 1u, 1);
+        put_bits(words, 2, (fl >> 2) & 1u, 1);
+    }
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < PACX_SUB; ++q)
+        total += len_s[q];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sb = 2 * wv + q;
+        int pos = 3;
+        for (int u = 0; u < sb; ++u)
+            pos += len_s[u];
+        if (lane == 0)
+            put_bits(words, pos, (unsigned)overall[cf * PACX_SUB + sb], T.n_scale_bits);
+        /* band header offsets: exclusive prefix over the bands (lanes < nb) */
+        const int a_mine = (lane < nb) ? ba_s[sb][lane] : 0;
+        const int width = (lane < nb) ? T.n_mant_size_bits + T.n_scale_bits + a_mine * T.band_lines_short[lane] : 0;
+        int incl = width;
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += t;
+        }
+        const int my_off = pos + T.n_scale_bits + incl - width;
+        if (lane < nb) {
+            put_bits(words, my_off, (unsigned)(a_mine ? a_mine - 1 : 0), T.n_mant_size_bits);
+            put_bits(words, my_off + T.n_mant_size_bits, (unsigned)sf_s[sb][lane], T.n_scale_bits);
+        }
+        /* first mantissa bit of the band of each of this lane's two lines */
+        const int f0 = __shfl(my_off, band0, 64) + T.n_mant_size_bits + T.n_scale_bits;
+        const int f1 = __shfl(my_off, band1, 64) + T.n_mant_size_bits + T.n_scale_bits;
+        const int a0 = ba_s[sb][band0], a1 = ba_s[sb][band1];
+        if (a0)
+            put_bits(words, f0 + (2 * lane - T.band_lower_short[band0]) * a0, (unsigned)mant[q][0], a0);
+        if (a1)
+            put_bits(words, f1 + (2 * lane + 1 - T.band_lower_short[band1]) * a1, (unsigned)mant[q][1], a1);
+    }
+    __syncthreads();
+    const int nbytes = (total + 4 + 7) >> 3;
+    unsigned *dst = (unsigned *)(payload + cf * (long long)payload_stride);
+    for (int i = tid; i < (nbytes + 3) / 4; i += 256)
+        dst[i] = __builtin_bswap32(words[i]);
+    if (tid == 0)
+        n_bytes[cf] = nbytes;
+}
+
 /* ----------------------------------------------------------- body gather */
 #define SCAN_CHUNK 256
 
@@ -907,7 +1062,7 @@ void pacx_launch_pack(const PacxTables &T, const uint8_t *flags, int n_ch, long 
 void pacx_launch_tail(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf, const double *smr,
                       const double *lines, const int32_t *overall, int32_t *bit_alloc, int32_t *scale_factor,
                       int32_t *mantissa, uint32_t *status, uint8_t *payload, int payload_stride,
-                      int32_t *n_bytes, hipStream_t st)
+                      int32_t *n_bytes, const int32_t *list_short, const int32_t *count_short, hipStream_t st)
 {
     if (n_cf <= 0)
         return;
@@ -915,7 +1070,12 @@ void pacx_launch_tail(const PacxTables &T, const uint8_t *flags, int n_ch, long 
     hipLaunchKernelGGL(k_tail_long, dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch, n_cf, mixed, smr,
                        lines, overall, bit_alloc, scale_factor, mantissa, status, payload, payload_stride,
                        n_bytes);
-    if (mixed) {
+    if (mixed && list_short && T.nb_short <= 8) {
+        /* short frames: one fused workgroup each, over the compacted list */
+        hipLaunchKernelGGL(k_tail_short, dim3((unsigned)n_cf), dim3(256), 0, st, T, flags, n_ch, list_short,
+                           count_short, smr, lines, overall, bit_alloc, scale_factor, mantissa, status, payload,
+                           payload_stride, n_bytes);
+    } else if (mixed) {
         const long long units = n_cf * PACX_SUB;
         hipLaunchKernelGGL(k_bitalloc, dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st, T, flags, n_ch, n_cf,
                            0, 1, 1, smr, bit_alloc, status);

@@ -48,7 +48,7 @@ void pacx_launch_pack(const PacxTables &T, const uint8_t *flags, int n_ch, long 
 void pacx_launch_tail(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf, const double *smr,
                       const double *lines, const int32_t *overall, int32_t *bit_alloc, int32_t *scale_factor,
                       int32_t *mantissa, uint32_t *status, uint8_t *payload, int payload_stride,
-                      int32_t *n_bytes, hipStream_t st);
+                      int32_t *n_bytes, const int32_t *list_short, const int32_t *count_short, hipStream_t st);
 void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stride,
                         const int32_t *n_bytes, long long *chunk_buf, long long *offs_buf, uint8_t *body,
                         long long capacity, long long *total, hipStream_t st);
@@ -739,7 +739,8 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
                      nullptr, h->n_cu, h->ws_lists, h->ws_lists + n_cf, h->ws_lists + 2 * n_cf, st);
     /* BitAlloc + scale factors/mantissas (+ payload): one fused kernel for long frames */
     pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
-                     mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, st);
+                     mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_lists + n_cf,
+                     h->ws_lists + 2 * n_cf + 1, st);
     return post_launch(h, what);
 }
 
