@@ -57,65 +57,81 @@ __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, in
        runs only (201 - passes) mod L more passes.  Same result, ~10 passes. */
     int snap_bits = -1, snap_flip = -1, snap_pass = 0, snap_next = 1, stop_at = -1;
     unsigned snap_dropped = 0xFFFFFFFFu;
+    /* Everything up to the rounding ladder depends on the set of dropped bands only;
+       while the loop merely raises n_flip on a stable set it is reused, and the
+       all-pairs rank count behind ladder[n_flip-1] is made once per set. */
+    unsigned cache_key = 0xFFFFFFFEu;            /* never a value of `dropped` (bit 0 clear, rest set) */
+    bool valid = false, posf = false, have_rank = false;
+    unsigned pmask = 0;
+    int nd = 0, lt = 0, le = 0;
+    double want = 0.0, frac = 0.0;
     while (__ballot(!done)) {
-        const bool valid = has && !((dropped >> l) & 1u);
-        const unsigned vmask = (unsigned)(__ballot(valid) >> (32 * half));
-        const int nv = __popc(vmask);
-        const int pos = __popc(vmask & lt_mask);
-        const int total_i = half_sum_i(valid ? nl : 0);
-        double total = (double)total_i;
-        if (total_i == 0)
-            total = total + 1e-12;
-        if (valid)
-            c[pos] = (double)nl * s;
-        wave_lds_fence();
-        /* np.sum of c[0..nv) */
-        double sum;
-        if (nv < 8) {
-            sum = -0.0;
-            for (int i = 0; i < nv; ++i)
-                sum = sum + c[i];
-        } else {
-            const int n8 = nv - (nv & 7);
-            double r = 0.0;
-            if (l < 8) {
-                r = c[l];
-                for (int i = 8; i < n8; i += 8)
-                    r = r + c[i + l];
+        if (__ballot(dropped != cache_key)) {    /* wave-uniform: both halves recompute together */
+            cache_key = dropped;
+            have_rank = false;
+            valid = has && !((dropped >> l) & 1u);
+            const unsigned vmask = (unsigned)(__ballot(valid) >> (32 * half));
+            const int nv = __popc(vmask);
+            const int pos = __popc(vmask & lt_mask);
+            const int total_i = half_sum_i(valid ? nl : 0);
+            double total = (double)total_i;
+            if (total_i == 0)
+                total = total + 1e-12;
+            if (valid)
+                c[pos] = (double)nl * s;
+            wave_lds_fence();
+            /* np.sum of c[0..nv) */
+            double sum;
+            if (nv < 8) {
+                sum = -0.0;
+                for (int i = 0; i < nv; ++i)
+                    sum = sum + c[i];
+            } else {
+                const int n8 = nv - (nv & 7);
+                double r = 0.0;
+                if (l < 8) {
+                    r = c[l];
+                    for (int i = 8; i < n8; i += 8)
+                        r = r + c[i + l];
+                }
+                double t = r + __shfl_down(r, 1, 32);           /* lanes 0,2,4,6: r0+r1, r2+r3, ... */
+                double u = t + __shfl_down(t, 2, 32);           /* lanes 0,4 */
+                sum = u + __shfl_down(u, 4, 32);                /* lane 0 */
+                for (int i = n8; i < nv; ++i)
+                    sum = sum + c[i];
+                sum = __shfl(sum, 0, 32);
             }
-            double t = r + __shfl_down(r, 1, 32);           /* lanes 0,2,4,6: r0+r1, r2+r3, ... */
-            double u = t + __shfl_down(t, 2, 32);           /* lanes 0,4 */
-            sum = u + __shfl_down(u, 4, 32);                /* lane 0 */
-            for (int i = n8; i < nv; ++i)
-                sum = sum + c[i];
-            sum = __shfl(sum, 0, 32);
+            wave_lds_fence();
+            const double mean = sum / total;
+            want = budget / total + (1.0 / PACX_DB_PER_BIT) * (s - mean);
+            frac = (want - floor(want)) - 0.5;
+            posf = valid && frac > 0.0;
+            pmask = (unsigned)(__ballot(posf) >> (32 * half));
+            nd = __popc(pmask);
         }
-        wave_lds_fence();
-        const double mean = sum / total;
-        const double want = budget / total + (1.0 / PACX_DB_PER_BIT) * (s - mean);
-        const double frac = (want - floor(want)) - 0.5;
-        const bool posf = valid && frac > 0.0;
-        const unsigned pmask = (unsigned)(__ballot(posf) >> (32 * half));
-        const int nd = __popc(pmask);
         int new_bits = bits;
         int new_flip = n_flip;
+        if (__ballot(!have_rank && n_flip > 0 && n_flip <= nd)) {   /* ladder ranks of this set */
+            have_rank = true;
+            lt = 0;
+            le = 0;
+            for (int k = 0; k < 32; ++k) {
+                const double fk = __shfl(frac, k, 32);
+                if ((pmask >> k) & 1u) {
+                    lt += fk < frac;
+                    le += fk <= frac;
+                }
+            }
+        }
         if (n_flip > nd) {
             new_flip = n_flip - 1;                           /* bits keep their previous values */
         } else {
             double level = 0.0;
-            if (n_flip > 0) {                                /* ladder[n_flip-1]: rank select */
-                int lt = 0, le = 0;
-                for (int k = 0; k < 32; ++k) {
-                    const double fk = __shfl(frac, k, 32);
-                    if ((pmask >> k) & 1u) {
-                        lt += fk < frac;
-                        le += fk <= frac;
-                    }
-                }
-                const bool sel = posf && lt <= n_flip - 1 && n_flip - 1 < le;
-                const unsigned smask = (unsigned)(__ballot(sel) >> (32 * half));
-                level = __shfl(frac, smask ? __builtin_ctz(smask) : 0, 32);
-            }
+            const bool sel = n_flip > 0 && posf && lt <= n_flip - 1 && n_flip - 1 < le;
+            const unsigned smask = (unsigned)(__ballot(sel) >> (32 * half));
+            const double pick = __shfl(frac, smask ? __builtin_ctz(smask) : 0, 32);
+            if (n_flip > 0)
+                level = pick;                                /* ladder[n_flip-1] */
             if (valid)
                 new_bits = (int)rint(want - level);
         }
