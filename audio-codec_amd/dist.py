@@ -28,6 +28,16 @@ def shard_with_halo(pcm, world_size, rank, hop=1024):
     return out
 
 
+def shard_flags(flags, world_size, rank):
+    """Block-switching flags of this rank's frames.  `flags` holds one
+    (last, cur, next) byte per hop of the WHOLE stream: a frame's flags look two
+    hops back (coder/pacfile.py:732-741), so they are computed once for the
+    stream (pacx_transient_flags, per-hop independent) and sliced, not
+    recomputed per shard."""
+    lo, hi = shard_bounds(len(flags), world_size, rank)
+    return flags[lo:hi]
+
+
 def gather_bitstream(body, n_bytes_total, group=None, dst=0):
     """body: uint8 device (or CPU, for gloo) tensor holding this rank's packed
     '<L nBytes'+payload records in its first n_bytes_total bytes.  Rank `dst`

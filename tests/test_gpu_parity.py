@@ -616,3 +616,32 @@ def test_gather_body_small_and_large_paths(A):
                         for i, k in enumerate(nb) if k > 0)
         assert int(total.item()) == len(want)
         assert body[:len(want)].cpu().numpy().tobytes() == want
+
+
+def test_block_switched_shards_equal_whole(A, torch):
+    """Sharding a block-switched stream by hop ranges (one-hop PCM halo, flags
+    sliced from the whole-stream flags: audio-codec_amd/dist.py) gives the bytes
+    of the unsharded encode, for the scalar and the gain-shape + SBR coder."""
+    ex = load_excerpt("castanet")
+    pcm = np.ascontiguousarray(ex["pcm"][:48 * 1024])
+    sr = int(ex["sr"])
+    n_hops = len(pcm) // 1024
+    for vq in (False, True):
+        enc = A.engine.Encoder(sr, (96 if vq else 128) / (sr / 1000), use_vq=vq, use_sbr=vq)
+        stream = A.pacfile.device_stream(enc, pcm)
+        _, flags = enc.transient_flags(stream, n_hops)
+        flags = flags[:n_hops]
+        assert int(((flags >> 1) & 1).sum()) > 4            # the excerpt does switch blocks
+
+        def run(planar, fl):
+            view = A.engine.PcmView.stream(torch.as_tensor(planar, device=enc.device))
+            out = enc.encode_vq(view, fl) if vq else enc.encode_pack(view, fl)
+            nb = out["n_bytes"].cpu().numpy()
+            pl = out["payload"].cpu().numpy()
+            return [pl[i, :nb[i]].tobytes() for i in range(len(nb))]
+
+        whole = run(A.synth.planar_with_halo(pcm), flags)
+        parts = []
+        for rank in range(3):
+            parts += run(A.dist.shard_with_halo(pcm, 3, rank), A.dist.shard_flags(flags, 3, rank))
+        assert parts == whole
