@@ -60,3 +60,59 @@ def gather_bitstream(body, n_bytes_total, group=None, dst=0):
         return torch.cat([b[:n] for b, n in zip(bufs, sizes)])
     dist.gather(send, None, dst=dst, group=group)
     return None
+
+
+# ---- asynchronous, fixed-slot flavour (what bench.py uses for N > 1) -----------------
+HEADER = 8          # bytes: little-endian int64 = valid bytes that follow
+
+
+def slot_bytes(n_cf, target_bits_per_sample, hop=1024):
+    """Upper bound on one rank's body ('<L nBytes' + payload per cf) so that the
+    gather can use fixed-size slots with no size exchange: a channel-block never
+    exceeds its bit budget (long: target*hop bits; short frames are budgeted from
+    int(1.45*128) lines per sub-block, i.e. 1.45x) plus flags, per-band headers,
+    rounding and the 4-byte length."""
+    per_cf = int(np.ceil(target_bits_per_sample * hop * 1.45 / 8)) + 128
+    return HEADER + int(n_cf) * per_cf
+
+
+class BitstreamGather:
+    """Fixed-slot gather of every rank's packed body to rank `dst`, enqueued
+    asynchronously: no host synchronisation, no size exchange.  Each rank sends one
+    slot = [int64 valid bytes][body ... padding]; rank dst receives world slots and
+    can slice them later with unpack().  Two send buffers alternate so that the
+    gather of step i overlaps the encode of step i+1 (the caller must not reuse a
+    buffer before wait(k))."""
+
+    def __init__(self, slot, device, group=None, dst=0, depth=2):
+        self.group, self.dst, self.slot = group, dst, int(slot)
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.send = [torch.zeros(self.slot, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.recv = [[torch.empty(self.slot, dtype=torch.uint8, device=device) for _ in range(self.world)]
+                     if self.rank == dst else None for _ in range(depth)]
+        self.work = [None] * depth
+
+    def body(self, k):
+        """Where the encoder writes its records of step k (after the header)."""
+        return self.send[k][HEADER:]
+
+    def launch(self, k, total):
+        """total: int64 device tensor [1] = valid bytes in body(k) (device-side, no .item())."""
+        self.send[k][:HEADER].copy_(total.view(torch.uint8))
+        self.work[k] = dist.gather(self.send[k], self.recv[k], dst=self.dst, group=self.group, async_op=True)
+
+    def wait(self, k):
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+
+    def unpack(self, k):
+        """Rank dst, after wait(k): the concatenated bodies in rank order (uint8 tensor)."""
+        parts = []
+        for buf in self.recv[k]:
+            n = int(buf[:HEADER].view(torch.int64).item())
+            if n > self.slot - HEADER:
+                raise RuntimeError("a rank's body overflowed its gather slot")
+            parts.append(buf[HEADER:HEADER + n])
+        return torch.cat(parts)

@@ -82,8 +82,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
+        rehearsal = bool(os.environ.get("PACX_BENCH_ONE_GPU"))
+        if rehearsal:
+            # rehearsal of the N > 1 control flow on a 1-GPU box: every rank on cuda:0, the
+            # gather over gloo with host staging (RCCL refuses two ranks on one device)
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -100,9 +108,22 @@ def main():
     n_cf = view.n_cf
     enc.reserve(n_cf)
     out = enc.alloc_outputs(n_cf, with_payload=True)
-    cap = n_cf * 512
-    body = torch.empty(cap, dtype=torch.uint8, device=dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
+    gather = None
+    if world > 1:
+        # fixed-slot asynchronous gather of the packed bodies to rank 0 (RCCL): two send
+        # buffers alternate, the gather of step i overlaps the encode of step i+1, no host
+        # synchronisation and no size exchange inside a step
+        on_host = dist.get_backend() == "gloo"          # rehearsal only
+        gather = A.dist.BitstreamGather(A.dist.slot_bytes(n_cf, kbps / (SAMPLE_RATE / 1000)),
+                                        torch.device("cpu") if on_host else dev)
+        bodies = [gather.body(0), gather.body(1)]
+        if on_host:
+            host_bodies, bodies = bodies, [torch.empty_like(b, device=dev) for b in bodies]
+    else:
+        bodies = [torch.empty(n_cf * 512, dtype=torch.uint8, device=dev)]
+    cap = int(bodies[0].numel())
+    step_no = [0]
     import ctypes
     from audio_codec_amd.engine import _ptr
 
@@ -111,16 +132,26 @@ def main():
         vq_out = {k: out[k] for k in ("overall", "bit_alloc", "status", "payload", "n_bytes")}
 
     def device_step():
+        k = step_no[0] % len(bodies)
+        if gather is not None:
+            gather.wait(k)                      # the gather that last used this buffer (stream-level wait)
         if vq_kbps:
             enc.encode_vq(view, None, vq_out)
         else:
             enc.encode_pack(view, None, out)
         enc._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(out["payload"]), _ptr(out["n_bytes"]),
-                  _ptr(body), ctypes.c_int64(cap), _ptr(total), enc._stream())
+                  _ptr(bodies[k]), ctypes.c_int64(cap), _ptr(total), enc._stream())
+        if gather is not None:
+            if dist.get_backend() == "gloo":            # rehearsal: stage through the host
+                host_bodies[k].copy_(bodies[k])
+                gather.launch(k, total.cpu())
+            else:
+                gather.launch(k, total)
+        step_no[0] += 1
 
     # optional: the ~15 kernel launches of a step captured once into a hipGraph and replayed
     graph = None
-    if args.graph:
+    if args.graph and world == 1:
         device_step()
         torch.cuda.synchronize()
         try:
@@ -138,10 +169,12 @@ def main():
             graph.replay()
         else:
             device_step()
-        if world > 1:
-            A.dist.gather_bitstream(body, total.item())
 
     def sync_all():
+        if gather is not None:
+            for k in range(len(bodies)):
+                gather.wait(k)
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -214,7 +247,8 @@ def main():
                                    f"N=1024 long blocks, {kbps} kb/s/ch, "
                                    f"{'gain-shape PVQ' + (' + SBR' if kbps < 128 else '') if vq_kbps else 'scalar mantissas'}, "
                                    "int16 PCM resident in HBM; step = encode + "
-                                   ".pac bit packing + body assembly" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                                   ".pac bit packing + body assembly" +
+                                   (" + asynchronous RCCL gather of the bodies to rank 0" if world > 1 else ""),
                        "stereo_frames_per_s": world * n_frames * args.steps / dt,
                        "launch": "hipGraph replay of the captured step" if graph is not None else "direct launches",
                        "sharding": f"{world} x frame-range shards, no data-path collective"},

@@ -48,6 +48,17 @@ def _worker(rank, world, port, n_hops, out_dir):
         open(os.path.join(out_dir, "gathered.bin"), "wb").write(got.numpy().tobytes())
     else:
         assert got is None
+    # the asynchronous fixed-slot flavour bench.py uses: two steps in flight
+    slot = A.dist.slot_bytes((hi - lo) * 2, 128 / 48.0)
+    assert len(mine) + A.dist.HEADER <= slot
+    g = A.dist.BitstreamGather(slot, torch.device("cpu"))
+    for k in range(2):
+        g.body(k)[:len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+        g.launch(k, torch.tensor([len(mine)], dtype=torch.int64))
+    for k in range(2):
+        g.wait(k)
+        if rank == 0:
+            open(os.path.join(out_dir, f"gathered_async{k}.bin"), "wb").write(g.unpack(k).numpy().tobytes())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,3 +91,5 @@ def test_two_rank_gather_equals_single_stream(tmp_path):
             n_bytes, payload = po.pack_channel_block(p, (0, 0, 0), [po.encode_channel(x, p)])
             want += int(n_bytes).to_bytes(4, "little") + payload
     assert got == want
+    for k in range(2):
+        assert open(tmp_path / f"gathered_async{k}.bin", "rb").read() == want
