@@ -68,9 +68,11 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay a captured hipGraph of the step instead of launching its kernels one by one "
                          "(measured slower on ROCm 7.2: 0.408 vs 0.397 ms/step -- the queue is GPU-bound)")
-    ap.add_argument("--workload", choices=["scalar128", "vq128", "vq96"], default="scalar128",
+    ap.add_argument("--workload", choices=["scalar128", "vq128", "vq96", "bs128"], default="scalar128",
                     help="scalar128 = BASELINE configs[1] (the headline); vq128 / vq96 = the gain-shape "
-                         "coder of configs[3] (vq96 with SBR) on the same synthetic stream")
+                         "coder of configs[3] (vq96 with SBR) on the same synthetic stream; bs128 = "
+                         "configs[2]: block switching on, the castanet excerpt of tests/golden tiled to "
+                         "--frames hops (44.1 kHz), transient detector inside the step")
     args = ap.parse_args()
 
     import torch
@@ -98,13 +100,27 @@ def main():
 
     # ---- workload: device-resident before any timing
     n_frames = args.frames
-    pcm = A.synth.stream(n_frames, N_CH, seed=A.synth.SEED + rank)
-    vq_kbps = {"scalar128": None, "vq128": 128, "vq96": 96}[args.workload]
+    vq_kbps = {"scalar128": None, "vq128": 128, "vq96": 96, "bs128": None}[args.workload]
     kbps = vq_kbps or KBPS
-    enc = A.engine.Encoder(SAMPLE_RATE, kbps / (SAMPLE_RATE / 1000), use_vq=bool(vq_kbps),
+    block_switched = args.workload == "bs128"
+    sample_rate = SAMPLE_RATE
+    if block_switched:
+        ex = np.load(os.path.join(ROOT, "tests", "golden", "excerpt_castanet.npz"))
+        sample_rate = int(ex["sr"])
+        reps = -(-n_frames * 1024 // len(ex["pcm"]))
+        pcm = np.ascontiguousarray(np.tile(ex["pcm"], (reps, 1))[:n_frames * 1024])
+    else:
+        pcm = A.synth.stream(n_frames, N_CH, seed=A.synth.SEED + rank)
+    enc = A.engine.Encoder(sample_rate, kbps / (sample_rate / 1000), use_vq=bool(vq_kbps),
                            use_sbr=bool(vq_kbps and vq_kbps < 128))
     planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=dev)
     view = A.engine.PcmView.stream(planar)
+    hop_view = None
+    if block_switched:      # the hops as the transient detector sees them (hop h = planar hop h+1)
+        hop_view = A._lib.PacxPcm(planar.data_ptr() + 2 * 1024, A._lib.PCM_I16, N_CH, n_frames, 1024,
+                                  planar.shape[1], 1)
+        tr_buf = torch.empty(n_frames, dtype=torch.uint8, device=dev)
+        fl_buf = torch.empty(n_frames + 2, dtype=torch.uint8, device=dev)
     n_cf = view.n_cf
     enc.reserve(n_cf)
     out = enc.alloc_outputs(n_cf, with_payload=True)
@@ -115,7 +131,7 @@ def main():
         # buffers alternate, the gather of step i overlaps the encode of step i+1, no host
         # synchronisation and no size exchange inside a step
         on_host = dist.get_backend() == "gloo"          # rehearsal only
-        gather = A.dist.BitstreamGather(A.dist.slot_bytes(n_cf, kbps / (SAMPLE_RATE / 1000)),
+        gather = A.dist.BitstreamGather(A.dist.slot_bytes(n_cf, kbps / (sample_rate / 1000)),
                                         torch.device("cpu") if on_host else dev)
         bodies = [gather.body(0), gather.body(1)]
         if on_host:
@@ -137,6 +153,9 @@ def main():
             gather.wait(k)                      # the gather that last used this buffer (stream-level wait)
         if vq_kbps:
             enc.encode_vq(view, None, vq_out)
+        elif block_switched:
+            enc._call("pacx_transient_flags", ctypes.byref(hop_view), _ptr(tr_buf), _ptr(fl_buf), enc._stream())
+            enc.encode_pack(view, fl_buf[:n_frames], out)
         else:
             enc.encode_pack(view, None, out)
         enc._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(out["payload"]), _ptr(out["n_bytes"]),
@@ -229,7 +248,10 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "audio channel-frames/s encode (48 kHz, 1024-line long blocks, 128 kb/s/ch)" if not vq_kbps
+            "metric": "audio channel-frames/s encode (48 kHz, 1024-line long blocks, 128 kb/s/ch)"
+                      if not (vq_kbps or block_switched)
+                      else "audio channel-frames/s encode, block switching on (castanet excerpt tiled, 44.1 kHz, "
+                           "128 kb/s/ch)" if block_switched
                       else f"audio channel-frames/s encode, gain-shape PVQ{' + SBR' if vq_kbps < 128 else ''} "
                            f"(48 kHz, 1024-line long blocks, {vq_kbps} kb/s/ch)",
             "value": world * n_cf * args.steps / dt,
@@ -242,9 +264,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"{n_frames} synthetic 48 kHz stereo frames per GPU ({n_cf} channel-frames), "
-                                   f"N=1024 long blocks, {kbps} kb/s/ch, "
+            "data": "castanet excerpt of tests/golden, tiled" if block_switched else "synthetic",
+            "config": {"workload": (f"{n_frames} stereo frames per GPU of the castanet excerpt tiled "
+                                    f"({n_cf} channel-frames, 44.1 kHz), long + short blocks by the transient "
+                                    "detector (inside the step), " if block_switched else
+                                    f"{n_frames} synthetic 48 kHz stereo frames per GPU ({n_cf} channel-frames), "
+                                    "N=1024 long blocks, ") + f"{kbps} kb/s/ch, "
                                    f"{'gain-shape PVQ' + (' + SBR' if kbps < 128 else '') if vq_kbps else 'scalar mantissas'}, "
                                    "int16 PCM resident in HBM; step = encode + "
                                    ".pac bit packing + body assembly" +
@@ -262,7 +287,18 @@ def main():
                          "mdct_cf_per_s": n_cf / (mdct_ms * 1e-3)},
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(256, vq_kbps) if vq_kbps else cpu_baseline()
+            if block_switched:
+                from oracle import pac_oracle as po
+                n_hops_cpu = 192
+                t0 = time.perf_counter()
+                po.encode_stream(pcm[:n_hops_cpu * 1024], sample_rate, KBPS, block_switching=True)
+                dtc = time.perf_counter() - t0
+                res["cpu_baseline"] = {"value": (n_hops_cpu + 2) * N_CH / dtc, "unit": "channel-frames/s",
+                                       "cores": 1, "kind": "port",
+                                       "sample": f"first {n_hops_cpu} hops of the same tiled stream through "
+                                                 f"oracle/pac_oracle.py encode_stream (block switching on), {dtc:.1f} s"}
+            else:
+                res["cpu_baseline"] = cpu_baseline(256, vq_kbps) if vq_kbps else cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
