@@ -317,6 +317,96 @@ __device__ __forceinline__ void vq_leaf(const VqView &V, VqOut &o, const double 
     vq_emit(o, 0, idx, width, lane);
 }
 
+/* ---- two sibling leaves at once -------------------------------------------- */
+/* 93 % of the leaves are the two children of a bottom split (5..20 components
+ * each): the mid leaf runs on lanes 0-31, the side leaf on lanes 32-63, same
+ * code, per-half pulse count and index width.  n <= 32; both leaves have n
+ * components.  Same arithmetic as vq_leaf, component l of each vector in lane l
+ * of its half. */
+__device__ __forceinline__ double half_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1)
+        v = v + __shfl_xor(v, off, 32);
+    return v;
+}
+
+__device__ __forceinline__ void vq_leaf_pair(const VqView &V, VqOut &o, const double *mid, const double *side,
+                                             int n, int bits_mid, int bits_side, int lane)
+{
+    const int h = lane >> 5, l = lane & 31;
+    const int bits = h ? bits_side : bits_mid;
+    const int K = V.k_of[n * 33 + bits];
+    const int width = V.w_of[n * 33 + bits];
+    const double x = (l < n) ? (h ? side[l] : mid[l]) : 0.0;
+    /* L1 norm in np.sum order (n <= 32: sequential below 8, else eight interleaved
+       accumulators, fixed tree, scalar tail) */
+    const double ax = fabs(x);
+    double l1;
+    if (n < 8) {
+        l1 = -0.0;
+        for (int i = 0; i < n; ++i)
+            l1 = l1 + __shfl(ax, i, 32);
+    } else {
+        const int n8 = n - (n & 7);
+        double r = ax;                                   /* lanes 0..7: a[j] + a[8+j] + ... */
+        for (int i = 8; i < n8; i += 8) {
+            const double t = __shfl_down(ax, i, 32);
+            r = r + t;
+        }
+        const double t = r + __shfl_down(r, 1, 32);
+        const double u = t + __shfl_down(t, 2, 32);
+        l1 = u + __shfl_down(u, 4, 32);
+        l1 = __shfl(l1, 0, 32);
+        for (int i = n8; i < n; ++i)
+            l1 = l1 + __shfl(ax, i, 32);
+    }
+    const bool ok = l1 > 0.0;                            /* per half */
+    const double kd = (double)K;
+    const double tgt = ok ? fabs(kd * x / l1) : 0.0;
+    double y = floor(tgt);
+    const int missing = K - (int)half_sum_f64((l < n) ? y : 0.0);
+    {
+        const double r = (l < n) ? (tgt - y) : -1.0;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double rj = __shfl(r, j, 32);
+            rank += (rj > r) || (rj == r && j < l);
+        }
+        if (l < n && rank < missing)
+            y += 1.0;
+    }
+    int a = (l < n && x != 0.0 && ok) ? (int)y : 0;
+    int incl = a;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const int t = __shfl_up(incl, off, 32);
+        if (l >= off)
+            incl += t;
+    }
+    const long long k = (long long)K - (incl - a);
+    unsigned long long term = 0;
+    if (a >= 1) {
+        const int ld = n - l;
+        term = vq_N(V, ld - 1, k);
+        term += 2ull * (vq_P(V, ld - 1, k - 1) - vq_P(V, ld - 1, k - a));
+        if (x < 0.0)
+            term += vq_N(V, ld - 1, k - a);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1)
+        term = term + (unsigned long long)__shfl_xor((long long)term, off, 32);
+    /* mid first, then side (coder/gain_shape_quantize.py:372-393) */
+    const unsigned long long idx_mid = (unsigned long long)__shfl((long long)term, 0, 64);
+    const unsigned long long idx_side = (unsigned long long)__shfl((long long)term, 32, 64);
+    const int w_mid = __shfl(width, 0, 64), w_side = __shfl(width, 32, 64);
+    const unsigned long long okm = __ballot(ok);
+    if (!(okm & 1ull) || !((okm >> 32) & 1ull))
+        o.flags |= PACX_ST_VQ_UNDEFINED;                  /* an all-zero half: NaN pulses in the reference */
+    vq_emit(o, 0, (okm & 1ull) ? idx_mid : 0ull, w_mid, lane);
+    vq_emit(o, 0, ((okm >> 32) & 1ull) ? idx_side : 0ull, w_side, lane);
+}
+
 /* ---- the split tree of one band ------------------------------------------- */
 /* region: LDS doubles for the mid/side vectors of every depth (2 n0 + 4 VQ_DEPTH:
  * depth d takes 2*ceil(n_d/2)); a leaf borrows the still unused tail of it for
@@ -398,7 +488,12 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
             /* children live one level down */
             reg = reg + 2 * half;
             depth += 1;
-            if (a_mid > 0) {
+            if (a_mid > 0 && a_mid <= PACX_VQ_SPLIT_BITS && a_side > 0 && a_side <= PACX_VQ_SPLIT_BITS &&
+                half >= 2 && half <= 32) {
+                /* both children are small leaves: code them side by side */
+                vq_leaf_pair(V, o, mv, sv, half, a_mid, a_side, lane);
+                stack[2 * (depth - 1) + 1] = -1;            /* side done */
+            } else if (a_mid > 0) {
                 cur = mv;
                 n = half;
                 bits = a_mid;
