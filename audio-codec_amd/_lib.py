@@ -46,6 +46,7 @@ class PacxConfig(ctypes.Structure):
         ("use_vq", ctypes.c_int32),
         ("use_sbr", ctypes.c_int32),
         ("half_log2", c_double_p),
+        ("vq_log2_tan", c_double_p),
         ("log_mu1", ctypes.c_double),
         ("sbr_gauss", c_double_p),
         ("sbr_gauss_radius", ctypes.c_int32),

@@ -51,6 +51,7 @@ struct VqView {
     const double *half_log2;
     int l_max;
     double log_mu1;                    /* np.log(1 + 255) */
+    const double *log2_tan;            /* [2^12 - 1] log2(tan(theta_q) + eps), see pacx_config */
     /* work order: bands by decreasing size (SBR-omitted long bands count as 1);
        the first VQ_WAVES entries go to waves 0.. statically, the rest by
        ticket, so wave w only needs scratch for the (w+1)-th largest band */
@@ -453,6 +454,7 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
             /* QuantizeUniform / DequantizeUniform of theta/(pi/2) */
             const double tn = theta / half_pi;
             double theta_q = 0.0;
+            unsigned long long theta_code = 0;
             if (a_theta <= 0) {
                 vq_emit(o, 0, 0, a_theta < 0 ? 0 : a_theta, lane);
             } else if (a_theta > 62) {
@@ -468,6 +470,7 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
                     code = (unsigned long long)floor((factor * tn + 1.0) * 0.5);
                 }
                 vq_emit(o, 0, code, a_theta, lane);
+                theta_code = code;
                 const unsigned long long mag = code & ((1ull << (a_theta - 1)) - 1ull);
                 const double den = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
                 double dq = (double)(2ull * mag) / den;
@@ -478,7 +481,14 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
             /* bit_allocation_ms */
             int a_mid = 0;
             if (theta_q != 0.0) {
-                const double v = ((double)a_rest - (double)(half - 1) * log2(tan(fabs(theta_q)) + PACX_EPS)) / 2.0;
+                /* log2(tan(theta_q) + eps): quantised angles of up to 12 bits come from the
+                   table the caller evaluated (one scalar load instead of tan + log2) */
+                double lt;
+                if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta_q > 0.0)
+                    lt = V.log2_tan[((1 << (a_theta - 1)) - 1) + (int)theta_code];
+                else
+                    lt = log2(tan(fabs(theta_q)) + PACX_EPS);
+                const double v = ((double)a_rest - (double)(half - 1) * lt) / 2.0;
                 const double f = floor(v);
                 a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
             }
@@ -843,10 +853,11 @@ size_t pacx_vq_view_size(void) { return sizeof(VqView); }
 /* sizes_long / sizes_short: vector dimension of every band as the coder sees it */
 void pacx_vq_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
                        const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
-                       double log_mu1, const int32_t *sizes_long, int nb_long, const int32_t *sizes_short,
-                       int nb_short)
+                       double log_mu1, const double *log2_tan, const int32_t *sizes_long, int nb_long,
+                       const int32_t *sizes_short, int nb_short)
 {
     VqView *v = (VqView *)dst;
+    v->log2_tan = log2_tan;
     auto sort_desc = [](const int32_t *sz, int nb, uint8_t *order) {
         for (int i = 0; i < nb; ++i)
             order[i] = (uint8_t)i;

@@ -40,6 +40,7 @@ struct VqDecView {
     const uint8_t *w_of;
     const double *half_log2;
     int l_max;
+    const double *log2_tan;       /* as VqView::log2_tan                       */
     const double *gauss;          /* [2r+1] normalised weights, centre at r   */
     int gauss_r;
     const double *line_freq;      /* [1024] (k + 1/2) * sampleRate / 2048      */
@@ -224,8 +225,10 @@ __device__ __forceinline__ void vqd_shape(const VqDecView &V, const unsigned *wo
             if (a_rest < 0)
                 a_rest = 0;
             double theta = 0.0;
+            unsigned long long theta_code = 0;
             if (a_theta > 0 && a_theta <= 62) {
                 const unsigned long long code = vqd_get(words, pos, a_theta);
+                theta_code = code;
                 const unsigned long long mag = code & ((1ull << (a_theta - 1)) - 1ull);
                 const double den = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
                 double dq = (double)(2ull * mag) / den;
@@ -238,7 +241,12 @@ __device__ __forceinline__ void vqd_shape(const VqDecView &V, const unsigned *wo
             pos += a_theta > 0 ? a_theta : 0;
             int a_mid = 0;
             if (theta != 0.0) {
-                const double v = ((double)a_rest - (double)(half - 1) * log2(tan(fabs(theta)) + PACX_EPS)) / 2.0;
+                double lt;
+                if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta > 0.0)
+                    lt = V.log2_tan[((1 << (a_theta - 1)) - 1) + (int)theta_code];
+                else
+                    lt = log2(tan(fabs(theta)) + PACX_EPS);
+                const double v = ((double)a_rest - (double)(half - 1) * lt) / 2.0;
                 const double f = floor(v);
                 a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
             }
@@ -581,9 +589,10 @@ size_t pacx_vqdec_view_size(void) { return sizeof(VqDecView); }
 
 void pacx_vqdec_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
                           const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
-                          const double *gauss, int gauss_r, const double *line_freq)
+                          const double *log2_tan, const double *gauss, int gauss_r, const double *line_freq)
 {
     VqDecView *v = (VqDecView *)dst;
+    v->log2_tan = log2_tan;
     v->n_tab = n_tab;
     v->p_tab = p_tab;
     v->row_off = row_off;

@@ -74,7 +74,7 @@ void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const
 size_t pacx_vqdec_view_size(void);
 void pacx_vqdec_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
                           const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
-                          const double *gauss, int gauss_r, const double *line_freq);
+                          const double *log2_tan, const double *gauss, int gauss_r, const double *line_freq);
 void pacx_launch_vq_dec(const PacxTables &T, const void *view, long long n_cf, const uint8_t *payload,
                         int payload_stride, const long long *offsets, const int32_t *n_bytes,
                         uint8_t *cf_flags, int32_t *overall, int32_t *bit_alloc, double *lines,
@@ -89,8 +89,8 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
 size_t pacx_vq_view_size(void);
 void pacx_vq_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
                        const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
-                       double log_mu1, const int32_t *sizes_long, int nb_long, const int32_t *sizes_short,
-                       int nb_short);
+                       double log_mu1, const double *log2_tan, const int32_t *sizes_long, int nb_long,
+                       const int32_t *sizes_short, int nb_short);
 
 #define PACX_PAYLOAD_STRIDE 2192
 #define PACX_VQ_UNIT_WORDS 548
@@ -438,8 +438,21 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         std::vector<int32_t> sizes_long(cfg->band_lines_long, cfg->band_lines_long + T.nb_long);
         for (int b = T.first_omitted; b < T.nb_long; ++b)
             sizes_long[b] = 1;
+        /* log2(tan(theta_q) + eps) of the quantised split angles (bit_allocation_ms) */
+        std::vector<double> lt((1u << PACX_VQ_THETA_TABLE_BITS) - 1, 0.0);
+        if (cfg->vq_log2_tan) {
+            memcpy(lt.data(), cfg->vq_log2_tan, sizeof(double) * lt.size());
+        } else {
+            for (int a = 1; a <= PACX_VQ_THETA_TABLE_BITS; ++a)
+                for (long long code = 1; code < (1ll << (a - 1)); ++code) {
+                    const double th = ((double)(2 * code) / (double)((1ll << a) - 1)) * 1.5707963267948966;
+                    lt[((1u << (a - 1)) - 1) + code] = log2(tan(fabs(th)) + PACX_EPS);
+                }
+        }
+        const double *d_lt;
+        TRY(upload(h, lt.data(), lt.size(), &d_lt));
         pacx_vq_view_fill(h->vq_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max,
-                          cfg->log_mu1 != 0.0 ? cfg->log_mu1 : log(256.0), sizes_long.data(), T.nb_long,
+                          cfg->log_mu1 != 0.0 ? cfg->log_mu1 : log(256.0), d_lt, sizes_long.data(), T.nb_long,
                           cfg->band_lines_short, T.nb_short);
         /* decode side: Gaussian weights of gaussian_filter1d(sigma=200) (radius
            int(4*200 + 0.5)) and the MDCT line frequencies of Decode_SBR */
@@ -467,7 +480,7 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         TRY(upload(h, gw.data(), gw.size(), &d_gw));
         TRY(upload(h, lf.data(), lf.size(), &d_lf));
         h->vqdec_view.resize(pacx_vqdec_view_size());
-        pacx_vqdec_view_fill(h->vqdec_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max, d_gw, gr, d_lf);
+        pacx_vqdec_view_fill(h->vqdec_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max, d_lt, d_gw, gr, d_lf);
     }
 #undef TRY
     *out = h;

@@ -23,6 +23,7 @@
 #define PACX_DB_PER_BIT 6.2        /* coder/bitalloc.py:61                         */
 #define PACX_EPS 2.220446049250313e-16 /* np.finfo(float).eps, coder/psychoac.py:20 */
 #define PACX_VQ_SPLIT_BITS 32      /* coder/gain_shape_quantize.py:27              */
+#define PACX_VQ_THETA_TABLE_BITS 12 /* split angles of up to this many bits: log2(tan) tabulated */
 
 /* A0 -- coder/pcmfile.py:89-99 + coder/quantize.py:82-95:
  * value = +-(2*(|c| & 32767)) / 65535 with a correctly rounded division

@@ -112,6 +112,7 @@ class Encoder:
         cfg.use_vq, cfg.use_sbr = int(self.use_vq), int(self.use_sbr)
         l_max = int(max(np.max(self.sfBands.nLines), np.max(self.sfBandsShort.nLines)))
         cfg.half_log2 = f64("hl2", tables.half_log2(l_max))
+        cfg.vq_log2_tan = f64("lt", tables.vq_log2_tan())
         cfg.log_mu1 = tables.log_mu1()
         gw, gr = tables.sbr_gauss()
         cfg.sbr_gauss, cfg.sbr_gauss_radius = f64("gw", gw), gr

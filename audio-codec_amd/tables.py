@@ -107,3 +107,23 @@ def sbr_gauss(sigma=200, truncate=4.0):
     j = np.arange(-r, r + 1)
     w = np.exp(-0.5 / (sigma * sigma) * j ** 2)
     return w / w.sum(), r
+
+
+VQ_THETA_TABLE_BITS = 12
+
+
+def vq_log2_tan(max_bits=VQ_THETA_TABLE_BITS):
+    """log2(tan(theta_q) + eps) for every quantised split angle of up to max_bits
+    bits, evaluated exactly as bit_allocation_ms does
+    (coder/gain_shape_quantize.py:302-309 with theta_q =
+    DequantizeUniform(code, a) * (pi/2), coder/quantize.py:39-57).  Layout: the
+    2^(a-1) non-negative codes of width a start at offset 2^(a-1) - 1."""
+    eps = np.finfo(float).eps
+    out = np.zeros((1 << max_bits) - 1)
+    for a in range(1, max_bits + 1):
+        base = (1 << (a - 1)) - 1
+        for code in range(1 << (a - 1)):
+            theta = (1 * 2 * code / (2 ** a - 1)) * (np.pi / 2)
+            if theta != 0:
+                out[base + code] = np.log2(np.tan(abs(theta)) + eps)
+    return out

@@ -131,6 +131,9 @@ typedef struct pacx_config {
     int32_t use_vq;
     int32_t use_sbr;
     const double *half_log2;        /* optional [max band lines + 1]: 0.5*np.log2(L) */
+    const double *vq_log2_tan;      /* optional [2^12 - 1]: log2(tan(theta_q) + eps) of every
+                                       quantised split angle of <= 12 bits; the codes of width a
+                                       start at 2^(a-1) - 1 (bit_allocation_ms, :302-309)       */
     double log_mu1;                 /* np.log(256.0) of mu_law_fn; 0 = compute       */
     /* decode side of an SBR file (coder/codec.py:147, 163-164), optional: */
     const double *sbr_gauss;        /* [2r+1] normalised weights of gaussian_filter1d(sigma=200) */
