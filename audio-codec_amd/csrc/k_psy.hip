@@ -47,20 +47,6 @@ __device__ __forceinline__ double hann_sample(const typename PcmStage<DT>::elem 
     }
 }
 
-/* intensity of real-FFT bin i from the packed complex spectrum Z (period P) */
-__device__ __forceinline__ double bin_intensity(const cplx *Z, int i, int P, cplx w, double norm)
-{
-    const cplx a = Z[i & (P - 1)];
-    const cplx bz = Z[(P - i) & (P - 1)];
-    const cplx s = make_double2(a.x + bz.x, a.y - bz.y);      /* a + conj(b) */
-    const cplx d = make_double2(a.x - bz.x, a.y + bz.y);      /* a - conj(b) */
-    const cplx wd = c_mul(w, d);
-    const double xr = 0.5 * (s.x + wd.y), xi = 0.5 * (s.y - wd.x);
-    /* |X|^2 directly; the reference squares abs(x_fft) = hypot(re, im), equal to
-       this within an ulp or two */
-    return norm * fma(xr, xr, xi * xi);
-}
-
 /* one tonal masker from bins f-1, f (coder/psychoac.py:321-328, :61-68) */
 __device__ __forceinline__ PacxPeak make_peak(double left, double centre, int f, double fstep)
 {

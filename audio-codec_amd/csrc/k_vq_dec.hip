@@ -631,8 +631,8 @@ void pacx_launch_vq_dec(const PacxTables &T, const void *view, long long n_cf, c
     const size_t smem = fixed + (size_t)VQD_WAVES * A.scr_len * 8;
     hipLaunchKernelGGL(k_vq_dec, dim3((unsigned)n_cf), dim3(64 * VQD_WAVES), smem, st, T, V, A);
     if (T.use_sbr) {
-        const int cut = 0;   /* sizes below use the worst case n_omit = 1024 */
-        (void)cut;
+        /* LDS sized for the worst case (every line above the cut): lines, mirrored
+           envelope, smoothed envelope, interpolation ordinates */
         const size_t s2 = (size_t)(PACX_M_LONG + (2 * PACX_M_LONG + 2 * V.gauss_r) + PACX_M_LONG + PACX_M_LONG + 2) * 8;
         hipLaunchKernelGGL(k_sbr_recon, dim3((unsigned)n_cf), dim3(SBR_THREADS), s2, st, T, V, n_cf, sbr_flag, lines);
     }
