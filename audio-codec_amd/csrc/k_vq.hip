@@ -318,28 +318,18 @@ __device__ __forceinline__ void vq_leaf(const VqView &V, VqOut &o, const double 
     vq_emit(o, 0, idx, width, lane);
 }
 
-/* ---- two sibling leaves at once -------------------------------------------- */
+/* ---- several small leaves at once ------------------------------------------ */
 /* 93 % of the leaves are the two children of a bottom split (5..20 components
- * each): the mid leaf runs on lanes 0-31, the side leaf on lanes 32-63, same
- * code, per-half pulse count and index width.  n <= 32; both leaves have n
- * components.  Same arithmetic as vq_leaf, component l of each vector in lane l
- * of its half. */
-__device__ __forceinline__ double half_sum_f64(double v)
+ * each).  A group of W lanes (W = 32: two leaves per wave, W = 16: four) codes
+ * one leaf: component l of the vector in lane l of its group, the group's own
+ * pulse count K.  Same arithmetic and the same summation orders as vq_leaf (an
+ * xor butterfly over W lanes with zeros in the unused ones adds in the order of
+ * the 64-lane one).  Returns the enumeration index in every lane of the group;
+ * ok = false for an all-zero vector (NaN pulses in the reference). */
+template <int W>
+__device__ __forceinline__ unsigned long long vq_leaf_group(const VqView &V, double x, int n, int K, int l,
+                                                            bool &ok)
 {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1)
-        v = v + __shfl_xor(v, off, 32);
-    return v;
-}
-
-__device__ __forceinline__ void vq_leaf_pair(const VqView &V, VqOut &o, const double *mid, const double *side,
-                                             int n, int bits_mid, int bits_side, int lane)
-{
-    const int h = lane >> 5, l = lane & 31;
-    const int bits = h ? bits_side : bits_mid;
-    const int K = V.k_of[n * 33 + bits];
-    const int width = V.w_of[n * 33 + bits];
-    const double x = (l < n) ? (h ? side[l] : mid[l]) : 0.0;
     /* L1 norm in np.sum order (n <= 32: sequential below 8, else eight interleaved
        accumulators, fixed tree, scalar tail) */
     const double ax = fabs(x);
@@ -347,41 +337,45 @@ __device__ __forceinline__ void vq_leaf_pair(const VqView &V, VqOut &o, const do
     if (n < 8) {
         l1 = -0.0;
         for (int i = 0; i < n; ++i)
-            l1 = l1 + __shfl(ax, i, 32);
+            l1 = l1 + __shfl(ax, i, W);
     } else {
         const int n8 = n - (n & 7);
         double r = ax;                                   /* lanes 0..7: a[j] + a[8+j] + ... */
         for (int i = 8; i < n8; i += 8) {
-            const double t = __shfl_down(ax, i, 32);
+            const double t = __shfl_down(ax, i, W);
             r = r + t;
         }
-        const double t = r + __shfl_down(r, 1, 32);
-        const double u = t + __shfl_down(t, 2, 32);
-        l1 = u + __shfl_down(u, 4, 32);
-        l1 = __shfl(l1, 0, 32);
+        const double t = r + __shfl_down(r, 1, W);
+        const double u = t + __shfl_down(t, 2, W);
+        l1 = u + __shfl_down(u, 4, W);
+        l1 = __shfl(l1, 0, W);
         for (int i = n8; i < n; ++i)
-            l1 = l1 + __shfl(ax, i, 32);
+            l1 = l1 + __shfl(ax, i, W);
     }
-    const bool ok = l1 > 0.0;                            /* per half */
+    ok = l1 > 0.0;
     const double kd = (double)K;
     const double tgt = ok ? fabs(kd * x / l1) : 0.0;
     double y = floor(tgt);
-    const int missing = K - (int)half_sum_f64((l < n) ? y : 0.0);
+    double ysum = (l < n) ? y : 0.0;
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1)
+        ysum = ysum + __shfl_xor(ysum, off, W);
+    const int missing = K - (int)ysum;
     {
         const double r = (l < n) ? (tgt - y) : -1.0;
         int rank = 0;
         for (int j = 0; j < n; ++j) {
-            const double rj = __shfl(r, j, 32);
+            const double rj = __shfl(r, j, W);
             rank += (rj > r) || (rj == r && j < l);
         }
         if (l < n && rank < missing)
             y += 1.0;
     }
-    int a = (l < n && x != 0.0 && ok) ? (int)y : 0;
+    const int a = (l < n && x != 0.0 && ok) ? (int)y : 0;
     int incl = a;
 #pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-        const int t = __shfl_up(incl, off, 32);
+    for (int off = 1; off < W; off <<= 1) {
+        const int t = __shfl_up(incl, off, W);
         if (l >= off)
             incl += t;
     }
@@ -395,8 +389,22 @@ __device__ __forceinline__ void vq_leaf_pair(const VqView &V, VqOut &o, const do
             term += vq_N(V, ld - 1, k - a);
     }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1)
-        term = term + (unsigned long long)__shfl_xor((long long)term, off, 32);
+    for (int off = W / 2; off > 0; off >>= 1)
+        term = term + (unsigned long long)__shfl_xor((long long)term, off, W);
+    return term;
+}
+
+/* the two children of a bottom split: mid on lanes 0-31, side on lanes 32-63 */
+__device__ __forceinline__ void vq_leaf_pair(const VqView &V, VqOut &o, const double *mid, const double *side,
+                                             int n, int bits_mid, int bits_side, int lane)
+{
+    const int h = lane >> 5, l = lane & 31;
+    const int bits = h ? bits_side : bits_mid;
+    const int K = V.k_of[n * 33 + bits];
+    const int width = V.w_of[n * 33 + bits];
+    const double x = (l < n) ? (h ? side[l] : mid[l]) : 0.0;
+    bool ok;
+    const unsigned long long term = vq_leaf_group<32>(V, x, n, K, l, ok);
     /* mid first, then side (coder/gain_shape_quantize.py:372-393) */
     const unsigned long long idx_mid = (unsigned long long)__shfl((long long)term, 0, 64);
     const unsigned long long idx_side = (unsigned long long)__shfl((long long)term, 32, 64);
@@ -406,6 +414,101 @@ __device__ __forceinline__ void vq_leaf_pair(const VqView &V, VqOut &o, const do
         o.flags |= PACX_ST_VQ_UNDEFINED;                  /* an all-zero half: NaN pulses in the reference */
     vq_emit(o, 0, (okm & 1ull) ? idx_mid : 0ull, w_mid, lane);
     vq_emit(o, 0, ((okm >> 32) & 1ull) ? idx_side : 0ull, w_side, lane);
+}
+
+/* Two sibling bottom splits at once.  xa / xb: the two unit vectors (n <= 32
+ * components each, bits_a / bits_b > 32 bits).  Split a runs on lanes 0-31, split
+ * b on lanes 32-63 (fold, norms, angle, bit split: the arithmetic of vq_shape's
+ * split step); if all four grandchildren turn out to be leaves, they are coded
+ * on the four 16-lane quarters and the six fields go out in the reference's
+ * order (theta a, a.mid, a.side, theta b, b.mid, b.side).  Otherwise nothing is
+ * emitted and the caller walks the two subtrees the ordinary way. */
+__device__ __forceinline__ bool vq_quad_try(const VqView &V, VqOut &o, const double *xa, const double *xb,
+                                            int n, int bits_a, int bits_b, int lane)
+{
+    const double half_pi = 1.5707963267948966;
+    const int h = lane >> 5, l = lane & 31;
+    const double *xs = h ? xb : xa;
+    const int bits = h ? bits_b : bits_a;
+    const int cut = n / 2, hh = n - cut;                    /* hh <= 16 */
+    const double left = (l < cut) ? xs[l] : 0.0;
+    const double right = (l < hh) ? xs[cut + l] : 0.0;
+    double m = (l < hh) ? (left + right) / 2.0 : 0.0;
+    double sd = (l < hh) ? (left - right) / 2.0 : 0.0;
+    double mm = fma(m, m, 0.0), ss = fma(sd, sd, 0.0);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+        mm = mm + __shfl_xor(mm, off, 32);
+        ss = ss + __shfl_xor(ss, off, 32);
+    }
+    const double m_l2 = sqrt(mm), s_l2 = sqrt(ss);
+    if (m_l2 != 0.0)
+        m = m / m_l2;
+    if (s_l2 != 0.0)
+        sd = sd / s_l2;
+    const double theta = (m_l2 == 0.0) ? 0.0 : atan(s_l2 / m_l2);
+    const int a_theta = (int)floor((double)bits / (double)hh + V.half_log2[hh]);
+    int a_rest = bits - a_theta;
+    if (a_rest < 0)
+        a_rest = 0;
+    bool fine = a_theta > 0 && a_theta <= 62 && hh >= 2;
+    unsigned long long code = 0;
+    double theta_q = 0.0;
+    if (fine) {
+        const double tn = theta / half_pi;
+        if (tn >= 1.0) {
+            code = (1ull << (a_theta - 1)) - 1ull;
+        } else {
+            const double factor = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+            code = (unsigned long long)floor((factor * tn + 1.0) * 0.5);
+        }
+        const unsigned long long mag = code & ((1ull << (a_theta - 1)) - 1ull);
+        const double den = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+        double dq = (double)(2ull * mag) / den;
+        if (code >> (a_theta - 1))
+            dq = -dq;
+        theta_q = dq * half_pi;
+    }
+    int a_mid = 0;
+    if (fine && theta_q != 0.0) {
+        double lt;
+        if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta_q > 0.0)
+            lt = V.log2_tan[((1 << (a_theta - 1)) - 1) + (int)code];
+        else
+            lt = log2(tan(fabs(theta_q)) + PACX_EPS);
+        const double v = ((double)a_rest - (double)(hh - 1) * lt) / 2.0;
+        const double f = floor(v);
+        a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
+    }
+    const int a_side = a_rest - a_mid;
+    fine = fine && a_mid > 0 && a_mid <= PACX_VQ_SPLIT_BITS && a_side > 0 && a_side <= PACX_VQ_SPLIT_BITS;
+    if (__ballot(!fine))
+        return false;                                       /* not two bottom splits: ordinary walk */
+    /* the four leaves, one per 16-lane quarter: (a.mid, a.side, b.mid, b.side) */
+    const int q = lane >> 4, ll = lane & 15;
+    const double from_side = __shfl(sd, 32 * h + ll, 64);
+    const double from_mid = __shfl(m, 32 * h + ll, 64);
+    const double x = (ll < hh) ? ((q & 1) ? from_side : from_mid) : 0.0;
+    const int lbits = (q & 1) ? a_side : a_mid;
+    const int K = V.k_of[hh * 33 + lbits];
+    const int width = V.w_of[hh * 33 + lbits];
+    bool ok;
+    const unsigned long long term = vq_leaf_group<16>(V, x, hh, K, ll, ok);
+    const unsigned long long okm = __ballot(ok);
+    if ((okm & 0x0001000100010001ull) != 0x0001000100010001ull)
+        o.flags |= PACX_ST_VQ_UNDEFINED;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const unsigned long long th = (unsigned long long)__shfl((long long)code, 32 * g, 64);
+        vq_emit(o, 0, th, __shfl(a_theta, 32 * g, 64), lane);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int src = 32 * g + 16 * c;
+            const unsigned long long idx = (unsigned long long)__shfl((long long)term, src, 64);
+            vq_emit(o, 0, ((okm >> src) & 1ull) ? idx : 0ull, __shfl(width, src, 64), lane);
+        }
+    }
+    return true;
 }
 
 /* ---- the split tree of one band ------------------------------------------- */
@@ -498,8 +601,12 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
             /* children live one level down */
             reg = reg + 2 * half;
             depth += 1;
-            if (a_mid > 0 && a_mid <= PACX_VQ_SPLIT_BITS && a_side > 0 && a_side <= PACX_VQ_SPLIT_BITS &&
-                half >= 2 && half <= 32) {
+            if (a_mid > PACX_VQ_SPLIT_BITS && a_side > PACX_VQ_SPLIT_BITS && half >= 4 && half <= 32 &&
+                depth < VQ_DEPTH && vq_quad_try(V, o, mv, sv, half, a_mid, a_side, lane)) {
+                /* both children were bottom splits: their six fields are out */
+                stack[2 * (depth - 1) + 1] = -1;            /* side done */
+            } else if (a_mid > 0 && a_mid <= PACX_VQ_SPLIT_BITS && a_side > 0 && a_side <= PACX_VQ_SPLIT_BITS &&
+                       half >= 2 && half <= 32) {
                 /* both children are small leaves: code them side by side */
                 vq_leaf_pair(V, o, mv, sv, half, a_mid, a_side, lane);
                 stack[2 * (depth - 1) + 1] = -1;            /* side done */
