@@ -645,3 +645,16 @@ def test_block_switched_shards_equal_whole(A, torch):
         for rank in range(3):
             parts += run(A.dist.shard_with_halo(pcm, 3, rank), A.dist.shard_flags(flags, 3, rank))
         assert parts == whole
+
+
+@pytest.mark.parametrize("kbps", [32, 64, 192, 320])
+def test_scalar_other_bit_rates_vs_oracle(A, kbps):
+    """Scalar coder at rates away from 96/128 kb/s (allocations pinned at 16 bits,
+    or almost nothing to allocate), with a click that switches blocks: .pac bytes
+    and decoded PCM against the oracle."""
+    pcm = A.synth.stream(6, 2, 48000, seed=12)
+    pcm[2 * 1024 + 300:2 * 1024 + 380] = -30000
+    want = po.encode_stream(pcm, 48000, kbps, block_switching=True)
+    got = A.pacfile.encode_stream(pcm, 48000, kbps, block_switching=True)
+    assert got == want
+    assert np.array_equal(A.pacfile.decode_stream(got), po.decode_stream(want))

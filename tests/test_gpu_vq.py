@@ -259,3 +259,19 @@ def test_pacfile_block_api_vq_round_trip(A, tmp_path):
         out.append(np.stack([A.pcmfile.fraction_to_codes(c) for c in d], axis=1))
     g.Close(cp2)
     assert np.array_equal(np.concatenate(out), want_pcm)
+
+
+@pytest.mark.parametrize("kbps", [48, 64, 192, 256, 384])
+def test_other_bit_rates_vs_oracle(A, kbps):
+    """Rates far from the shipped 96/128 kb/s reach the rare branches of the
+    gain-shape coder: allocations of up to 16 bits per line (split angles beyond
+    the 12-bit table, leaves of 3-4 components with hundreds of pulses, deep
+    trees), or very few bits (K = 0 leaves, one-bit indices).  Encode bytes and
+    decoded PCM against the oracle on a short stream with a transient."""
+    from oracle import pac_oracle_vq as pv
+    pcm = A.synth.stream(6, 2, 48000, seed=11)
+    pcm[3 * 1024 + 200:3 * 1024 + 260] = 30000          # a click: block switching kicks in
+    want = pv.encode_stream_vq(pcm, 48000, kbps)
+    got = A.pacfile.encode_stream(pcm, 48000, kbps, block_switching=True, use_vq=True, use_sbr=kbps < 128)
+    assert got == want, describe_diff(got, want)
+    assert np.array_equal(A.pacfile.decode_stream(got), pv.decode_stream_vq(want))
