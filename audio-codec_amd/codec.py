@@ -31,8 +31,8 @@ def unpack_long(enc, out, i, bands=None):
     nb = bands.nBands
     ba = out["bit_alloc"][i, :nb].astype(np.int64)
     sf = out["scale_factor"][i, :nb].astype(np.int32)
-    keep = np.repeat(ba != 0, bands.nLines)
-    mant = out["mantissa"][i][keep].astype(np.int32)
+    keep = np.repeat(ba != 0, bands.nLines)                # bands may stop short of the last line (> 48 kHz)
+    mant = out["mantissa"][i][:len(keep)][keep].astype(np.int32)
     return sf, ba, mant, int(out["overall"][i, 0])
 
 
@@ -42,7 +42,7 @@ def unpack_short(enc, out, i, sb):
     ba = out["bit_alloc"][i, sb * nb:(sb + 1) * nb].astype(np.int64)
     sf = out["scale_factor"][i, sb * nb:(sb + 1) * nb].astype(np.int32)
     keep = np.repeat(ba != 0, bands.nLines)
-    mant = out["mantissa"][i, sb * 128:(sb + 1) * 128][keep].astype(np.int32)
+    mant = out["mantissa"][i, sb * 128:sb * 128 + len(keep)][keep].astype(np.int32)
     return sf, ba, mant, int(out["overall"][i, sb])
 
 

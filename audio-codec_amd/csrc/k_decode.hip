@@ -81,6 +81,8 @@ __global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, con
                 pos += T.n_mant_size_bits + T.n_scale_bits;
                 offs[s][b] = pos;
                 bas[s][b] = a;
+                if (b == nb - 1 && nb < PACX_MAX_BANDS)
+                    bas[s][nb] = 0;                        /* dummy band of the lines no band covers */
                 ba_o[s * nb + b] = a;
                 sf_o[s * nb + b] = sf;
                 pos += a * cnt[b];
@@ -147,7 +149,8 @@ __global__ __launch_bounds__(64) void k_imdct_long(PacxTables T, long long n_cf,
         const int32_t *ba = bit_alloc + cf * T.band_stride, *sf = scale_factor + cf * T.band_stride;
         for (int k = lane; k < PACX_M_LONG; k += 64) {
             const int b = T.line_band_long[k];
-            buf[k] = dequant_line(mantissa[cf * PACX_M_LONG + k], sf[b], ba[b], T.n_scale_bits, ov);
+            buf[k] = (b < T.nb_long) ? dequant_line(mantissa[cf * PACX_M_LONG + k], sf[b], ba[b], T.n_scale_bits, ov)
+                                     : 0.0;
         }
     }
     __syncthreads();
@@ -213,8 +216,10 @@ __global__ __launch_bounds__(64) void k_imdct_short(PacxTables T, long long n_cf
         for (int k = lane; k < PACX_M_LONG; k += 64) {
             const int s = k / PACX_M_SHORT, kk = k % PACX_M_SHORT;
             const int b = T.line_band_short[kk];
-            buf[s][kk] = dequant_line(mantissa[cf * PACX_M_LONG + k], sf[s * T.nb_short + b], ba[s * T.nb_short + b],
-                                      T.n_scale_bits, overall[cf * PACX_SUB + s]);
+            buf[s][kk] = (b < T.nb_short)
+                             ? dequant_line(mantissa[cf * PACX_M_LONG + k], sf[s * T.nb_short + b],
+                                            ba[s * T.nb_short + b], T.n_scale_bits, overall[cf * PACX_SUB + s])
+                             : 0.0;
         }
     }
     __syncthreads();

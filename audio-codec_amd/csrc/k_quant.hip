@@ -350,6 +350,8 @@ __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__
     if constexpr (!SHORT) {
         if (lane < nb)
             ba_s[lane] = bit_alloc[boff + lane];
+        if (lane == nb && nb < PACX_MAX_BANDS)
+            ba_s[nb] = 0;                                 /* dummy band of the lines no band covers */
         double xl[16];
         uint8_t bandl[16];
         int32_t mantl[16];
@@ -365,6 +367,8 @@ __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__
         bmax[lane] = 0ull;
     if (lane < nb)
         ba_s[lane] = bit_alloc[boff + lane];
+    if (lane == nb && nb < PACX_MAX_BANDS)
+        ba_s[nb] = 0;                                     /* dummy band of the lines no band covers */
     const int k0 = PER * lane;
     double x[PER];
     uint8_t band[PER];
@@ -541,6 +545,8 @@ __device__ __forceinline__ int pack_body(const PacxTables &T, unsigned *words, i
         ba_s[lane] = a_mine;
         lower_s[lane] = lower[lane];
     }
+    if (lane == nb && nb < PACX_MAX_BANDS)
+        ba_s[nb] = 0;                                     /* dummy band of the lines no band covers */
     if (lane == nb - 1)
         offs[nb] = my_off + width;
     if (lane == 0)
@@ -669,6 +675,8 @@ __global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *_
             bit_alloc[boff + l] = bits;
             ba_s[l] = bits;
         }
+        if (alive && l == nb && nb < PACX_MAX_BANDS)
+            ba_s[nb] = 0;                                 /* dummy band of the lines no band covers */
         if (alive && cap && status && l == 0)
             atomicOr(&status[cf], 4u);
     }
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(256) void k_tail_short(PacxTables T, const uint8_t 
 {
     __shared__ unsigned words[PACX_PACK_WORDS];
     __shared__ double cp[4][2][32];
-    __shared__ int ba_s[PACX_SUB][8], sf_s[PACX_SUB][8], len_s[PACX_SUB];
+    __shared__ int ba_s[PACX_SUB][9], sf_s[PACX_SUB][9], len_s[PACX_SUB];   /* [.][nb] = dummy band */
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, l = lane & 31;
     if ((long long)blockIdx.x >= (long long)*cf_count)
         return;
@@ -783,6 +791,10 @@ __global__ __launch_bounds__(256) void k_tail_short(PacxTables T, const uint8_t 
         if (has) {
             bit_alloc[off + l] = bits;
             ba_s[sb][l] = bits;
+        }
+        if (l == nb) {
+            ba_s[sb][nb] = 0;
+            sf_s[sb][nb] = 0;
         }
         if (cap && status && l == 0)
             atomicOr(&status[cf], 4u);

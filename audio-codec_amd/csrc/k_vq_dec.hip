@@ -494,7 +494,8 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
 
 __global__ __launch_bounds__(SBR_THREADS) void k_sbr_recon(PacxTables T, VqDecView V, long long n_cf,
                                                           const uint8_t *__restrict__ sbr_flag,
-                                                          double *__restrict__ lines)
+                                                          double *__restrict__ lines,
+                                                          uint32_t *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const long long cf = blockIdx.x;
@@ -505,6 +506,14 @@ __global__ __launch_bounds__(SBR_THREADS) void k_sbr_recon(PacxTables T, VqDecVi
     const int cut = T.band_lower_long[T.first_omitted];
     const int n_omit = M - cut;
     const int r = V.gauss_r;
+    if (M / (M / n_omit) > M - 1) {
+        /* the interpolation needs line M/up, which does not exist when the cut lies in
+           the lower half (band tables that stop at 24 kHz: sample rates above 48 kHz):
+           Decode_SBR raises IndexError there (coder/codec.py:173-176) */
+        if (tid == 0)
+            atomicOr(&status[cf], PACX_ST_VQ_UNDEFINED);
+        return;
+    }
     double *ln = (double *)smem;                 /* [M] lines                          */
     double *ext = ln + M;                        /* [2 n_omit + 2 r] mirrored envelope */
     double *smooth = ext + 2 * n_omit + 2 * r;   /* [n_omit]                           */
@@ -634,6 +643,7 @@ void pacx_launch_vq_dec(const PacxTables &T, const void *view, long long n_cf, c
         /* LDS sized for the worst case (every line above the cut): lines, mirrored
            envelope, smoothed envelope, interpolation ordinates */
         const size_t s2 = (size_t)(PACX_M_LONG + (2 * PACX_M_LONG + 2 * V.gauss_r) + PACX_M_LONG + PACX_M_LONG + 2) * 8;
-        hipLaunchKernelGGL(k_sbr_recon, dim3((unsigned)n_cf), dim3(SBR_THREADS), s2, st, T, V, n_cf, sbr_flag, lines);
+        hipLaunchKernelGGL(k_sbr_recon, dim3((unsigned)n_cf), dim3(SBR_THREADS), s2, st, T, V, n_cf, sbr_flag, lines,
+                           status);
     }
 }

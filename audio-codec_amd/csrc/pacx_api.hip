@@ -189,11 +189,15 @@ extern "C" int pacx_band_stride(const pacx_handle *h) { return h ? h->T.band_str
 
 extern "C" int pacx_payload_stride(const pacx_handle *h) { return h ? PACX_PAYLOAD_STRIDE : PACX_E_ARG; }
 
+/* The bands need not reach the last MDCT line: above 48 kHz the critical-band table
+ * ends at 24 kHz and the reference leaves the lines beyond it uncoded
+ * (coder/psychoac.py:106-124).  Those lines map to the dummy band index nb, whose
+ * allocation the kernels keep at zero. */
 static int build_bands(pacx_handle *h, const int32_t *lines, int nb, int total,
-                       const int32_t **d_lower, const int32_t **d_lines, const uint8_t **d_map)
+                       const int32_t **d_lower, const int32_t **d_lines, const uint8_t **d_map, int *covered)
 {
     std::vector<int32_t> lower(nb), cnt(lines, lines + nb);
-    std::vector<uint8_t> map(total);
+    std::vector<uint8_t> map(total, (uint8_t)nb);
     int at = 0;
     for (int b = 0; b < nb; ++b) {
         lower[b] = at;
@@ -203,8 +207,11 @@ static int build_bands(pacx_handle *h, const int32_t *lines, int nb, int total,
             map[at + k] = (uint8_t)b;
         at += cnt[b];
     }
-    if (at != total)
-        return fail(h, PACX_E_ARG, "band line counts do not add up to the number of MDCT lines");
+    if (at > total)
+        return fail(h, PACX_E_ARG, "band line counts exceed the number of MDCT lines");
+    if (at < total && nb >= PACX_MAX_BANDS)
+        return fail(h, PACX_E_UNSUPPORTED, "at most 31 bands when the bands do not cover every line");
+    *covered = at;
     int rc;
     if ((rc = upload(h, lower.data(), nb, d_lower))) return rc;
     if ((rc = upload(h, cnt.data(), nb, d_lines))) return rc;
@@ -373,10 +380,16 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
 
     T.nb_long = cfg->n_bands_long;
     T.nb_short = cfg->n_bands_short;
+    int covered_long = ML, covered_short = MS;
     TRY(build_bands(h, cfg->band_lines_long, T.nb_long, ML, &T.band_lower_long, &T.band_lines_long,
-                    &T.line_band_long));
+                    &T.line_band_long, &covered_long));
     TRY(build_bands(h, cfg->band_lines_short, T.nb_short, MS, &T.band_lower_short, &T.band_lines_short,
-                    &T.line_band_short));
+                    &T.line_band_short, &covered_short));
+    if (covered_short < MS && T.nb_short >= 8) {
+        g_create_err = "pacx_create: at most 7 short bands when they do not cover every line";
+        pacx_destroy(h);
+        return PACX_E_UNSUPPORTED;
+    }
     T.band_stride = T.nb_long > PACX_SUB * T.nb_short ? T.nb_long : PACX_SUB * T.nb_short;
     T.n_scale_bits = cfg->n_scale_bits;
     T.n_mant_size_bits = cfg->n_mant_size_bits;
@@ -395,7 +408,7 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     if (T.use_sbr) {
         /* sbr.omitted_bands (coder/sbr.py:6-9): bands starting at or above upperLine[-1] // 2 */
         std::vector<int32_t> alloc_lines(cfg->band_lines_long, cfg->band_lines_long + T.nb_long);
-        const int cut = (ML - 1) / 2;
+        const int cut = (covered_long - 1) / 2;      /* sfBands.upperLine[-1] // 2 */
         int at = 0;
         for (int b = 0; b < T.nb_long; ++b) {
             if (at >= cut) {

@@ -20,6 +20,7 @@ from .pcmfile import codes_to_fraction
 from .psychoac import AssignMDCTLinesFromFreqLimits, ScaleFactorBands
 
 BYTESIZE = 8
+_ST_VQ_UNDEFINED = 8          # include/pacx.h
 
 
 def omitted_bands(sfBands, factor=2):
@@ -252,6 +253,10 @@ def decode_stream(data):
     sizes_t = torch.tensor(sizes, dtype=torch.int32, device=enc.device)
     offs_t = torch.tensor(offs, dtype=torch.int64, device=enc.device)
     if cp.useVQ:
-        return enc.decode_vq(body, sizes_t, cp.nChannels, offsets=offs_t)["pcm"].cpu().numpy()
+        out = enc.decode_vq(body, sizes_t, cp.nChannels, offsets=offs_t)
+        if int(out["status"].max().item()) & _ST_VQ_UNDEFINED:
+            raise RuntimeError("stream holds a gain-shape block the reference's decoder fails on "
+                               "(PACX_ST_VQ_UNDEFINED)")
+        return out["pcm"].cpu().numpy()
     codes = enc.unpack(body, sizes_t, offs_t)
     return enc.decode(codes, cp.nChannels).cpu().numpy()
