@@ -691,3 +691,21 @@ def test_other_sample_rates_vs_oracle(A, sr):
         got = A.pacfile.encode_stream(pcm, sr, 128, block_switching=True, use_vq=True)
         assert got == want
         assert np.array_equal(A.pacfile.decode_stream(got), pv.decode_stream_vq(want))
+
+
+@pytest.mark.parametrize("n_ch", [1, 3])
+def test_other_channel_counts_vs_oracle(A, n_ch):
+    """Mono and three channels (the transient detector averages over all channels,
+    a zero short sub-block in any channel drops the hop for all): scalar and
+    gain-shape streams against the oracle."""
+    from oracle import pac_oracle_vq as pv
+    pcm = A.synth.stream(6, n_ch, 48000, seed=14)
+    pcm[2 * 1024 + 500:2 * 1024 + 560, 0] = 29000
+    want = po.encode_stream(pcm, 48000, 128, block_switching=True)
+    got = A.pacfile.encode_stream(pcm, 48000, 128, block_switching=True)
+    assert got == want
+    assert np.array_equal(A.pacfile.decode_stream(got), po.decode_stream(want))
+    want = pv.encode_stream_vq(pcm, 48000, 96)
+    got = A.pacfile.encode_stream(pcm, 48000, 96, block_switching=True, use_vq=True, use_sbr=True)
+    assert got == want
+    assert np.array_equal(A.pacfile.decode_stream(got), pv.decode_stream_vq(want))
