@@ -165,15 +165,22 @@ if __name__ == "__main__":
     X8[g[:, None], r[:, None] + 8 * np.arange(8)[None, :]] = Y
     print("fft64x8 err", np.max(np.abs(X8 - np.fft.fft(x8, axis=1))))
 
-    import sys, os
-    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-    from oracle import pac_oracle as po
-    xw = po.sine_window(2048) * rng.standard_normal(2048)
-    ref = po.mdct_forward(xw, 1024, 1024)
+    def sine_window(n):
+        return np.sin(np.pi * (np.arange(n) + 0.5) / n)
+
+    def mdct_direct(x, half_n):
+        """X[k] = (2/N) sum x[n] cos(2 pi/N (n + n0)(k + 1/2)), n0 = N/4 + 1/2 (the definition)"""
+        n_total = 2 * half_n
+        n = np.arange(n_total)[None, :] + (half_n / 2 + 0.5)
+        k = np.arange(half_n)[:, None] + 0.5
+        return (2.0 / n_total) * (np.cos(2 * np.pi / n_total * n * k) @ np.atleast_2d(x).T).T.squeeze()
+
+    xw = sine_window(2048) * rng.standard_normal(2048)
+    ref = mdct_direct(xw, 1024)
     got = mdct_long(xw)
     print("mdct2048 rel err", np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
-    xw8 = po.sine_window(256)[None, :] * rng.standard_normal((8, 256))
-    ref = po.mdct_forward(xw8, 128, 128)
+    xw8 = sine_window(256)[None, :] * rng.standard_normal((8, 256))
+    ref = mdct_direct(xw8, 128)
     got = mdct_short8(xw8)
     print("mdct256x8 rel err", np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
     xh = rng.standard_normal(2048)
