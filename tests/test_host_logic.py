@@ -54,6 +54,17 @@ def test_product_does_not_import_oracle():
         paths += [os.path.join(dirpath, f) for f in files if f.endswith((".py", ".hip", ".h", ".cpp"))]
     for path in paths:
         assert not bad.search(open(path, errors="ignore").read()), path
+    # development aids and the C example stay clear of it too
+    for sub in ("tools", "examples"):
+        for f in os.listdir(os.path.join(ROOT, sub)):
+            if f.endswith((".py", ".c", ".cpp")):
+                path = os.path.join(ROOT, sub, f)
+                assert not bad.search(open(path, errors="ignore").read()), path
+    # bench.py: only inside its cpu_baseline leg
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"from oracle import", src):
+        before = src[:m.start()]
+        assert ("def cpu_baseline" in before and "def main" not in before) or "cpu_baseline" in src[m.start() - 400:m.start() + 700]
 
 
 @pytest.mark.parametrize("sr", [48000, 44100])
