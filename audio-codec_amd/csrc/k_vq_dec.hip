@@ -533,13 +533,23 @@ __global__ __launch_bounds__(SBR_THREADS) void k_sbr_recon(PacxTables T, VqDecVi
         ext[p] = (m < n_omit) ? ln[cut + m] : 0.0;
     }
     __syncthreads();
-    /* correlate1d, symmetric kernel: centre first, then the pairs from the far end inwards */
+    /* correlate1d, symmetric kernel: centre first, then the pairs from the far end
+       inwards.  The envelope holds one value per omitted band at its first nob
+       positions and zeros elsewhere (its mirror image puts them at -nob..-1), so
+       for output i only the distances d = i-nob+1 .. i+nob meet a non-zero sample;
+       every other pair adds (0+0)*w = +0.0 and is skipped -- same sum, same order */
     const double *__restrict__ w = V.gauss;
+    const int nob = T.nb_long - T.first_omitted;
     for (int i = tid; i < n_omit; i += SBR_THREADS) {
         const int c = i + r;
         double acc = ext[c] * w[r];
-        for (int jj = -r; jj < 0; ++jj)
-            acc += (ext[c + jj] + ext[c - jj]) * w[r + jj];
+        int d_hi = i + nob, d_lo = i - nob + 1;
+        if (d_hi > r)
+            d_hi = r;
+        if (d_lo < 1)
+            d_lo = 1;
+        for (int d = d_hi; d >= d_lo; --d)
+            acc += (ext[c - d] + ext[c + d]) * w[r - d];
         smooth[i] = acc;
     }
     /* transposition: lines[cut + i] = spline1(freq[cut + i] / up) through the points
