@@ -192,6 +192,84 @@ __device__ __forceinline__ void vqd_leaf(const VqDecView &V, const unsigned *wor
     vqd_normalize(out, n, lane);
 }
 
+/* The two leaf children of a bottom split at once (93 % of all leaves): the mid
+ * leaf on lanes 0-31, the side leaf on lanes 32-63.  The index walk is the one of
+ * vqd_pvq with per-half state; each half's lane 0 stores.  n <= 32 components,
+ * both indices are read before the walk (their widths come from the tables). */
+__device__ __forceinline__ void vqd_leaf_pair(const VqDecView &V, const unsigned *words, int &pos, double *mid,
+                                              double *side, int n, int bits_mid, int bits_side, int lane,
+                                              unsigned &flags)
+{
+    const int h = lane >> 5, l = lane & 31;
+    const int bits = h ? bits_side : bits_mid;
+    const int K = V.k_of[n * 33 + bits];
+    const int width = V.w_of[n * 33 + bits];
+    const int w_mid = __shfl(width, 0, 64);
+    const unsigned long long b = vqd_get(words, pos + (h ? w_mid : 0), width);
+    pos += w_mid + __shfl(width, 32, 64);
+    double *y = h ? side : mid;
+    if (l < n)
+        y[l] = 0.0;
+    vqd_fence();
+    unsigned long long xb = 0;
+    long long k = K;
+    int ld = n;
+    bool bad = false;
+    for (int i = 0; i < n; ++i, --ld) {
+        const bool live = k > 0 && !bad;                 /* per half */
+        if (!__ballot(live))
+            break;
+        if (!live)
+            continue;
+        if (b == xb) {                                   /* the rest is zero, the last component takes k */
+            if (l == 0)
+                y[n - 1] = (double)k;
+            k = 0;
+            continue;
+        }
+        const unsigned long long n0 = vqd_N(V, ld - 1, k);
+        if (b - xb < n0)
+            continue;                                    /* this component is zero */
+        xb += n0;
+        const unsigned long long r = b - xb;
+        const unsigned long long pk1 = vqd_P(V, ld - 1, k - 1);
+        long long lo = 1, hi = k;
+        while (lo < hi) {
+            const long long md = (lo + hi) >> 1;
+            const unsigned long long c = 2ull * (pk1 - vqd_P(V, ld - 1, k - md - 1));
+            if (r < c)
+                hi = md;
+            else
+                lo = md + 1;
+        }
+        const long long j = lo;
+        if (r >= 2ull * (pk1 - vqd_P(V, ld - 1, k - j - 1))) {
+            bad = true;                                  /* not an index of this codebook */
+            continue;
+        }
+        const unsigned long long base = 2ull * (pk1 - vqd_P(V, ld - 1, k - j));
+        const unsigned long long group = vqd_N(V, ld - 1, k - j);
+        const bool neg = (r - base) >= group;
+        if (l == 0)
+            y[i] = neg ? -(double)j : (double)j;
+        xb += base + (neg ? group : 0ull);
+        k -= j;
+    }
+    if (__ballot(bad || k > 0))
+        flags |= PACX_ST_VQ_UNDEFINED;
+    vqd_fence();
+    /* x / ||x|| per half (sums of squares of integers: exact in any order) */
+    const double v = (l < n) ? y[l] : 0.0;
+    double acc = v * v;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1)
+        acc = acc + __shfl_xor(acc, off, 32);
+    const double nrm = sqrt(acc);
+    if (l < n && nrm != 0.0)
+        y[l] = v / nrm;
+    vqd_fence();
+}
+
 /* frames of the split tree (per wave, in LDS) */
 struct VqdFrame {
     double theta;
@@ -269,6 +347,13 @@ __device__ __forceinline__ void vqd_shape(const VqDecView &V, const unsigned *wo
                 cur_bits = a_mid;
                 cur_reg = cur_reg + 2 * half;
                 continue;                                   /* phase 0 on the mid child */
+            }
+            if (a_mid > 0 && a_rest - a_mid > 0 && a_rest - a_mid <= PACX_VQ_SPLIT_BITS && half >= 2 && half <= 32) {
+                /* both children are small leaves: decode them side by side */
+                vqd_leaf_pair(V, words, pos, scr + mid_slot, scr + mid_slot + half, half, a_mid, a_rest - a_mid,
+                              lane, flags);
+                phase = 2;
+                continue;
             }
             if (a_mid > 0) {
                 vqd_leaf(V, words, pos, scr + mid_slot, half, a_mid, lane, flags);
