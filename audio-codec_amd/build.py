@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpacx.so")
 OBJ = os.path.join(HERE, "build")
 SOURCES = ["pacx_api.hip", "k_mdct.hip", "k_psy.hip", "k_quant.hip", "k_misc.hip", "k_mdct2.hip", "k_decode.hip",
-           "k_vq.hip", "k_vq_dec.hip"]
+           "k_vq.hip", "k_vq_dec.hip", "k_mdct3.hip"]
 # -ffp-contract=off: integer codes must follow the reference's individually
 # rounded double operations; FMAs are written explicitly where wanted.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",

@@ -22,7 +22,7 @@ for k in fetch:
     per[k] = {"FETCH_SIZE": {"launches": len(fetch[k]), "mean": sum(fetch[k]) / len(fetch[k])},
               "WRITE_SIZE": {"launches": len(write.get(k, [])),
                              "mean": sum(write.get(k, [0])) / max(1, len(write.get(k, [])))}}
-mdct = [k for k in per if "k_mdct_long_v2" in k][0]
+mdct = [k for k in per if "k_mdct_long_x2" in k or "k_mdct_long_v2" in k][0]
 f_kb, w_kb = per[mdct]["FETCH_SIZE"]["mean"], per[mdct]["WRITE_SIZE"]["mean"]
 out = {
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline",
