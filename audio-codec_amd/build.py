@@ -56,5 +56,23 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_mdct_debug():
+    """libpacx_dbg.so: the same library with k_mdct3.hip compiled -DPACX_MDCT_DEBUG
+    (in-kernel s_memtime stamps per phase, read by tools/mdct_phase_probe.py through
+    PACX_LIB).  A measuring aid, never loaded by default."""
+    build(verbose=False)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    dbg = os.path.join(OBJ, "k_mdct3_dbg.o")
+    subprocess.check_call([hipcc] + FLAGS + ["-DPACX_MDCT_DEBUG", "-c", os.path.join(CSRC, "k_mdct3.hip"), "-o", dbg])
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s != "k_mdct3.hip"]
+    out = os.path.join(HERE, "libpacx_dbg.so")
+    subprocess.check_call([hipcc, "-shared", "--offload-arch=gfx950", "-o", out] + objs + [dbg])
+    os.remove(dbg)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--mdct-debug" in sys.argv:
+        print(build_mdct_debug())
+    else:
+        print(build(force="--force" in sys.argv))

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
     __shared__ __attribute__((aligned(16))) double wsin[1024];
     __shared__ __attribute__((aligned(16))) cplx w64[7][8];        /* W64^(r k2), k2 = 1..7 */
     __shared__ __attribute__((aligned(16))) cplx w1s[7][64];       /* W512^(lane k1), k1 = 1..7 */
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     /* wave-uniform: frame index math on the SALU */
     cplx *tile = tiles[wv];
     short *raw = DBUF ? rawbuf[wv] : (short *)tile;
     const unsigned n_ch = (unsigned)in.n_ch;
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
             for (int n1 = 0; n1 < 8; ++n1) {
                 const int n = lane + 64 * n1;
                 auto code = [&](int i) -> double {
-                    const int c = raw[i];
+                    int c = raw[i];
+                    asm("" : "+v"(c));      /* opaque 32-bit: sign-extending load, no 16-bit narrowing */
                     lowest = min(lowest, c);
                     return (double)c;
                 };
@@ -197,18 +199,26 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
             b[k3] = -fma(v[k3].x, d.y, v[k3].y * d.x);        /* -Im y = X[1023 - 2k]           */
             mx = fmax(mx, fmax(fabs(a[k3]), fabs(b[k3])));
         }
+        /* X[2k+1] = X[1023 - 2(511-k)] is held by lane 63-lane, register 7-k3 */
+        double odd[8];
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3)
+            odd[k3] = __shfl(b[7 - k3], 63 - lane, 64);
+        /* overall scale = minimum of the lanes' own scales (ScaleFactor is non-increasing),
+           by bisection with one ballot per bit: see k_mdct3.hip */
+        int lo = 0;
+        if (scale_out) {
+            const int s = pacx_scale_factor(mx, T.n_scale_bits, 5);
+            for (int bit = T.n_scale_bits - 1; bit >= 0; --bit)
+                if (!__ballot(s < lo + (1 << bit)))
+                    lo += 1 << bit;
+        }
         double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);
 #pragma unroll
-        for (int k3 = 0; k3 < 8; ++k3) {
-            /* X[2k+1] = X[1023 - 2(511-k)] is held by lane 63-lane, register 7-k3 */
-            const double odd = __shfl(b[7 - k3], 63 - lane, 64);
-            out[lane + 64 * k3] = make_double2(a[k3], odd);
-        }
-        if (scale_out) {
-            mx = wave_max(mx);
-            if (lane == 0)
-                scale_out[(long long)cf * scale_stride] = pacx_scale_factor(mx, T.n_scale_bits, 5);
-        }
+        for (int k3 = 0; k3 < 8; ++k3)
+            out[lane + 64 * k3] = make_double2(a[k3], odd[k3]);
+        if (scale_out && lane == 0)
+            scale_out[(long long)cf * scale_stride] = lo;
     }
 }
 
@@ -230,11 +240,11 @@ void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8
         const char *e = getenv("PACX_MDCT_VARIANT");
         variant = e ? atoi(e) : -1;            /* -1: the defaults below */
     }
-    /* default: batches without per-frame flags (all sine windows) go to the
-       two-frames-per-wave kernel of k_mdct3.hip (23.6 vs 25.3 us per 8192 cf); batches
-       with flags (transition windows, frames left to the short kernel) stay here */
+    /* default: batches without per-frame flags (all sine windows) go to the pipelined
+       two-frames-per-wave kernel of k_mdct3.hip; batches with flags (transition
+       windows, frames left to the short kernel) stay here */
     if (variant == -1 && !flags) {
-        pacx_launch_mdct_x2(T, in, n_cf, lines, scale_out, scale_stride, status_init, n_cu, 8, st);
+        pacx_launch_mdct_x2(T, in, n_cf, lines, scale_out, scale_stride, status_init, n_cu, 0, st);
         return;
     }
 #define LAUNCH(W, MW, PER_CU, DB)                                                                        \

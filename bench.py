@@ -277,7 +277,7 @@ def main():
                        "stereo_frames_per_s": world * n_frames * args.steps / dt,
                        "launch": "hipGraph replay of the captured step" if graph is not None else "direct launches",
                        "sharding": f"{world} x frame-range shards, no data-path collective"},
-            "roofline": {"kernel": "k_mdct_long_x2 (window + MDCT, int16 in, float64 lines out; two frames in flight per wave)",
+            "roofline": {"kernel": "k_mdct_long_x2p (window + MDCT, int16 in, float64 lines out; two frames per wave alternating on one FFT tile, PCM prefetched a whole iteration ahead)",
                          "bound": "hbm", "achieved": mdct_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": mdct_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
