@@ -56,23 +56,29 @@ def build(force=False, verbose=True):
     return OUT
 
 
-def build_mdct_debug():
-    """libpacx_dbg.so: the same library with k_mdct3.hip compiled -DPACX_MDCT_DEBUG
-    (in-kernel s_memtime stamps per phase, read by tools/mdct_phase_probe.py through
-    PACX_LIB).  A measuring aid, never loaded by default."""
+def build_phase_debug():
+    """libpacx_dbg.so: the same library with k_mdct3.hip and k_psy.hip compiled with
+    -DPACX_MDCT_DEBUG / -DPACX_PSY_DEBUG (in-kernel s_memtime stamps per phase, read by
+    tools/mdct_phase_probe.py and tools/psy_phase_probe.py through PACX_LIB).  A
+    measuring aid, never loaded by default."""
     build(verbose=False)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    dbg = os.path.join(OBJ, "k_mdct3_dbg.o")
-    subprocess.check_call([hipcc] + FLAGS + ["-DPACX_MDCT_DEBUG", "-c", os.path.join(CSRC, "k_mdct3.hip"), "-o", dbg])
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s != "k_mdct3.hip"]
+    dbg_srcs = {"k_mdct3.hip": "-DPACX_MDCT_DEBUG", "k_psy.hip": "-DPACX_PSY_DEBUG"}
+    dbg_objs = []
+    for src, flag in dbg_srcs.items():
+        obj = os.path.join(OBJ, src.replace(".hip", "_dbg.o"))
+        subprocess.check_call([hipcc] + FLAGS + [flag, "-c", os.path.join(CSRC, src), "-o", obj])
+        dbg_objs.append(obj)
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s not in dbg_srcs]
     out = os.path.join(HERE, "libpacx_dbg.so")
-    subprocess.check_call([hipcc, "-shared", "--offload-arch=gfx950", "-o", out] + objs + [dbg])
-    os.remove(dbg)
+    subprocess.check_call([hipcc, "-shared", "--offload-arch=gfx950", "-o", out] + objs + dbg_objs)
+    for obj in dbg_objs:
+        os.remove(obj)
     return out
 
 
 if __name__ == "__main__":
-    if "--mdct-debug" in sys.argv:
-        print(build_mdct_debug())
+    if "--phase-debug" in sys.argv:
+        print(build_phase_debug())
     else:
         print(build(force="--force" in sys.argv))

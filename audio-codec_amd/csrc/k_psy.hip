@@ -47,6 +47,25 @@ __device__ __forceinline__ double hann_sample(const typename PcmStage<DT>::elem 
     }
 }
 
+#ifdef PACX_PSY_DEBUG
+/* phase stamps (s_memtime) of workgroup 5, accumulated per wave: a measuring aid read by
+   tools/psy_phase_probe.py from a library built with -DPACX_PSY_DEBUG */
+__device__ long long g_psy_dbg[16 * 16];
+#define PSY_T(k) do { long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                      if (dbg_on) dbg_acc[k] += t_ - dbg_last; dbg_last = t_; } while (0)
+extern "C" int pacx_debug_read_psy(long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_psy_dbg), sizeof(long long) * n);
+}
+/* side kernels: one wave per block, every block adds its phase times */
+#define SIDE_T(k) do { long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                       if (lane == 0 && side_last) atomicAdd((unsigned long long *)&g_psy_dbg[128 + (k)], (unsigned long long)(t_ - side_last)); \
+                       side_last = t_; } while (0)
+#else
+#define PSY_T(k) do { } while (0)
+#define SIDE_T(k) do { } while (0)
+#endif
+
 /* one tonal masker from bins f-1, f (coder/psychoac.py:321-328, :61-68) */
 __device__ __forceinline__ PacxPeak make_peak(double left, double centre, int f, double fstep)
 {
@@ -61,18 +80,24 @@ __device__ __forceinline__ PacxPeak make_peak(double left, double centre, int f,
 }
 
 /* ------------------------------------------------------------------ long */
-/* LDS of one wave: raw (until the FFT inputs are in registers) then inten share
- * one region; the FFT exchange tile then the packed spectrum Z share another */
-/* LDS of one wave (17.5 KB for int16 input -> 9 waves per CU):
- *   region A (9 KB): the FFT exchange tile, later the peak lists (idx, zs, ss)
- *   region B (8.06 KB, 16 KB for float64 input): raw samples, later the intensities
+/* LDS of one wave.  The three users of it follow one another in time: raw samples (until
+ * the FFT inputs are in registers), the FFT exchange tile (until the spectrum is in
+ * registers), then the intensities together with the peak lists.
+ *   COMPACT (no SBR): 13.1 KB for int16 input -> 12 waves per CU, what the registers allow
+ *     region B (8.06 KB): raw, then the tile, then inten -- whose low slots the maskers'
+ *       Bark values overwrite one round of 64 at a time (masker p comes from bins
+ *       i_p - 1, i_p with i_p >= 2 p + 1, so slot p is never read again)
+ *     region A (5 KB): peak bin numbers (1 KB) and SPLs (4 KB)
+ *   with SBR (inten is needed to the end): 17.5 KB -> 9 waves per CU
+ *     region A (9 KB): the tile, later bin numbers, Bark values, SPLs;  region B: raw, inten
  * The packed spectrum Z never goes to LDS: the real-FFT split needs Z[k] with
  * Z[N/2-k], and with natural-order FFT output (wave_fft.h fft512n) that
  * partner sits in the mirrored lane's mirrored register, one ds_bpermute away. */
-template <int DT> struct SideLongLds {
+template <int DT, bool COMPACT> struct SideLongLds {
     typedef typename PcmStage<DT>::elem E;
     static constexpr int RAW_BYTES = (int)sizeof(E) * PACX_N_LONG;
-    static constexpr int A_BYTES = 1024 + 2 * PACX_MAX_PEAKS * 8;             /* >= 512 * sizeof(cplx) */
+    static constexpr int A_BYTES = COMPACT ? 1024 + PACX_MAX_PEAKS * 8
+                                           : 1024 + 2 * PACX_MAX_PEAKS * 8;   /* >= 512 * sizeof(cplx) */
     static constexpr int B_BYTES = RAW_BYTES > 1032 * 8 ? RAW_BYTES : 1032 * 8;
     static constexpr int BYTES = A_BYTES + B_BYTES;
 };
@@ -128,7 +153,7 @@ __device__ __forceinline__ double pair_intensity(cplx a, cplx bz, cplx w, double
 
 /* one long channel-frame by one wave; every barrier is wave-local (the wave
  * owns its LDS slice) */
-template <int DT, bool FAST>
+template <int DT, bool FAST, bool COMPACT>
 __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcmView &in, long long cf,
                                               char *regA, char *regB, int lane,
                                               PacxPeak *__restrict__ peaks, int32_t *__restrict__ n_peaks,
@@ -137,12 +162,18 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
                                               int32_t *__restrict__ sbr_overall)
 {
     typedef typename PcmStage<DT>::elem E;
-    cplx *tile = (cplx *)regA;
+    cplx *tile = (cplx *)(COMPACT ? regB : regA);
     double *inten = (double *)regB;
     E *raw = (E *)regB;
 
+#ifdef PACX_PSY_DEBUG
+    long long side_last = 0;
+#endif
+    SIDE_T(15);
     stage_samples<DT, FAST>(raw, in, cf, 0, PACX_N_LONG, lane);
     wave_lds_fence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SIDE_T(0);
 
     const double *__restrict__ hw = T.hann_long, *__restrict__ hwp = T.hann_long_pcm;
     cplx ev[8], od[8];
@@ -153,8 +184,10 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
         od[n1] = make_double2(hann_sample<DT>(raw, i + 2, hw, hwp), hann_sample<DT>(raw, i + 3, hw, hwp));
     }
     wave_lds_fence();                  /* raw fully consumed: region B becomes inten */
+    SIDE_T(1);
     fft512n_g(ev, tile, T.w512, lane);
     fft512n_g(od, tile, T.w512, lane);
+    SIDE_T(2);
     /* ev[k3] = E[k], od[k3] = O[k], k = lane + 64 k3.  Z[k] = E[k] + W1024^k O[k],
        Z[k+512] = E[k] - W1024^k O[k].  Bins k and k+512 pair with Z[1024-k] and
        Z[512-k]: both are made of E[m], O[m], m = 512 - k, which lane 64-lane holds
@@ -188,7 +221,8 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
             inten[1024] = pair_intensity(zk, zk, T.w2048[1024], T.norm_long);
     }
     wave_lds_fence();
-    cplx *Z = (cplx *)regA;            /* region A from here on: idx, zs, ss */
+    SIDE_T(3);
+    cplx *Z = (cplx *)regA;            /* region A from here on: idx, (zs,) ss */
 
     /* pass 1: strict local maxima (coder/psychoac.py:312-317), their bin numbers
        compacted in ascending order into LDS (ballot + prefix popcount) */
@@ -208,10 +242,11 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
         count += __popcll(m);
     }
     wave_lds_fence();
+    SIDE_T(4);
     /* pass 2: one masker per lane, 64 at a time (log10 + two atan each); Bark and
        SPL go to LDS for the pruning scans */
-    double *zs = (double *)Z + 128;                       /* [512] after the 1 KB index list */
-    double *ss = zs + PACX_MAX_PEAKS;                     /* [512]                      */
+    double *zs = COMPACT ? inten : (double *)Z + 128;     /* [512]: in place, or after the 1 KB index list */
+    double *ss = COMPACT ? (double *)Z + 128 : zs + PACX_MAX_PEAKS;
     for (int p = lane; p < count; p += 64) {
         const int i = idx[p];
         const PacxPeak q = make_peak(inten[i - 1], inten[i], i, T.fstep_long);
@@ -219,6 +254,7 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
         ss[p] = q.spl;
     }
     wave_lds_fence();
+    SIDE_T(5);
     /* pass 3: drop maskers that cannot matter.  A masker p with S_p <= 40 dB has
        the 27 dB/Bark tent S_p - 16 - 27 max(|z - z_p| - 0.5, 0); any other masker q
        has a tent at least that steep-sided or shallower, so q >= p EVERYWHERE as
@@ -299,13 +335,14 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
             n_kept_out[cf * PACX_SUB] = n_kept;             /* what the mask kernel has to look at */
         }
     }
+    SIDE_T(6);
     /* SBR files (EncodeSingleChannel_SBR, coder/codec.py:459-472, 503-505): the
        same spectrum as |rfft|/halfN also bounds the overall scale factor and
        gives each omitted band its one coded value, the mean magnitude.
        ScaleFactor is monotone, so min(sf(max MDCT), sf(max FFT)) is
        sf(max of both); magnitudes come back from the intensities
        (|X| = sqrt(I/norm), two roundings away from np.abs). */
-    if (sbr_mean) {
+    if (!COMPACT && sbr_mean) {
         wave_lds_fence();
         double mx = 0.0;
         for (int i = lane; i <= 1024; i += 64)
@@ -331,7 +368,7 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
     }
 }
 
-template <int DT, bool FAST>
+template <int DT, bool FAST, bool COMPACT>
 __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
                                                  const uint8_t *__restrict__ flags, long long n_cf,
                                                  int skip_cur, PacxPeak *__restrict__ peaks,
@@ -340,15 +377,16 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
                                                  double *__restrict__ sbr_mean,
                                                  int32_t *__restrict__ sbr_overall)
 {
-    __shared__ __attribute__((aligned(16))) char regA[SideLongLds<DT>::A_BYTES];
-    __shared__ __attribute__((aligned(16))) char regB[SideLongLds<DT>::B_BYTES];
+    __shared__ __attribute__((aligned(16))) char regA[SideLongLds<DT, COMPACT>::A_BYTES];
+    __shared__ __attribute__((aligned(16))) char regB[SideLongLds<DT, COMPACT>::B_BYTES];
     const long long cf = blockIdx.x;
     if (cf >= n_cf)
         return;
     const unsigned fl = flags ? flags[cf / in.n_ch] : 0u;
     if (skip_cur && (fl & 2u))
         return;
-    side_long_one<DT, FAST>(T, in, cf, regA, regB, threadIdx.x, peaks, n_peaks, n_kept_out, sbr_mean, sbr_overall);
+    side_long_one<DT, FAST, COMPACT>(T, in, cf, regA, regB, threadIdx.x, peaks, n_peaks, n_kept_out, sbr_mean,
+                                     sbr_overall);
 }
 
 /* ----------------------------------------------------------------- short */
@@ -502,6 +540,7 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 #define MASK_WG_PER_CU 3
 #endif
 
+
 template <int M>
 __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T, const uint8_t *__restrict__ flags,
                                                          int n_ch, long long n_units, int mixed,
@@ -549,11 +588,22 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     const int nb = SHORT ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
+    /* band bounds, one band per lane, read once: inside the frame loop they would be
+       vector loads from HBM/L2 with a full wait each (the compiler cannot keep them
+       scalar past the kernel's own stores), two dependent ones per band */
+    const int lo_v = lane < nb ? lower[lane] : 0;
+    const int hi_v = lane < nb ? lo_v + count[lane] : 0;
 
     /* mixed streams: walk the compacted list of the frames this kernel owns, so the
        static striding stays balanced whatever the pattern of long and short frames */
     if (cf_list)
         n_units = SHORT ? (long long)(*cf_count) * PACX_SUB : (long long)(*cf_count);
+#ifdef PACX_PSY_DEBUG
+    const bool dbg_on = blockIdx.x == 5;
+    long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = 0;
+    PSY_T(7);
+    dbg_acc[7] = 0;
+#endif
     for (long long unit = (long long)blockIdx.x * MASK_WAVES + wv; unit < n_units;
          unit += (long long)gridDim.x * MASK_WAVES) {
         long long cf = SHORT ? unit / PACX_SUB : unit;
@@ -581,6 +631,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
         qn.z = 0.0; qn.spl = -1000.0; qn.slope = 0.0;             /* padding lanes never survive */
         if (lane < np)
             qn = pk[lane];
+        PSY_T(0);
         for (int pb = 0; pb < np; pb += 64) {
             const PacxPeak q = qn;
             qn.z = 0.0; qn.spl = -1000.0; qn.slope = 0.0;
@@ -595,8 +646,9 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                                                   __builtin_amdgcn_readlane(__double2loint(q.z), 0));
             const double bz_hi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q.z), n_in - 1),
                                                   __builtin_amdgcn_readlane(__double2loint(q.z), n_in - 1));
-            const double b_lvl = wave_max(lvl);
-            const double b_slope = wave_max(q.slope);
+            /* upper bounds are all the batch screen needs: DPP, no LDS round trips */
+            const double b_lvl = wave_max_upper(lvl);
+            const double b_slope = wave_max_upper(q.slope);
             const int zl = __double2loint(q.z), zh = __double2hiint(q.z);
             const int sl = __double2loint(q.spl), sh = __double2hiint(q.spl);
             const int ul = __double2loint(q.slope), uh = __double2hiint(q.slope);
@@ -644,6 +696,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
             }
         }
         wave_lds_fence();
+        PSY_T(1);
         /* per line: round trip of the winner, max with quiet, SMR term; the MDCT
            line is fetched one iteration ahead */
         double v_next = lines[loff + lane];
@@ -662,18 +715,42 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
             buf[k] = pacx_spl_array((v * v) * 4.0) - thr;
         }
         wave_lds_fence();
+        PSY_T(2);
         double *__restrict__ out = smr + cf * T.band_stride + sb * T.nb_short;
-        for (int b = 0; b < nb; ++b) {
-            const int lo = lower[b], hi = lo + count[b];
-            double m = -INFINITY;
-            for (int k = lo + lane; k < hi; k += 64)
-                m = fmax(m, buf[k]);
-            m = wave_max(m);
-            if (lane == 0)
-                out[b] = m;
+        if (nb <= 32) {
+            /* all band maxima in one transposing reduction (wave_fft.h wave_max_32): six
+               LDS round trips for the lot instead of six per band */
+            double m[32];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) {
+                double v = -INFINITY;
+                const int lo = __builtin_amdgcn_readlane(lo_v, b), hi = __builtin_amdgcn_readlane(hi_v, b);
+                for (int k = lo + lane; k < hi; k += 64)          /* empty for b >= nb */
+                    v = fmax(v, buf[k]);
+                m[b] = v;
+            }
+            wave_max_32(m, lane);
+            if (!(lane & 1) && (lane >> 1) < nb)
+                out[lane >> 1] = m[0];
+        } else {
+            for (int b = 0; b < nb; ++b) {
+                const int lo = lower[b], hi = lo + count[b];
+                double m = -INFINITY;
+                for (int k = lo + lane; k < hi; k += 64)
+                    m = fmax(m, buf[k]);
+                m = wave_max(m);
+                if (lane == 0)
+                    out[b] = m;
+            }
         }
         wave_lds_fence();
+        PSY_T(3);
     }
+#ifdef PACX_PSY_DEBUG
+    if (dbg_on && lane == 0 && M == PACX_M_LONG)
+        for (int k = 0; k < 8; ++k)
+            g_psy_dbg[wv * 16 + k] = dbg_acc[k];
+#endif
 }
 
 /* ------------------------------------------------------------- launchers */
@@ -684,8 +761,11 @@ static void launch_side(const PacxTables &T, const PacxPcmView &in, const uint8_
                         hipStream_t st)
 {
     const dim3 grid((unsigned)n_cf), block(64);
-    if (!short_blocks || mixed)
-        hipLaunchKernelGGL((k_side_long<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks,
+    if ((!short_blocks || mixed) && sbr_mean)
+        hipLaunchKernelGGL((k_side_long<DT, FAST, false>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks,
+                           n_peaks, n_kept, sbr_mean, sbr_overall);
+    else if (!short_blocks || mixed)
+        hipLaunchKernelGGL((k_side_long<DT, FAST, true>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks,
                            n_peaks, n_kept, sbr_mean, sbr_overall);
     if (short_blocks || mixed)
         hipLaunchKernelGGL((k_side_short<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks, n_peaks, n_kept);

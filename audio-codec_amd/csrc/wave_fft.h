@@ -178,4 +178,49 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 
+/* Upper bound of the wave maximum of v, without an LDS round trip: v is rounded UP to
+ * float and the 32-bit maximum runs on the DPP network (row shifts, then row
+ * broadcasts; max is idempotent, so no bank masks are needed), result from lane 63.
+ * For screens that only need "no lane exceeds this". */
+__device__ __forceinline__ double wave_max_upper(double v)
+{
+    float f = (float)v;
+    if ((double)f < v)
+        f = __int_as_float(__float_as_int(f) + (f >= 0.0f ? 1 : -1));     /* next float up (v finite) */
+    int x = __float_as_int(f);
+#define WMU_STEP(CTRL)                                                                            \
+    x = __float_as_int(fmaxf(__int_as_float(x),                                                   \
+                             __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false))))
+    WMU_STEP(0x111);        /* row_shr:1 */
+    WMU_STEP(0x112);        /* row_shr:2 */
+    WMU_STEP(0x114);        /* row_shr:4 */
+    WMU_STEP(0x118);        /* row_shr:8 */
+    WMU_STEP(0x142);        /* row_bcast:15 */
+    WMU_STEP(0x143);        /* row_bcast:31 */
+#undef WMU_STEP
+    return (double)__int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
+/* Maxima of up to 32 per-lane values over the wave, all at once: at every xor step a lane
+ * keeps half of its values and hands the other half to its partner, so the exchange
+ * volume halves per step (16+8+4+2+1+1 values = 64 ds_bpermute for 32 maxima, six
+ * dependent LDS round trips in all -- against six per maximum for wave_max).  On
+ * return m[0] of lane l holds the wave maximum of value number l >> 1. */
+__device__ __forceinline__ void wave_max_32(double m[32], int lane)
+{
+#define WM32_HALVE(OFF, N)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < (N); ++i) {                                             \
+        const bool up = (lane & (OFF)) != 0;                                                      \
+        const double keep = up ? m[(N) + i] : m[i], send = up ? m[i] : m[(N) + i];                \
+        m[i] = fmax(keep, __shfl_xor(send, (OFF), 64));                                           \
+    }
+    WM32_HALVE(32, 16)
+    WM32_HALVE(16, 8)
+    WM32_HALVE(8, 4)
+    WM32_HALVE(4, 2)
+    WM32_HALVE(2, 1)
+#undef WM32_HALVE
+    m[0] = fmax(m[0], __shfl_xor(m[0], 1, 64));
+}
+
 #endif
