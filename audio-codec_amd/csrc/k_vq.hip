@@ -89,6 +89,29 @@ __device__ __forceinline__ uint64_t vq_P(const VqView &V, int l, long long k)
     return V.p_tab[V.row_off[l] + k];
 }
 
+/* start of row l of the two tables, copied to LDS by every workgroup: the lookups of one
+   index term then cost one LDS read and ONE round trip to L2 (four independent loads)
+   instead of four dependent pairs (row offset, then entry) */
+#define VQ_LMAX 1024
+__shared__ int vq_row_off_s[VQ_LMAX + 1];
+
+/* index term of a component of magnitude a >= 1 with k >= a pulses left and l1 dimensions
+   after it: N(l1,k) + 2 (P(l1,k-1) - P(l1,k-a)) (+ N(l1,k-a) if negative) */
+__device__ __forceinline__ unsigned long long vq_term(const VqView &V, int l1, long long k, long long a, bool neg)
+{
+    if (l1 >= 3) {
+        const long long base = vq_row_off_s[l1], ka = k - a;
+        const uint64_t nk = V.n_tab[base + k], pk1 = V.p_tab[base + k - 1];
+        const uint64_t pka = V.p_tab[base + ka], nka = V.n_tab[base + ka];
+        return nk + 2ull * (pk1 - pka) + (neg ? nka : 0ull);
+    }
+    unsigned long long term = vq_N(V, l1, k);
+    term += 2ull * (vq_P(V, l1, k - 1) - vq_P(V, l1, k - a));
+    if (neg)
+        term += vq_N(V, l1, k - a);
+    return term;
+}
+
 /* ---- wave helpers --------------------------------------------------------- */
 __device__ __forceinline__ void vq_fence()
 {
@@ -304,14 +327,8 @@ __device__ __forceinline__ void vq_leaf(const VqView &V, VqOut &o, const double 
                 incl += t;
         }
         const long long k = k_left - (incl - a);
-        if (a >= 1) {
-            const int l = n - i;
-            unsigned long long term = vq_N(V, l - 1, k);
-            term += 2ull * (vq_P(V, l - 1, k - 1) - vq_P(V, l - 1, k - a));
-            if (neg)
-                term += vq_N(V, l - 1, k - a);
-            acc += term;
-        }
+        if (a >= 1)
+            acc += vq_term(V, n - i - 1, k, a, neg);
         k_left -= __shfl(incl, 63, 64);
     }
     const unsigned long long idx = wave_sum_u64(acc);
@@ -381,13 +398,8 @@ __device__ __forceinline__ unsigned long long vq_leaf_group(const VqView &V, dou
     }
     const long long k = (long long)K - (incl - a);
     unsigned long long term = 0;
-    if (a >= 1) {
-        const int ld = n - l;
-        term = vq_N(V, ld - 1, k);
-        term += 2ull * (vq_P(V, ld - 1, k - 1) - vq_P(V, ld - 1, k - a));
-        if (x < 0.0)
-            term += vq_N(V, ld - 1, k - a);
-    }
+    if (a >= 1)
+        term = vq_term(V, n - l - 1, k, a, x < 0.0);
 #pragma unroll
     for (int off = W / 2; off > 0; off >>= 1)
         term = term + (unsigned long long)__shfl_xor((long long)term, off, W);
@@ -710,6 +722,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
 
     for (int i = tid; i < VQ_WORDS; i += 64 * VQ_WAVES)
         words[i] = 0u;
+    for (int i = tid; i <= min(V.l_max, VQ_LMAX); i += 64 * VQ_WAVES)
+        vq_row_off_s[i] = V.row_off[i];
     if (tid == 0)
         *ticket = VQ_WAVES;
     double *scr = scr_all + V.scr_off[wave];
