@@ -969,64 +969,14 @@ __global__ __launch_bounds__(256) void k_scan_offsets(const int32_t *__restrict_
         offs[i] = chunk_off[blockIdx.x] + buf[t] - v;
 }
 
-/* small batches: the whole exclusive scan in one 1024-thread block (each thread
- * owns a run of consecutive records) instead of three launches */
-#define SCAN_SMALL_MAX 32768
-__global__ __launch_bounds__(1024) void k_scan_small(const int32_t *__restrict__ n_bytes, long long n,
-                                                    long long *__restrict__ offs, long long *total)
-{
-    __shared__ long long wave_tot[16];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int per = (int)((n + 1023) / 1024);
-    const long long first = (long long)t * per;
-    long long sum = 0;
-    for (int i = 0; i < per; ++i)
-        if (first + i < n)
-            sum += rec_len(n_bytes[first + i]);
-    long long incl = sum;                                  /* inclusive scan inside the wave */
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const long long v = __shfl_up(incl, off, 64);
-        if (lane >= off)
-            incl += v;
-    }
-    if (lane == 63)
-        wave_tot[wv] = incl;
-    __syncthreads();
-    long long base = 0, all = 0;
-    for (int w = 0; w < 16; ++w) {
-        const long long v = wave_tot[w];
-        if (w < wv)
-            base += v;
-        all += v;
-    }
-    long long run = base + incl - sum;
-    for (int i = 0; i < per; ++i)
-        if (first + i < n) {
-            offs[first + i] = run;
-            run += rec_len(n_bytes[first + i]);
-        }
-    if (total && t == 0)
-        *total = all;
-}
+#define SCAN_SMALL_MAX 32768          /* up to here: k_gather_small, one launch */
 
-/* one wave per record: "<L nBytes" then the payload bytes */
-__global__ __launch_bounds__(64) void k_copy_body(const int32_t *__restrict__ n_bytes, long long n,
-                                                 const long long *__restrict__ offs,
-                                                 const uint8_t *__restrict__ payload, int payload_stride,
-                                                 uint8_t *__restrict__ body, long long capacity)
+/* one record by one wave: "<L nBytes" then the payload bytes */
+__device__ __forceinline__ void copy_record(int nb, long long off, const uint8_t *__restrict__ src,
+                                            uint8_t *__restrict__ body, long long capacity, int lane)
 {
-    const long long i = blockIdx.x;
-    if (i >= n)
+    if (nb <= 0 || off + nb + 4 > capacity)
         return;
-    const int nb = n_bytes[i];
-    if (nb <= 0)
-        return;
-    const long long off = offs[i];
-    if (off + nb + 4 > capacity)
-        return;
-    const uint8_t *src = payload + i * (long long)payload_stride;
-    const int lane = threadIdx.x;
     if (lane < 4)
         body[off + lane] = (uint8_t)((unsigned)nb >> (8 * lane));
     uint8_t *dst = body + off + 4;
@@ -1043,6 +993,70 @@ __global__ __launch_bounds__(64) void k_copy_body(const int32_t *__restrict__ n_
     const int done = head + 4 * n_words;
     if (done + lane < nb && lane < 4)
         dst[done + lane] = src[done + lane];
+}
+
+__global__ __launch_bounds__(64) void k_copy_body(const int32_t *__restrict__ n_bytes, long long n,
+                                                 const long long *__restrict__ offs,
+                                                 const uint8_t *__restrict__ payload, int payload_stride,
+                                                 uint8_t *__restrict__ body, long long capacity)
+{
+    const long long i = blockIdx.x;
+    if (i >= n)
+        return;
+    copy_record(n_bytes[i], offs[i], payload + i * (long long)payload_stride, body, capacity, threadIdx.x);
+}
+
+/* Small batches (the bench batch): scan and copy in ONE launch, no dependency between
+ * workgroups.  A 4-wave workgroup owns GATHER_REC consecutive records; it finds its
+ * byte offset by adding up the lengths of ALL earlier records itself (coalesced 4-byte
+ * reads that hit L2: n/2 entries on average, 8 MB over the whole grid at n = 8192),
+ * scans its own records in one wave and copies them, one wave per record.  Sums fit
+ * 32 bits: n <= SCAN_SMALL_MAX records of at most payload_stride + 4 bytes. */
+#define GATHER_REC 16
+__global__ __launch_bounds__(256) void k_gather_small(const int32_t *__restrict__ n_bytes, long long n,
+                                                     const uint8_t *__restrict__ payload, int payload_stride,
+                                                     uint8_t *__restrict__ body, long long capacity,
+                                                     long long *__restrict__ total)
+{
+    __shared__ int part[4];
+    __shared__ int offs_s[GATHER_REC + 1];
+    __shared__ int len_s[GATHER_REC];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long long first = (long long)blockIdx.x * GATHER_REC;
+    int acc = 0;
+    for (long long j = t; j < first; j += 256)
+        acc += (int)rec_len(n_bytes[j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        acc += __shfl_xor(acc, off, 64);
+    if (lane == 0)
+        part[wv] = acc;
+    __syncthreads();
+    if (wv == 0) {
+        const int base = part[0] + part[1] + part[2] + part[3];
+        const int nb = (lane < GATHER_REC && first + lane < n) ? n_bytes[first + lane] : 0;
+        const int len = (int)rec_len(nb);
+        int incl = len;
+#pragma unroll
+        for (int off = 1; off < GATHER_REC; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += v;
+        }
+        if (lane < GATHER_REC) {
+            offs_s[lane] = base + incl - len;
+            len_s[lane] = nb;
+        }
+        if (lane == GATHER_REC - 1) {
+            offs_s[GATHER_REC] = base + incl;
+            if (total && first + GATHER_REC >= n)
+                *total = (long long)(base + incl);
+        }
+    }
+    __syncthreads();
+    for (int r = wv; r < GATHER_REC && first + r < n; r += 4)
+        copy_record(len_s[r], (long long)offs_s[r], payload + (first + r) * (long long)payload_stride, body,
+                    capacity, lane);
 }
 
 /* ------------------------------------------------------------- launchers */
@@ -1122,9 +1136,8 @@ void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stri
     if (n_cf <= 0)
         return;
     if (n_cf <= SCAN_SMALL_MAX) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, n_bytes, n_cf, offs_buf, total);
-        hipLaunchKernelGGL(k_copy_body, dim3((unsigned)n_cf), dim3(64), 0, st, n_bytes, n_cf, offs_buf, payload,
-                           payload_stride, body, capacity);
+        hipLaunchKernelGGL(k_gather_small, dim3((unsigned)((n_cf + GATHER_REC - 1) / GATHER_REC)), dim3(256), 0, st,
+                           n_bytes, n_cf, payload, payload_stride, body, capacity, total);
         return;
     }
     const long long n_chunks = (n_cf + SCAN_CHUNK - 1) / SCAN_CHUNK;
