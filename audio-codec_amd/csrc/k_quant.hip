@@ -1007,12 +1007,12 @@ __global__ __launch_bounds__(64) void k_copy_body(const int32_t *__restrict__ n_
 }
 
 /* Small batches (the bench batch): scan and copy in ONE launch, no dependency between
- * workgroups.  A 4-wave workgroup owns GATHER_REC consecutive records; it finds its
+ * workgroups.  A 4-wave workgroup owns GATHER_REC consecutive records (8); it finds its
  * byte offset by adding up the lengths of ALL earlier records itself (coalesced 4-byte
  * reads that hit L2: n/2 entries on average, 8 MB over the whole grid at n = 8192),
  * scans its own records in one wave and copies them, one wave per record.  Sums fit
  * 32 bits: n <= SCAN_SMALL_MAX records of at most payload_stride + 4 bytes. */
-#define GATHER_REC 16
+#define GATHER_REC 8
 __global__ __launch_bounds__(256) void k_gather_small(const int32_t *__restrict__ n_bytes, long long n,
                                                      const uint8_t *__restrict__ payload, int payload_stride,
                                                      uint8_t *__restrict__ body, long long capacity,
@@ -1024,8 +1024,13 @@ __global__ __launch_bounds__(256) void k_gather_small(const int32_t *__restrict_
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const long long first = (long long)blockIdx.x * GATHER_REC;
     int acc = 0;
-    for (long long j = t; j < first; j += 256)
-        acc += (int)rec_len(n_bytes[j]);
+    const int4 *__restrict__ nb4 = (const int4 *)n_bytes;       /* first is a multiple of GATHER_REC >= 4 */
+    const int n4 = (int)(first >> 2);
+#pragma unroll 8
+    for (int j = t; j < n4; j += 256) {
+        const int4 v = nb4[j];
+        acc += (int)(rec_len(v.x) + rec_len(v.y) + rec_len(v.z) + rec_len(v.w));
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
         acc += __shfl_xor(acc, off, 64);
