@@ -534,7 +534,8 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 #define MASK_OCC 3                 /* waves per SIMD the register budget is set for */
 #endif
 #ifndef MASK_LDS_TABLES
-#define MASK_LDS_TABLES 3          /* bit 0: Bark table in LDS, bit 1: threshold-in-quiet in LDS */
+#define MASK_LDS_TABLES 1          /* bit 0: Bark table in LDS, bit 1: threshold-in-quiet in LDS (its 8 KB
+                                      now hold the maskers of the batch, see mk[]) */
 #endif
 #ifndef MASK_WG_PER_CU
 #define MASK_WG_PER_CU 3
@@ -559,6 +560,11 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     __shared__ __attribute__((aligned(16))) double quiet_l[QUIET_LDS ? M : 1];
     __shared__ __attribute__((aligned(16))) double chunk_c[PER][4];        /* zlo-0.5, zhi+0.5, qmin-0.01 */
     __shared__ __attribute__((aligned(16))) double bufs[MASK_WAVES][M];    /* best, then mdct_spl - thr */
+    /* the 64 maskers of the current batch, (z, spl, slope, -) each: a surviving masker is
+       fetched by all lanes with two broadcast LDS reads -- the LDS pipe idles in this
+       kernel, the VALU is its bound, and six v_readlane + two v_mov per survivor were
+       40 % of the evaluation loop's VALU instructions */
+    __shared__ __attribute__((aligned(16))) double mks[MASK_WAVES][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *__restrict__ bark_g = SHORT ? T.bark_short : T.bark_long;
     const double *__restrict__ quiet_g = SHORT ? T.thresh_short : T.thresh_long;
@@ -585,6 +591,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     __syncthreads();
 
     double *buf = bufs[wv];
+    double (*mk)[4] = mks[wv];
     const int nb = SHORT ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
@@ -649,9 +656,11 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
             /* upper bounds are all the batch screen needs: DPP, no LDS round trips */
             const double b_lvl = wave_max_upper(lvl);
             const double b_slope = wave_max_upper(q.slope);
-            const int zl = __double2loint(q.z), zh = __double2hiint(q.z);
-            const int sl = __double2loint(q.spl), sh = __double2hiint(q.spl);
-            const int ul = __double2loint(q.slope), uh = __double2hiint(q.slope);
+            wave_lds_fence();                      /* the previous batch's reads are done */
+            mk[lane][0] = q.z;
+            mk[lane][1] = q.spl;
+            mk[lane][2] = q.slope;
+            wave_lds_fence();
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 /* keep the 3 x 16 chunk constants in LDS (broadcast reads), not hoisted
@@ -680,9 +689,8 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 while (todo) {
                     const int b = __builtin_ctzll(todo);
                     todo &= todo - 1;
-                    const double pz = __hiloint2double(__builtin_amdgcn_readlane(zh, b), __builtin_amdgcn_readlane(zl, b));
-                    const double ps = __hiloint2double(__builtin_amdgcn_readlane(sh, b), __builtin_amdgcn_readlane(sl, b));
-                    const double pu = __hiloint2double(__builtin_amdgcn_readlane(uh, b), __builtin_amdgcn_readlane(ul, b));
+                    const double2 zs = *(const double2 *)mk[b];          /* broadcast reads */
+                    const double pz = zs.x, ps = zs.y, pu = mk[b][2];
                     /* gain = -27 a below the masker, pu a above, 0 inside +-0.5 Bark
                        (a = |dz| - 0.5): select the slope by the sign of dz and clamp a
                        at 0 -- same products as the reference's masked assignments
@@ -690,7 +698,9 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                     const double dz = zj - pz;
                     const double a = fmax(fabs(dz) - 0.5, 0.0);
                     const double gain = (dz < 0.0 ? -27.0 : pu) * a;
-                    bj = fmax(bj, (ps + gain) - 16.0);
+                    /* bare v_max_f64 (no NaNs here): fmax() would re-canonicalise bj every turn */
+                    const double cand = (ps + gain) - 16.0;
+                    asm("v_max_f64 %0, %1, %2" : "=v"(bj) : "v"(bj), "v"(cand));
                 }
                 buf[lane + 64 * j] = bj;
             }
