@@ -272,6 +272,8 @@ void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8
     case 4: LAUNCH(4, 2, 2, true); break;    /* 2 x 4 waves, landing buffer (2 x 72 KB)       */
     case 5: LAUNCH(16, 4, 1, false); break;  /* 16 waves/CU, 128 VGPRs (152 KB LDS)           */
     case 6: LAUNCH(12, 3, 1, false); break;  /* 12 waves/CU in one workgroup (120 KB LDS)     */
+    case 12: LAUNCH(4, 2, 1, false); break;  /* 4 waves/CU (56 KB LDS): room for the side chain */
+    case 13: LAUNCH(6, 3, 1, false); break;  /* 6 waves/CU (72 KB LDS)                          */
     default: LAUNCH(8, 2, 1, false); break;  /* 8 waves/CU, one workgroup per CU              */
     }
 #undef LAUNCH

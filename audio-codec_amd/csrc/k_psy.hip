@@ -722,7 +722,15 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 thr = fmax(thr, pacx_spl_of_intensity_of(bst));
             if (thr_out)
                 thr_out[loff + k] = thr;
-            buf[k] = pacx_spl_array((v * v) * 4.0) - thr;
+            /* pacx_spl_array((v * v) * 4.0), coder/psychoac.py:10-25, with the lean log10 of
+               pacx_exact.h (the argument is positive and normal) */
+            double it = (v * v) * 4.0;
+            if (it == 0.0)
+                it = 1e-8;
+            double spl = 96.0 + 10.0 * pacx_log10_pos(it + PACX_EPS);
+            if (spl < -30.0)
+                spl = -30.0;
+            buf[k] = spl - thr;
         }
         wave_lds_fence();
         PSY_T(2);

@@ -11,6 +11,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #define PACX_HD __host__ __device__ __forceinline__
@@ -213,6 +214,61 @@ PACX_HD int pacx_bit_alloc(double budget, int max_mant_bits, int n_bands,
         }
     }
     return passes;
+}
+
+/* log10 of a positive normal double, for the mask kernel's per-line SPL (its argument is
+ * 4 v^2 + eps with |v| < 8).  The classic argument reduction x = 2^k (1 + f),
+ * sqrt(1/2) < 1 + f < sqrt(2), s = f / (2 + f), a degree-14 odd series in s, and the
+ * head/tail assembly of k log10(2) + log(1 + f) / ln(10) (as in the BSD libm's log10);
+ * error below one ulp.  A third of the instructions of the device library's log10,
+ * which carries the whole evaluation in double-double -- and this kernel is bound by
+ * VALU issue.  NumPy's own log10 is the host libm's (< 1-2 ulp, platform dependent), so
+ * the reference's value is defined to that precision only; the integer codes, checked
+ * against the reference's .pac files, do not depend on the last bit here. */
+PACX_HD double pacx_log10_pos(double x)
+{
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const double ivln10hi = 4.34294481878168880939e-01, ivln10lo = 2.50829467116452752298e-11,
+                 log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int hx = (int)(bits >> 32);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;                 /* mantissa >= sqrt(2): use x/2 */
+    bits = ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32) | (bits & 0xFFFFFFFFull);
+    memcpy(&x, &bits, 8);
+    k += i >> 20;
+    const double f = x - 1.0, dk = (double)k;
+    const double hfsq = (0.5 * f) * f;
+    /* s = f / (2 + f): reciprocal refined twice, then one correction of the quotient */
+    const double d = 2.0 + f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double rc = __builtin_amdgcn_rcp(d);
+#else
+    double rc = 1.0 / d;
+#endif
+    rc = fma(fma(-d, rc, 1.0), rc, rc);
+    rc = fma(fma(-d, rc, 1.0), rc, rc);
+    double sq = f * rc;
+    sq = fma(fma(-d, sq, f), rc, sq);
+    const double z = sq * sq, w = z * z;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double r = sq * (hfsq + (t2 + t1));
+    double hi = f - hfsq;
+    memcpy(&bits, &hi, 8);
+    bits &= 0xFFFFFFFF00000000ull;
+    memcpy(&hi, &bits, 8);
+    const double lo = ((f - hi) - hfsq) + r;
+    double val_hi = hi * ivln10hi;
+    const double y2 = dk * log10_2hi;
+    double val_lo = fma(dk, log10_2lo, fma(lo + hi, ivln10lo, lo * ivln10hi));
+    const double wv = y2 + val_hi;
+    val_lo += (y2 - wv) + val_hi;
+    return val_lo + wv;
 }
 
 /* coder/psychoac.py:10-25, array flavour: exact zero -> 1e-8, floor at -30. */

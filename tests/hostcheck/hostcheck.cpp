@@ -17,6 +17,7 @@ int hc_bit_alloc(double budget, int max_mant, int nb, const int32_t *n_lines, co
                  int32_t *bits, int *hit_cap)
 { return pacx_bit_alloc(budget, max_mant, nb, n_lines, smr, bits, hit_cap); }
 double hc_spl_array(double v) { return pacx_spl_array(v); }
+double hc_log10_pos(double x) { return pacx_log10_pos(x); }
 double hc_round_trip(double x) { return pacx_spl_of_intensity_of(x); }
 double hc_spl_scalar(double v) { return pacx_spl_scalar(v); }
 double hc_bark(double f) { return pacx_bark(f); }

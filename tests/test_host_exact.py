@@ -173,6 +173,24 @@ def test_psycho_scalars(hc, tables):
     assert np.max(np.abs(got - tables["thresh_1024_48000"]) / np.abs(tables["thresh_1024_48000"])) < 1e-12
 
 
+def test_lean_log10_within_one_ulp(hc):
+    """pacx_log10_pos (the mask kernel's per-line log10): against np.log10 evaluated in
+    extended precision, over the range its argument takes (eps .. 4*8^2) and at the
+    powers of ten; the reference's own np.log10 is the host libm's, itself 1-2 ulp."""
+    hc.hc_log10_pos.restype = ctypes.c_double
+    hc.hc_log10_pos.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(11)
+    x = np.concatenate((10.0 ** rng.uniform(-16, 3, 20000), 1.0 + rng.uniform(-0.3, 0.45, 5000),
+                        10.0 ** np.arange(-15, 3), [2.220446049250313e-16, 1e-8 + 2.220446049250313e-16]))
+    got = np.array([hc.hc_log10_pos(float(v)) for v in x])
+    want = (np.log(x.astype(np.longdouble)) / np.log(np.longdouble(10))).astype(np.longdouble)
+    ulp = np.spacing(np.abs(want.astype(np.float64))).astype(np.longdouble)
+    # values next to log10(1) = 0 are measured against the spacing of the argument's distance from 1
+    err = np.abs(got.astype(np.longdouble) - want) / np.maximum(ulp, np.longdouble(1e-300))
+    assert float(err.max()) <= 1.0, float(err.max())
+    assert hc.hc_log10_pos(1.0) == 0.0 and hc.hc_log10_pos(100.0) == 2.0
+
+
 # ------------------------------------------------- gain-shape (PVQ) host tables
 def test_vq_budget_rule(hc):
     """coder/codec.py:292-294 (VQ) and :446-453 (SBR long block: flags ignored)."""
