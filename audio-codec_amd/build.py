@@ -58,12 +58,12 @@ def build(force=False, verbose=True):
 
 def build_phase_debug():
     """libpacx_dbg.so: the same library with k_mdct3.hip and k_psy.hip compiled with
-    -DPACX_MDCT_DEBUG / -DPACX_PSY_DEBUG (in-kernel s_memtime stamps per phase, read by
+    -DPACX_MDCT_DEBUG / -DPACX_PSY_DEBUG / -DPACX_TAIL_DEBUG (in-kernel s_memtime stamps per phase, read by
     tools/mdct_phase_probe.py and tools/psy_phase_probe.py through PACX_LIB).  A
     measuring aid, never loaded by default."""
     build(verbose=False)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    dbg_srcs = {"k_mdct3.hip": "-DPACX_MDCT_DEBUG", "k_psy.hip": "-DPACX_PSY_DEBUG"}
+    dbg_srcs = {"k_mdct3.hip": "-DPACX_MDCT_DEBUG", "k_psy.hip": "-DPACX_PSY_DEBUG", "k_quant.hip": "-DPACX_TAIL_DEBUG"}
     dbg_objs = []
     for src, flag in dbg_srcs.items():
         obj = os.path.join(OBJ, src.replace(".hip", "_dbg.o"))

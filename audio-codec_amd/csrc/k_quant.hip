@@ -630,10 +630,25 @@ __global__ __launch_bounds__(64) void k_pack(PacxTables T, const uint8_t *__rest
 }
 
 /* ------------------------------------------------- fused tail, long blocks */
-/* BitAlloc -> scale factors + mantissas -> payload of one LONG channel-frame in
- * one wave: the three stages above back to back, the lines read once and the
+/* BitAlloc -> scale factors + mantissas -> payload of LONG channel-frames, two per
+ * wave: the three stages above back to back, the lines read once and the
  * mantissas packed straight from registers (same arithmetic, same helpers).
  * Short frames keep the separate kernels. */
+#ifdef PACX_TAIL_DEBUG
+/* phase stamps (s_memtime), summed over all blocks: a measuring aid read by
+   tools/psy_phase_probe.py from a library built with --phase-debug */
+__device__ long long g_tail_dbg[16];
+#define TAIL_T(k) do { long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                       if (threadIdx.x == 0 && tail_last) atomicAdd((unsigned long long *)&g_tail_dbg[k], (unsigned long long)(t_ - tail_last)); \
+                       tail_last = t_; } while (0)
+extern "C" int pacx_debug_read_tail(long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_dbg), sizeof(long long) * n);
+}
+#else
+#define TAIL_T(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
                                                  long long n_cf, int mixed, const double *__restrict__ smr,
                                                  const double *__restrict__ lines,
@@ -647,25 +662,31 @@ __global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *_
     __shared__ unsigned words[PACX_PACK_WORDS];
     __shared__ double cp[2][32];
     __shared__ unsigned long long bmax[PACX_MAX_BANDS];
-    __shared__ int ba_s[PACX_MAX_BANDS], sf_s[PACX_MAX_BANDS], offs[PACX_MAX_BANDS + 1], lower_s[PACX_MAX_BANDS];
+    __shared__ int ba_2[2][PACX_MAX_BANDS], sf_s[PACX_MAX_BANDS], offs[PACX_MAX_BANDS + 1], lower_s[PACX_MAX_BANDS];
     const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
-    const long long cf = blockIdx.x;
-    if (cf >= n_cf)
-        return;
-    const unsigned fl = flags ? flags[cf / n_ch] : 0u;
-    if (mixed && (fl & 2u))
+    /* two channel-frames per wave: BitAlloc is a half-wave job (lanes = bands), so the two
+       halves run it for the two frames at once; scale factors, mantissas and payload
+       then take the whole wave, one frame after the other */
+    const long long cf0 = 2 * (long long)blockIdx.x;
+    if (cf0 >= n_cf)
         return;
     const int nb = T.nb_long;
-    const long long boff = cf * T.band_stride;
-    /* 1. BitAlloc on the first half wave */
+#ifdef PACX_TAIL_DEBUG
+    long long tail_last = 0;
+#endif
+    TAIL_T(15);
+    /* 1. BitAlloc */
     {
+        const long long cfh = cf0 + half;
+        const unsigned flh = (flags && cfh < n_cf) ? flags[cfh / n_ch] : 0u;
+        const bool alive = cfh < n_cf && !(mixed && (flh & 2u));
+        const long long boff = cfh * T.band_stride;
         const int32_t *__restrict__ n_lines = T.use_sbr ? T.band_lines_long_alloc : T.band_lines_long;
-        const double budget = pacx_bit_budget(T.target_bps, PACX_M_LONG, 0, (fl & 5u) != 0, T.n_scale_bits,
+        const double budget = pacx_bit_budget(T.target_bps, PACX_M_LONG, 0, (flh & 5u) != 0, T.n_scale_bits,
                                               T.n_mant_size_bits, nb, T.use_vq, T.use_sbr);
         int max_mant = 1 << T.n_mant_size_bits;
         if (max_mant > 16)
             max_mant = 16;
-        const bool alive = (half == 0);
         const bool has = alive && l < nb;
         const double sv = has ? smr[boff + l] : 0.0;
         const int nl = has ? n_lines[l] : 0;
@@ -673,76 +694,90 @@ __global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *_
         bitalloc_half(alive, has, sv, nl, budget, max_mant, cp[half], half, l, bits, cap);
         if (has) {
             bit_alloc[boff + l] = bits;
-            ba_s[l] = bits;
+            ba_2[half][l] = bits;
         }
         if (alive && l == nb && nb < PACX_MAX_BANDS)
-            ba_s[nb] = 0;                                 /* dummy band of the lines no band covers */
+            ba_2[half][nb] = 0;                           /* dummy band of the lines no band covers */
         if (alive && cap && status && l == 0)
-            atomicOr(&status[cf], 4u);
+            atomicOr(&status[cfh], 4u);
     }
-    if (payload)
-        for (int i = lane; i < PACX_PACK_WORDS; i += 64)
-            words[i] = 0u;
-    __syncthreads();
-    /* 2. scale factors + mantissas */
-    const int ov = overall[cf * PACX_SUB];
-    double x[16];
-    uint8_t band[16];
-    int32_t mant[16];
-    quantize_long_core(T, lines + cf * PACX_M_LONG, (double)(1 << ov), bmax, ba_s, sf_s, lane, x, band, mant);
-    if (lane < nb)
-        scale_factor[boff + lane] = sf_s[lane];
-    const int k0 = 16 * lane;
-    if (mantissa) {
+    TAIL_T(0);
+    for (int c = 0; c < 2; ++c) {
+        const long long cf = cf0 + c;
+        if (cf >= n_cf)
+            break;
+        const unsigned fl = flags ? flags[cf / n_ch] : 0u;
+        if (mixed && (fl & 2u))
+            continue;
+        const long long boff = cf * T.band_stride;
+        int *ba_s = ba_2[c];
+        __syncthreads();                                  /* ba_2 visible; words, offs free again */
+        if (payload)
+            for (int i = lane; i < PACX_PACK_WORDS; i += 64)
+                words[i] = 0u;
+        __syncthreads();
+        /* 2. scale factors + mantissas */
+        const int ov = overall[cf * PACX_SUB];
+        double x[16];
+        uint8_t band[16];
+        int32_t mant[16];
+        quantize_long_core(T, lines + cf * PACX_M_LONG, (double)(1 << ov), bmax, ba_s, sf_s, lane, x, band, mant);
+        if (lane < nb)
+            scale_factor[boff + lane] = sf_s[lane];
+        const int k0 = 16 * lane;
+        if (mantissa) {
 #pragma unroll
-        for (int j = 0; j < 16; j += 4)
-            *(int4 *)(mantissa + cf * PACX_M_LONG + k0 + j) = make_int4(mant[j], mant[j + 1], mant[j + 2], mant[j + 3]);
-    }
-    if (!payload)
-        return;
-    /* 3. payload (layout of pack_body) */
-    const int a_mine = (lane < nb) ? ba_s[lane] : 0;
-    const int width = (lane < nb) ? T.n_mant_size_bits + T.n_scale_bits + a_mine * T.band_lines_long[lane] : 0;
-    int incl = width;
+            for (int j = 0; j < 16; j += 4)
+                *(int4 *)(mantissa + cf * PACX_M_LONG + k0 + j) = make_int4(mant[j], mant[j + 1], mant[j + 2], mant[j + 3]);
+        }
+        if (!payload)
+            continue;
+        TAIL_T(1);
+        /* 3. payload (layout of pack_body) */
+        const int a_mine = (lane < nb) ? ba_s[lane] : 0;
+        const int width = (lane < nb) ? T.n_mant_size_bits + T.n_scale_bits + a_mine * T.band_lines_long[lane] : 0;
+        int incl = width;
 #pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off)
-            incl += t;
-    }
-    const int my_off = 3 + T.n_scale_bits + incl - width;
-    if (lane < nb) {
-        offs[lane] = my_off + T.n_mant_size_bits + T.n_scale_bits;
-        lower_s[lane] = T.band_lower_long[lane];
-    }
-    if (lane == nb - 1)
-        offs[nb] = my_off + width;
-    if (lane == 0) {
-        put_bits(words, 0, fl & 1u, 1);
-        put_bits(words, 1, (fl >> 1) & 1u, 1);
-        put_bits(words, 2, (fl >> 2) & 1u, 1);
-        put_bits(words, 3, (unsigned)ov, T.n_scale_bits);
-    }
-    if (lane < nb) {
-        put_bits(words, my_off, (unsigned)(a_mine ? a_mine - 1 : 0), T.n_mant_size_bits);
-        put_bits(words, my_off + T.n_mant_size_bits, (unsigned)sf_s[lane], T.n_scale_bits);
-    }
-    __syncthreads();
+        for (int off = 1; off < 32; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += t;
+        }
+        const int my_off = 3 + T.n_scale_bits + incl - width;
+        if (lane < nb) {
+            offs[lane] = my_off + T.n_mant_size_bits + T.n_scale_bits;
+            lower_s[lane] = T.band_lower_long[lane];
+        }
+        if (lane == nb - 1)
+            offs[nb] = my_off + width;
+        if (lane == 0) {
+            put_bits(words, 0, fl & 1u, 1);
+            put_bits(words, 1, (fl >> 1) & 1u, 1);
+            put_bits(words, 2, (fl >> 2) & 1u, 1);
+            put_bits(words, 3, (unsigned)ov, T.n_scale_bits);
+        }
+        if (lane < nb) {
+            put_bits(words, my_off, (unsigned)(a_mine ? a_mine - 1 : 0), T.n_mant_size_bits);
+            put_bits(words, my_off + T.n_mant_size_bits, (unsigned)sf_s[lane], T.n_scale_bits);
+        }
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int b = band[j];
-        const int a = ba_s[b];
-        if (a)
-            put_bits(words, offs[b] + (k0 + j - lower_s[b]) * a, (unsigned)mant[j], a);
+        for (int j = 0; j < 16; ++j) {
+            const int b = band[j];
+            const int a = ba_s[b];
+            if (a)
+                put_bits(words, offs[b] + (k0 + j - lower_s[b]) * a, (unsigned)mant[j], a);
+        }
+        const int end = offs[nb];
+        __syncthreads();
+        const int nbytes = ((end - 3) + 4 + 7) >> 3;
+        unsigned *dst = (unsigned *)(payload + cf * (long long)payload_stride);
+        for (int i = lane; i < (nbytes + 3) / 4; i += 64)
+            dst[i] = __builtin_bswap32(words[i]);
+        if (lane == 0)
+            n_bytes[cf] = nbytes;
+        TAIL_T(2);
     }
-    const int end = offs[nb];
-    __syncthreads();
-    const int nbytes = ((end - 3) + 4 + 7) >> 3;
-    unsigned *dst = (unsigned *)(payload + cf * (long long)payload_stride);
-    for (int i = lane; i < (nbytes + 3) / 4; i += 64)
-        dst[i] = __builtin_bswap32(words[i]);
-    if (lane == 0)
-        n_bytes[cf] = nbytes;
 }
 
 /* ------------------------------------------------ fused tail, short frames */
@@ -1114,7 +1149,7 @@ void pacx_launch_tail(const PacxTables &T, const uint8_t *flags, int n_ch, long 
     if (n_cf <= 0)
         return;
     const int mixed = flags ? 1 : 0;
-    hipLaunchKernelGGL(k_tail_long, dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch, n_cf, mixed, smr,
+    hipLaunchKernelGGL(k_tail_long, dim3((unsigned)((n_cf + 1) / 2)), dim3(64), 0, st, T, flags, n_ch, n_cf, mixed, smr,
                        lines, overall, bit_alloc, scale_factor, mantissa, status, payload, payload_stride,
                        n_bytes);
     if (mixed && list_short && T.nb_short <= 8) {

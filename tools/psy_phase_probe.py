@@ -13,7 +13,7 @@ pcm = A.synth.stream(n_frames, 2)
 planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=enc.device)
 view = A.engine.PcmView.stream(planar)
 for _ in range(3):
-    enc.encode(view)
+    enc.encode_pack(view)
 torch.cuda.synchronize()
 lib = A._lib.load()
 out = (ctypes.c_longlong * 256)()
@@ -31,3 +31,10 @@ names = ["stage PCM", "Hann window", "2 x FFT-512", "split + intensities", "peak
 print("k_side_long, all blocks, share of a block's time:")
 for k in range(7):
     print("  %-26s %.1f %%" % (names[k], 100.0 * b[k] / b[:7].sum()))
+t = (ctypes.c_longlong * 16)()
+lib.pacx_debug_read_tail.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.pacx_debug_read_tail(t, 16)
+t = np.array(t[:3], dtype=np.float64)
+print("k_tail_long, all blocks, share of a block's time:")
+for name, v in zip(["BitAlloc (half wave)", "scale factors + mantissas", "payload"], t):
+    print("  %-26s %.1f %%" % (name, 100.0 * v / t.sum()))
