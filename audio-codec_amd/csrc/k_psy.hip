@@ -170,20 +170,41 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
     long long side_last = 0;
 #endif
     SIDE_T(15);
-    stage_samples<DT, FAST>(raw, in, cf, 0, PACX_N_LONG, lane);
-    wave_lds_fence();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SIDE_T(0);
-
     const double *__restrict__ hw = T.hann_long, *__restrict__ hwp = T.hann_long_pcm;
     cplx ev[8], od[8];
+    if constexpr (DT == 0 && FAST) {
+        /* int16, unit stride, aligned rows: lane (lane, n1) needs the four consecutive
+           samples 4 (lane + 64 n1) .. +3 -- one 8-byte load, no staging through LDS; the
+           eight PCM loads and the sixteen window loads are all in flight together */
+        const long long f = cf / in.n_ch;
+        const int ch = (int)(cf - f * in.n_ch);
+        const short *src = (const short *)in.base + f * in.frame_stride + ch * in.ch_stride;
+        int2 q[8];
 #pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) {
-        const int i = 4 * (lane + 64 * n1);
-        ev[n1] = make_double2(hann_sample<DT>(raw, i, hw, hwp), hann_sample<DT>(raw, i + 1, hw, hwp));
-        od[n1] = make_double2(hann_sample<DT>(raw, i + 2, hw, hwp), hann_sample<DT>(raw, i + 3, hw, hwp));
+        for (int n1 = 0; n1 < 8; ++n1)
+            q[n1] = *(const int2 *)(src + 4 * (lane + 64 * n1));
+        SIDE_T(0);
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int i = 4 * (lane + 64 * n1);
+            const double2 h01 = *(const double2 *)(hwp + i), h23 = *(const double2 *)(hwp + i + 2);
+            const int c0 = (short)(q[n1].x & 0xFFFF), c1 = q[n1].x >> 16;
+            const int c2 = (short)(q[n1].y & 0xFFFF), c3 = q[n1].y >> 16;
+            ev[n1] = make_double2(h01.x * (double)(c0 == -32768 ? 0 : c0), h01.y * (double)(c1 == -32768 ? 0 : c1));
+            od[n1] = make_double2(h23.x * (double)(c2 == -32768 ? 0 : c2), h23.y * (double)(c3 == -32768 ? 0 : c3));
+        }
+    } else {
+        stage_samples<DT, FAST>(raw, in, cf, 0, PACX_N_LONG, lane);
+        wave_lds_fence();
+        SIDE_T(0);
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int i = 4 * (lane + 64 * n1);
+            ev[n1] = make_double2(hann_sample<DT>(raw, i, hw, hwp), hann_sample<DT>(raw, i + 1, hw, hwp));
+            od[n1] = make_double2(hann_sample<DT>(raw, i + 2, hw, hwp), hann_sample<DT>(raw, i + 3, hw, hwp));
+        }
+        wave_lds_fence();              /* raw fully consumed: region B becomes inten */
     }
-    wave_lds_fence();                  /* raw fully consumed: region B becomes inten */
     SIDE_T(1);
     fft512n_g(ev, tile, T.w512, lane);
     fft512n_g(od, tile, T.w512, lane);
