@@ -102,36 +102,62 @@ template <int DT, bool COMPACT> struct SideLongLds {
     static constexpr int BYTES = A_BYTES + B_BYTES;
 };
 
-/* natural-order 512-point FFT with the per-lane twiddles read from the global
- * W512 table (L1/L2 resident) */
-__device__ __forceinline__ void fft512n_g(cplx v[8], cplx *tile, const cplx *__restrict__ w512, int lane)
+/* natural-order 512-point FFTs (wave_fft.h fft512n) with the per-lane twiddles read from
+ * the global W512 table (L1/L2 resident).  The two FFTs of a long block (even and odd
+ * samples) run together: every twiddle is loaded once and serves both, and the two
+ * transforms take turns on the ONE exchange tile
+ * (a's reads are followed by b's writes without a wait: DS instructions of a wave execute
+ * in order), so one transform's butterflies run while the other's values cross the LDS */
+__device__ __forceinline__ void fft512n_g2(cplx a[8], cplx b[8], cplx *tile, const cplx *__restrict__ w512, int lane)
 {
     const int g = lane >> 3, r = lane & 7;
-    dft8(v);
+    dft8(a);
+    dft8(b);
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1)
-        v[k1] = c_mul(v[k1], w512[(lane * k1) & 511]);
+    for (int k1 = 1; k1 < 8; ++k1) {
+        const cplx w = w512[(lane * k1) & 511];
+        a[k1] = c_mul(a[k1], w);
+        b[k1] = c_mul(b[k1], w);
+    }
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1)
-        tile[64 * k1 + (lane ^ (8 * k1))] = v[k1];
+        tile[64 * k1 + (lane ^ (8 * k1))] = a[k1];
     wave_lds_fence();
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2)
-        v[n2] = tile[64 * g + 8 * (n2 ^ g) + r];
-    wave_lds_fence();
-    dft8(v);
+        a[n2] = tile[64 * g + 8 * (n2 ^ g) + r];
 #pragma unroll
-    for (int k2 = 1; k2 < 8; ++k2)
-        v[k2] = c_mul(v[k2], w512[(8 * r * k2) & 511]);
+    for (int k1 = 0; k1 < 8; ++k1)
+        tile[64 * k1 + (lane ^ (8 * k1))] = b[k1];
+    dft8(a);
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2)
+        b[n2] = tile[64 * g + 8 * (n2 ^ g) + r];
+    dft8(b);
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2) {
+        const cplx w = w512[(8 * r * k2) & 511];
+        a[k2] = c_mul(a[k2], w);
+        b[k2] = c_mul(b[k2], w);
+    }
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2)
-        tile[64 * g + 8 * k2 + (r ^ g)] = v[k2];
+        tile[64 * g + 8 * k2 + (r ^ g)] = a[k2];
     wave_lds_fence();
 #pragma unroll
     for (int n3 = 0; n3 < 8; ++n3)
-        v[n3] = tile[64 * r + 8 * g + (n3 ^ r)];
+        a[n3] = tile[64 * r + 8 * g + (n3 ^ r)];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2)
+        tile[64 * g + 8 * k2 + (r ^ g)] = b[k2];
+    dft8(a);
     wave_lds_fence();
-    dft8(v);
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3)
+        b[n3] = tile[64 * r + 8 * g + (n3 ^ r)];
+    wave_lds_fence();
+    dft8(b);
 }
 
 __device__ __forceinline__ double bperm_f64(double v, int src_lane)
@@ -206,8 +232,7 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
         wave_lds_fence();              /* raw fully consumed: region B becomes inten */
     }
     SIDE_T(1);
-    fft512n_g(ev, tile, T.w512, lane);
-    fft512n_g(od, tile, T.w512, lane);
+    fft512n_g2(ev, od, tile, T.w512, lane);
     SIDE_T(2);
     /* ev[k3] = E[k], od[k3] = O[k], k = lane + 64 k3.  Z[k] = E[k] + W1024^k O[k],
        Z[k+512] = E[k] - W1024^k O[k].  Bins k and k+512 pair with Z[1024-k] and
@@ -217,7 +242,8 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) {
         const int k = lane + 64 * k3;
-        const cplx t = c_mul(T.w1024[k], od[k3]);
+        const cplx w1k = T.w1024[k], w2k = T.w2048[k];
+        const cplx t = c_mul(w1k, od[k3]);
         const cplx zk = c_add(ev[k3], t), zk5 = c_sub(ev[k3], t);
         /* partner E[m], O[m] */
         cplx pe, po;
@@ -229,15 +255,16 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
             pe = ev[(8 - k3) & 7];
             po = od[(8 - k3) & 7];
         }
-        const int m = (512 - k) & 511;
-        const cplx tm = c_mul(T.w1024[m], po);
+        /* W1024^m = -conj(W1024^k), W2048^(k+512) = -j W2048^k: the tables are built
+           exactly symmetric (pacx_api.hip), so these ARE their entries m and k + 512 */
+        const cplx tm = c_mul(make_double2(-w1k.x, w1k.y), po);
         cplx zm = c_add(pe, tm), zm5 = c_sub(pe, tm);       /* Z[m], Z[m+512] */
         if (k == 0) {                                       /* bins 0 and 512 pair with themselves */
             zm5 = zk;
             zm = zk5;
         }
-        inten[k] = pair_intensity(zk, zm5, T.w2048[k], T.norm_long);
-        inten[k + 512] = pair_intensity(zk5, zm, T.w2048[k + 512], T.norm_long);
+        inten[k] = pair_intensity(zk, zm5, w2k, T.norm_long);
+        inten[k + 512] = pair_intensity(zk5, zm, make_double2(w2k.y, -w2k.x), T.norm_long);
         if (k == 0)
             inten[1024] = pair_intensity(zk, zk, T.w2048[1024], T.norm_long);
     }

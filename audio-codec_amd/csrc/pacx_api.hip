@@ -340,8 +340,19 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         t = unit_circle(512, 8, 1, 8192);  TRY(upload(h, t.data(), t.size(), &T.tw_long));
         t = unit_circle(64, 8, 1, 1024);   TRY(upload(h, t.data(), t.size(), &T.tw_short));
         t = unit_circle(512, 2, 0, 512);   TRY(upload(h, t.data(), t.size(), &T.w512));
-        t = unit_circle(512, 2, 0, 1024);  TRY(upload(h, t.data(), t.size(), &T.w1024));
-        t = unit_circle(1025, 2, 0, 2048); TRY(upload(h, t.data(), t.size(), &T.w2048));
+        /* the two tables of the long side chain's real-FFT split are made exactly
+           symmetric (a handful of entries move by one ulp), so that the kernel derives
+           W1024^(512-k) = -conj(W1024^k) and W2048^(k+512) = -j W2048^k from the entry it
+           has already loaded instead of fetching them */
+        t = unit_circle(512, 2, 0, 1024);
+        for (int k = 1; k < 256; ++k)
+            t[512 - k] = make_double2(-t[k].x, t[k].y);
+        t[256].x = 0.0;
+        TRY(upload(h, t.data(), t.size(), &T.w1024));
+        t = unit_circle(1025, 2, 0, 2048);
+        for (int k = 0; k <= 512; ++k)
+            t[k + 512] = make_double2(t[k].y, -t[k].x);
+        TRY(upload(h, t.data(), t.size(), &T.w2048));
         t = unit_circle(64, 2, 0, 128);    TRY(upload(h, t.data(), t.size(), &T.w128));
         t = unit_circle(129, 2, 0, 256);   TRY(upload(h, t.data(), t.size(), &T.w256));
     }
