@@ -77,8 +77,21 @@ def build_phase_debug():
     return out
 
 
+def build_tools():
+    """tools/hbm_mix_probe.hip -> variants/hbm_mix_probe (stand-alone HIP program, a measuring aid)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out_dir = os.path.join(HERE, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "hbm_mix_probe")
+    subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-Wno-unused-result",
+                           os.path.join(HERE, "..", "tools", "hbm_mix_probe.hip"), "-o", out])
+    return out
+
+
 if __name__ == "__main__":
-    if "--phase-debug" in sys.argv:
+    if "--tools" in sys.argv:
+        print(build_tools())
+    elif "--phase-debug" in sys.argv:
         print(build_phase_debug())
     else:
         print(build(force="--force" in sys.argv))
