@@ -729,7 +729,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                    of the two distances is positive) */
                 const double ub = q.slope * fmax(lo_edge - q.z, 0.0) + -27.0 * fmax(q.z - hi_edge, 0.0);
                 const bool live = (q.slope > 0.0 && q.spl > -1000.0) || (lvl + ub > need);
-                unsigned long long todo = __ballot(live);
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
                 if (!todo)
                     continue;
                 const double zj = bark_s[lane + 64 * j];
