@@ -688,6 +688,10 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
             qn = pk[lane];
         PSY_T(0);
         for (int pb = 0; pb < np; pb += 64) {
+#ifdef PACX_PSY_DEBUG
+            if (lane == 0 && M == PACX_M_LONG)
+                atomicAdd((unsigned long long *)&g_psy_dbg[163], 1ull);
+#endif
             const PacxPeak q = qn;
             qn.z = 0.0; qn.spl = -1000.0; qn.slope = 0.0;
             if (pb + 64 + lane < np)
@@ -730,6 +734,13 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 const double ub = q.slope * fmax(lo_edge - q.z, 0.0) + -27.0 * fmax(q.z - hi_edge, 0.0);
                 const bool live = (q.slope > 0.0 && q.spl > -1000.0) || (lvl + ub > need);
                 unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
+#ifdef PACX_PSY_DEBUG
+                if (lane == 0 && M == PACX_M_LONG) {      /* screen statistics */
+                    atomicAdd((unsigned long long *)&g_psy_dbg[160], 1ull);
+                    atomicAdd((unsigned long long *)&g_psy_dbg[161], (unsigned long long)__popcll(todo));
+                    atomicAdd((unsigned long long *)&g_psy_dbg[162], todo ? 1ull : 0ull);
+                }
+#endif
                 if (!todo)
                     continue;
                 const double zj = bark_s[lane + 64 * j];

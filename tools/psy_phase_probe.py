@@ -31,6 +31,10 @@ names = ["stage PCM", "Hann window", "2 x FFT-512", "split + intensities", "peak
 print("k_side_long, all blocks, share of a block's time:")
 for k in range(7):
     print("  %-26s %.1f %%" % (names[k], 100.0 * b[k] / b[:7].sum()))
+st = np.array(out[160:164], dtype=np.float64)
+n_units = 3 * 2 * n_frames          # three encode calls
+print("k_mask<1024> screen, per channel-frame: %.1f masker batches, %.1f (batch, chunk) pairs past the batch screen, "
+      "%.1f of them with survivors, %.1f survivor evaluations" % (st[3] / n_units, st[0] / n_units, st[2] / n_units, st[1] / n_units))
 t = (ctypes.c_longlong * 16)()
 lib.pacx_debug_read_tail.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.pacx_debug_read_tail(t, 16)
