@@ -151,6 +151,35 @@ def test_mdct_layouts_agree(A, torch):
     assert np.max(np.abs(a[4 * 2 + 1] - want)) <= MDCT_TOL * np.max(np.abs(want))
 
 
+def test_mdct_pipelined_kernel_equals_one_frame_kernel(A, torch):
+    """The headline MDCT kernel (k_mdct_long_x2p: two frames per wave taking turns on one
+    LDS tile, PCM prefetched by an assembly-issued LDS-DMA, counted waits) and the
+    one-frame-per-wave kernel a batch WITH flags goes to (k_mdct_long_v2) do the same
+    arithmetic frame by frame: lines and overall scales must agree bit for bit on every
+    frame of a batch large enough that each wave runs many iterations, twice over (a
+    race in the tile hand-over or a late DMA would show as a sporadic difference).
+    Includes the -32768 code (refold path) and an odd number of channel-frames."""
+    enc = enc_for(A, 48000)
+    n_frames = 16384 + 3                                  # 32774 cf: ragged last pairs
+    pcm = np.tile(A.synth.stream(4096, 2), (5, 1))[:n_frames * 1024].copy()
+    pcm[12345, 0] = -32768
+    pcm[1024 * 7000 + 5, 1] = -32768
+    planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=enc.device)
+    view = A.engine.PcmView.stream(planar)
+    zeros = np.zeros(n_frames, np.uint8)
+    ref_lines, ref_scale = enc.mdct(view, flags=zeros, want_scale=True)          # k_mdct_long_v2
+    for _ in range(2):
+        lines, scale = enc.mdct(view, want_scale=True)                           # k_mdct_long_x2p
+        assert torch.equal(lines.view(torch.int64), ref_lines.view(torch.int64))
+        assert torch.equal(scale, ref_scale)
+    # one channel (odd cf count inside a pair) and a batch smaller than one pair per wave
+    mono = torch.as_tensor(A.synth.planar_with_halo(pcm[:1024 * 37, :1]), device=enc.device)
+    v1 = A.engine.PcmView.stream(mono)
+    a = enc.mdct(v1, flags=np.zeros(37, np.uint8))
+    b = enc.mdct(v1)
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+
+
 # ------------------------------------------------------------ psychoacoustics
 @pytest.mark.parametrize("kind", ["long", "short"])
 def test_threshold_and_smr_golden(A, torch, stages, kind):
