@@ -768,15 +768,17 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
         PSY_T(1);
         /* per line: round trip of the winner, max with quiet, SMR term; the MDCT
            line is fetched one iteration ahead */
-        double v_next = lines[loff + lane];
+        double v_next = lines[loff + lane], q_next = quiet_s[lane];
 #pragma unroll 1
         for (int j = 0; j < PER; ++j) {
             const int k = lane + 64 * j;
             const double v = v_next;
-            if (j + 1 < PER)
+            double thr = q_next;                           /* threshold in quiet, also one ahead */
+            if (j + 1 < PER) {
                 v_next = lines[loff + k + 64];
+                q_next = quiet_s[k + 64];
+            }
             const double bst = buf[k];
-            double thr = quiet_s[k];
             if (bst > -INFINITY)
                 thr = fmax(thr, pacx_spl_of_intensity_of(bst));
             if (thr_out)
