@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
                 }
                 v[n1] = c_mul(make_double2(re, im), twl[n]);
             }
-            if (pass || !__ballot(lowest == -32768))
+            if (pass || !__builtin_amdgcn_ballot_w64(lowest == -32768))
                 break;
             /* rare: rewrite the -32768 codes of this frame to 0 in LDS and fold again */
             wave_lds_fence();
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
         if (scale_out) {
             const int s = pacx_scale_factor(mx, T.n_scale_bits, 5);
             for (int bit = T.n_scale_bits - 1; bit >= 0; --bit)
-                if (!__ballot(s < lo + (1 << bit)))
+                if (!__builtin_amdgcn_ballot_w64(s < lo + (1 << bit)))
                     lo += 1 << bit;
         }
         double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);

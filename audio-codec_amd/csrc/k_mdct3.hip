@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2(PacxTables T,
                     v[f][n1] = c_mul(make_double2(re, im), tw);
                 }
             }
-            if (pass || !__ballot(lowest[0] == -32768 || lowest[1] == -32768))
+            if (pass || !__builtin_amdgcn_ballot_w64(lowest[0] == -32768 || lowest[1] == -32768))
                 break;
             wave_lds_fence();
 #pragma unroll
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
         if (scale_out) {
             const int s = pacx_scale_factor(mx, T.n_scale_bits, 5);
             for (int bit = T.n_scale_bits - 1; bit >= 0; --bit)
-                if (!__ballot(s < lo + (1 << bit)))
+                if (!__builtin_amdgcn_ballot_w64(s < lo + (1 << bit)))
                     lo += 1 << bit;
         }
         double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
                     v[f][n1] = c_mul(make_double2(re, im), tw);
                 }
             }
-            if (pass || !__ballot(lowest[0] == -32768 || lowest[1] == -32768))
+            if (pass || !__builtin_amdgcn_ballot_w64(lowest[0] == -32768 || lowest[1] == -32768))
                 break;
             wave_lds_fence();
 #pragma unroll

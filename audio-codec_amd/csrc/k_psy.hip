@@ -284,7 +284,7 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
             const double c = inten[i];
             pk = (c > inten[i - 1]) && (i == 1024 || c > inten[i + 1]);
         }
-        const unsigned long long m = __ballot(pk);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pk);
         if (pk)
             idx[count + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
         count += __popcll(m);
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
             const double c = ig[i];
             pk = (c > ig[i - 1]) && (i == 128 || c > ig[i + 1]);
         }
-        const unsigned m = (unsigned)((__ballot(pk) >> (8 * g)) & 0xFFull);
+        const unsigned m = (unsigned)((__builtin_amdgcn_ballot_w64(pk) >> (8 * g)) & 0xFFull);
         if (pk)
             pk_idx[g][count + __popc(m & ((1u << r) - 1u))] = (unsigned char)i;
         count += __popc(m);

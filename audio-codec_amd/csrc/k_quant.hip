@@ -65,12 +65,12 @@ __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, in
     unsigned pmask = 0;
     int nd = 0, lt = 0, le = 0;
     double want = 0.0, frac = 0.0;
-    while (__ballot(!done)) {
-        if (__ballot(dropped != cache_key)) {    /* wave-uniform: both halves recompute together */
+    while (__builtin_amdgcn_ballot_w64(!done)) {
+        if (__builtin_amdgcn_ballot_w64(dropped != cache_key)) {    /* wave-uniform: both halves recompute together */
             cache_key = dropped;
             have_rank = false;
             valid = has && !((dropped >> l) & 1u);
-            const unsigned vmask = (unsigned)(__ballot(valid) >> (32 * half));
+            const unsigned vmask = (unsigned)(__builtin_amdgcn_ballot_w64(valid) >> (32 * half));
             const int nv = __popc(vmask);
             const int pos = __popc(vmask & lt_mask);
             const int total_i = half_sum_i(valid ? nl : 0);
@@ -106,12 +106,12 @@ __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, in
             want = budget / total + (1.0 / PACX_DB_PER_BIT) * (s - mean);
             frac = (want - floor(want)) - 0.5;
             posf = valid && frac > 0.0;
-            pmask = (unsigned)(__ballot(posf) >> (32 * half));
+            pmask = (unsigned)(__builtin_amdgcn_ballot_w64(posf) >> (32 * half));
             nd = __popc(pmask);
         }
         int new_bits = bits;
         int new_flip = n_flip;
-        if (__ballot(!have_rank && n_flip > 0 && n_flip <= nd)) {   /* ladder ranks of this set */
+        if (__builtin_amdgcn_ballot_w64(!have_rank && n_flip > 0 && n_flip <= nd)) {   /* ladder ranks of this set */
             have_rank = true;
             lt = 0;
             le = 0;
@@ -128,7 +128,7 @@ __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, in
         } else {
             double level = 0.0;
             const bool sel = n_flip > 0 && posf && lt <= n_flip - 1 && n_flip - 1 < le;
-            const unsigned smask = (unsigned)(__ballot(sel) >> (32 * half));
+            const unsigned smask = (unsigned)(__builtin_amdgcn_ballot_w64(sel) >> (32 * half));
             const double pick = __shfl(frac, smask ? __builtin_ctz(smask) : 0, 32);
             if (n_flip > 0)
                 level = pick;                                /* ladder[n_flip-1] */
@@ -140,7 +140,7 @@ __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, in
         const bool drop = has && new_bits < 2;
         if (drop || !has)
             new_bits = 0;
-        const unsigned now = (unsigned)(__ballot(drop) >> (32 * half));
+        const unsigned now = (unsigned)(__builtin_amdgcn_ballot_w64(drop) >> (32 * half));
         const int spent = half_sum_i(new_bits * nl);
         if (!done) {
             const bool stable = (now == dropped);
@@ -162,7 +162,7 @@ __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, in
         /* cycle detection on the state after this pass (per half wave) */
         {
             const bool same_lane = (bits == snap_bits);
-            const unsigned eq = (unsigned)(__ballot(same_lane || !has) >> (32 * half));
+            const unsigned eq = (unsigned)(__builtin_amdgcn_ballot_w64(same_lane || !has) >> (32 * half));
             const bool same = (eq == 0xFFFFFFFFu) && dropped == snap_dropped && n_flip == snap_flip;
             if (!done && stop_at < 0 && same) {
                 const int period = passes - snap_pass;

@@ -421,7 +421,7 @@ __device__ __forceinline__ void vq_leaf_pair(const VqView &V, VqOut &o, const do
     const unsigned long long idx_mid = (unsigned long long)__shfl((long long)term, 0, 64);
     const unsigned long long idx_side = (unsigned long long)__shfl((long long)term, 32, 64);
     const int w_mid = __shfl(width, 0, 64), w_side = __shfl(width, 32, 64);
-    const unsigned long long okm = __ballot(ok);
+    const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
     if (!(okm & 1ull) || !((okm >> 32) & 1ull))
         o.flags |= PACX_ST_VQ_UNDEFINED;                  /* an all-zero half: NaN pulses in the reference */
     vq_emit(o, 0, (okm & 1ull) ? idx_mid : 0ull, w_mid, lane);
@@ -494,7 +494,7 @@ __device__ __forceinline__ bool vq_quad_try(const VqView &V, VqOut &o, const dou
     }
     const int a_side = a_rest - a_mid;
     fine = fine && a_mid > 0 && a_mid <= PACX_VQ_SPLIT_BITS && a_side > 0 && a_side <= PACX_VQ_SPLIT_BITS;
-    if (__ballot(!fine))
+    if (__builtin_amdgcn_ballot_w64(!fine))
         return false;                                       /* not two bottom splits: ordinary walk */
     /* the four leaves, one per 16-lane quarter: (a.mid, a.side, b.mid, b.side) */
     const int q = lane >> 4, ll = lane & 15;
@@ -506,7 +506,7 @@ __device__ __forceinline__ bool vq_quad_try(const VqView &V, VqOut &o, const dou
     const int width = V.w_of[hh * 33 + lbits];
     bool ok;
     const unsigned long long term = vq_leaf_group<16>(V, x, hh, K, ll, ok);
-    const unsigned long long okm = __ballot(ok);
+    const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
     if ((okm & 0x0001000100010001ull) != 0x0001000100010001ull)
         o.flags |= PACX_ST_VQ_UNDEFINED;
 #pragma unroll
