@@ -59,6 +59,14 @@ struct VqView {
     int scr_off[VQ_WAVES + 1];         /* doubles: scratch of wave w = [scr_off[w], scr_off[w+1]) */
 };
 
+/* read-only table entry at a wave-uniform address: through the constant address space the
+   load becomes a scalar (SMEM) one -- the compiler otherwise issues a vector load with a
+   full vmcnt wait for every table read that follows one of the kernel's own stores */
+template <typename T> __device__ __forceinline__ T ldc(const T *p)
+{
+    return *(const __attribute__((address_space(4))) T *)(unsigned long long)p;
+}
+
 /* ---- table access --------------------------------------------------------- */
 __device__ __forceinline__ uint64_t vq_N(const VqView &V, int l, long long k)
 {
@@ -236,8 +244,8 @@ __device__ __forceinline__ void vq_quantize_emit(VqOut &o, double x, int n_bits,
 __device__ __forceinline__ void vq_leaf(const VqView &V, VqOut &o, const double *xs, int n, int bits,
                                         double *t1, double *t2, int lane)
 {
-    const int K = V.k_of[n * 33 + bits];
-    const int width = V.w_of[n * 33 + bits];
+    const int K = ldc(&V.k_of[n * 33 + bits]);
+    const int width = ldc(&V.w_of[n * 33 + bits]);
     if (K < 0) {                              /* a 1-dimensional leaf: the reference never returns */
         o.flags |= PACX_ST_VQ_UNDEFINED;
         return;
@@ -412,8 +420,8 @@ __device__ __forceinline__ void vq_leaf_pair(const VqView &V, VqOut &o, const do
 {
     const int h = lane >> 5, l = lane & 31;
     const int bits = h ? bits_side : bits_mid;
-    const int K = V.k_of[n * 33 + bits];
-    const int width = V.w_of[n * 33 + bits];
+    const int K = ldc(&V.k_of[n * 33 + bits]);
+    const int width = ldc(&V.w_of[n * 33 + bits]);
     const double x = (l < n) ? (h ? side[l] : mid[l]) : 0.0;
     bool ok;
     const unsigned long long term = vq_leaf_group<32>(V, x, n, K, l, ok);
@@ -459,7 +467,7 @@ __device__ __forceinline__ bool vq_quad_try(const VqView &V, VqOut &o, const dou
     if (s_l2 != 0.0)
         sd = sd / s_l2;
     const double theta = (m_l2 == 0.0) ? 0.0 : atan(s_l2 / m_l2);
-    const int a_theta = (int)floor((double)bits / (double)hh + V.half_log2[hh]);
+    const int a_theta = (int)floor((double)bits / (double)hh + ldc(&V.half_log2[hh]));
     int a_rest = bits - a_theta;
     if (a_rest < 0)
         a_rest = 0;
@@ -502,8 +510,8 @@ __device__ __forceinline__ bool vq_quad_try(const VqView &V, VqOut &o, const dou
     const double from_mid = __shfl(m, 32 * h + ll, 64);
     const double x = (ll < hh) ? ((q & 1) ? from_side : from_mid) : 0.0;
     const int lbits = (q & 1) ? a_side : a_mid;
-    const int K = V.k_of[hh * 33 + lbits];
-    const int width = V.w_of[hh * 33 + lbits];
+    const int K = ldc(&V.k_of[hh * 33 + lbits]);
+    const int width = ldc(&V.w_of[hh * 33 + lbits]);
     bool ok;
     const unsigned long long term = vq_leaf_group<16>(V, x, hh, K, ll, ok);
     const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
@@ -562,7 +570,7 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
             vq_fence();
             const double theta = (m_l2 == 0.0) ? 0.0 : atan(s_l2 / m_l2);
             /* gain_shape_alloc(bits, half): floor(bits/half + 0.5 log2(half)) for the angle */
-            int a_theta = (int)floor((double)bits / (double)half + V.half_log2[half]);
+            int a_theta = (int)floor((double)bits / (double)half + ldc(&V.half_log2[half]));
             int a_rest = bits - a_theta;
             if (a_rest < 0)
                 a_rest = 0;
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
             const double v = A.sbr_mean[cf * PACX_SUB + (b - first_omit)] * up;
             g = sqrt(v * v);
         } else {
-            const int lo = lower[b], cnt = count[b];
+            const int lo = ldc(&lower[b]), cnt = ldc(&count[b]);
             double acc = 0.0;
             for (int i = lane; i < cnt; i += 64) {
                 const double x = lin[lo + i] * up;
@@ -821,9 +829,9 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
             const double g = log(1.0 + 255.0 * fabs(gain / 1.0)) / V.log_mu1;
             vq_quantize_emit(o, g, ba, lane);
         } else {
-            const int lo = lower[b], cnt = count[b];
+            const int lo = ldc(&lower[b]), cnt = ldc(&count[b]);
             const int r_bits = ba * cnt;
-            int bits_gain = (int)floor((double)r_bits / (double)cnt + V.half_log2[cnt]);
+            int bits_gain = (int)floor((double)r_bits / (double)cnt + ldc(&V.half_log2[cnt]));
             int bits_shape = r_bits - bits_gain;
             if (bits_shape < 0)
                 bits_shape = 0;
