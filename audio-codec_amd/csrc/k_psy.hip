@@ -103,19 +103,20 @@ template <int DT, bool COMPACT> struct SideLongLds {
 };
 
 /* natural-order 512-point FFTs (wave_fft.h fft512n) with the per-lane twiddles read from
- * the global W512 table (L1/L2 resident).  The two FFTs of a long block (even and odd
+ * the global W512 table by the caller.  The two FFTs of a long block (even and odd
  * samples) run together: every twiddle is loaded once and serves both, and the two
  * transforms take turns on the ONE exchange tile
  * (a's reads are followed by b's writes without a wait: DS instructions of a wave execute
  * in order), so one transform's butterflies run while the other's values cross the LDS */
-__device__ __forceinline__ void fft512n_g2(cplx a[8], cplx b[8], cplx *tile, const cplx *__restrict__ w512, int lane)
+__device__ __forceinline__ void fft512n_g2(cplx a[8], cplx b[8], cplx *tile, const cplx tw1[7], const cplx tw2[7],
+                                           int lane)
 {
     const int g = lane >> 3, r = lane & 7;
     dft8(a);
     dft8(b);
 #pragma unroll
     for (int k1 = 1; k1 < 8; ++k1) {
-        const cplx w = w512[(lane * k1) & 511];
+        const cplx w = tw1[k1 - 1];
         a[k1] = c_mul(a[k1], w);
         b[k1] = c_mul(b[k1], w);
     }
@@ -137,7 +138,7 @@ __device__ __forceinline__ void fft512n_g2(cplx a[8], cplx b[8], cplx *tile, con
     dft8(b);
 #pragma unroll
     for (int k2 = 1; k2 < 8; ++k2) {
-        const cplx w = w512[(8 * r * k2) & 511];
+        const cplx w = tw2[k2 - 1];
         a[k2] = c_mul(a[k2], w);
         b[k2] = c_mul(b[k2], w);
     }
@@ -198,6 +199,14 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
     SIDE_T(15);
     const double *__restrict__ hw = T.hann_long, *__restrict__ hwp = T.hann_long_pcm;
     cplx ev[8], od[8];
+    /* the FFTs' per-lane twiddles W512^(lane k1) and W64^(r k2) are fetched here, with the PCM
+       and the window: one round trip to L2 for all of them instead of one per FFT stage */
+    cplx tw1[7], tw2[7];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        tw1[k - 1] = T.w512[(lane * k) & 511];
+        tw2[k - 1] = T.w512[(8 * (lane & 7) * k) & 511];
+    }
     if constexpr (DT == 0 && FAST) {
         /* int16, unit stride, aligned rows: lane (lane, n1) needs the four consecutive
            samples 4 (lane + 64 n1) .. +3 -- one 8-byte load, no staging through LDS; the
@@ -232,7 +241,7 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
         wave_lds_fence();              /* raw fully consumed: region B becomes inten */
     }
     SIDE_T(1);
-    fft512n_g2(ev, od, tile, T.w512, lane);
+    fft512n_g2(ev, od, tile, tw1, tw2, lane);
     SIDE_T(2);
     /* ev[k3] = E[k], od[k3] = O[k], k = lane + 64 k3.  Z[k] = E[k] + W1024^k O[k],
        Z[k+512] = E[k] - W1024^k O[k].  Bins k and k+512 pair with Z[1024-k] and
