@@ -689,8 +689,25 @@ struct VqArgs {
     int log_cap;               /* entries per band                          */
 };
 
+#ifdef PACX_VQ_DEBUG
+/* phase stamps (s_memtime) summed over all waves: a measuring aid (build.py --phase-debug) */
+__device__ long long g_vq_dbg[16];
+#define VQ_T(k) do { long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                     if ((threadIdx.x & 63) == 0 && vq_last) atomicAdd((unsigned long long *)&g_vq_dbg[k], (unsigned long long)(t_ - vq_last)); \
+                     vq_last = t_; } while (0)
+extern "C" int pacx_debug_read_vq(long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vq_dbg), sizeof(long long) * n);
+}
+#else
+#define VQ_T(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqView V, VqArgs A)
 {
+#ifdef PACX_VQ_DEBUG
+    long long vq_last = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *words = (unsigned *)smem;                               /* VQ_WORDS        */
     double *gain_s = (double *)(smem + VQ_WORDS * 4);                 /* 32              */
@@ -738,6 +755,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
     int *stack = stack_all + wave * 2 * VQ_DEPTH;
     const uint8_t *order = is_short ? V.order_short : V.order_long;
 
+    VQ_T(15);
     /* phase A: gains (np.linalg.norm of the scaled band; an omitted band is the
        one-element vector [mean |FFT|]) */
     for (int b = wave; b < nb; b += VQ_WAVES) {
@@ -757,7 +775,9 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
         if (lane == 0)
             gain_s[b] = g;
     }
+    VQ_T(0);
     __syncthreads();
+    VQ_T(1);
     if (tid < 64) {
         /* final allocations, band positions, header fields */
         int ba = 0, r_bits = 0;
@@ -794,6 +814,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
                      T.n_mant_size_bits);
     }
     __syncthreads();
+    VQ_T(2);
 
     /* phase B: bands largest first; wave w starts on the (w+1)-th largest, the
        rest go by ticket */
@@ -857,7 +878,9 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
     }
     if (raised && A.status && lane == 0)
         atomicOr(&A.status[cf], raised);
+    VQ_T(3);
     __syncthreads();
+    VQ_T(4);
 
     /* hand the string over */
     const int written = start_s[nb];                       /* includes `lead` */
@@ -881,6 +904,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
             A.unit_bits[unit * 2 + 1] = size_rule;
         }
     }
+    VQ_T(5);
 }
 
 /* short frames: flags + the 8 sub-block strings, back to back */

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Phase split of k_vq from in-kernel s_memtime stamps (debug build, PACX_LIB=...libpacx_dbg.so)."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import audio_codec_amd as A
+
+kbps = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+enc = A.context.encoder(48000, kbps / 48.0, use_vq=True, use_sbr=kbps < 128)
+pcm = A.synth.stream(4096, 2)
+planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=enc.device)
+view = A.engine.PcmView.stream(planar)
+for _ in range(2):
+    enc.encode_vq(view)
+torch.cuda.synchronize()
+lib = A._lib.load()
+out = (ctypes.c_longlong * 16)()
+lib.pacx_debug_read_vq.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.pacx_debug_read_vq(out, 16)
+t = np.array(out[:6], dtype=np.float64)
+names = ["phase A: band gains", "wait at barrier 1", "header (wave 0) + barrier 2", "phase B: bands (busy)",
+         "wait for the slowest wave", "hand-over of the string"]
+print("k_vq at %d kb/s, all waves, share of a wave's time:" % kbps)
+for n, v in zip(names, t):
+    print("  %-30s %.1f %%" % (n, 100.0 * v / t.sum()))
