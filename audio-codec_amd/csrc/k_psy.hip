@@ -83,11 +83,11 @@ __device__ __forceinline__ PacxPeak make_peak(double left, double centre, int f,
 /* LDS of one wave.  The three users of it follow one another in time: raw samples (until
  * the FFT inputs are in registers), the FFT exchange tile (until the spectrum is in
  * registers), then the intensities together with the peak lists.
- *   COMPACT (no SBR): 13.1 KB for int16 input -> 12 waves per CU, what the registers allow
+ *   COMPACT (no SBR): 9.1 KB for int16 input
  *     region B (8.06 KB): raw, then the tile, then inten -- whose low slots the maskers'
- *       Bark values overwrite one round of 64 at a time (masker p comes from bins
- *       i_p - 1, i_p with i_p >= 2 p + 1, so slot p is never read again)
- *     region A (5 KB): peak bin numbers (1 KB) and SPLs (4 KB)
+ *       Bark values and SPLs overwrite one round of 64 at a time (masker p comes from bins
+ *       i_p - 1, i_p with i_p >= 2 p + 1, so slots 2p, 2p + 1 are never read again)
+ *     region A (1 KB): peak bin numbers
  *   with SBR (inten is needed to the end): 17.5 KB -> 9 waves per CU
  *     region A (9 KB): the tile, later bin numbers, Bark values, SPLs;  region B: raw, inten
  * The packed spectrum Z never goes to LDS: the real-FFT split needs Z[k] with
@@ -96,7 +96,7 @@ __device__ __forceinline__ PacxPeak make_peak(double left, double centre, int f,
 template <int DT, bool COMPACT> struct SideLongLds {
     typedef typename PcmStage<DT>::elem E;
     static constexpr int RAW_BYTES = (int)sizeof(E) * PACX_N_LONG;
-    static constexpr int A_BYTES = COMPACT ? 1024 + PACX_MAX_PEAKS * 8
+    static constexpr int A_BYTES = COMPACT ? 1024
                                            : 1024 + 2 * PACX_MAX_PEAKS * 8;   /* >= 512 * sizeof(cplx) */
     static constexpr int B_BYTES = RAW_BYTES > 1032 * 8 ? RAW_BYTES : 1032 * 8;
     static constexpr int BYTES = A_BYTES + B_BYTES;
@@ -302,13 +302,17 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
     SIDE_T(4);
     /* pass 2: one masker per lane, 64 at a time (log10 + two atan each); Bark and
        SPL go to LDS for the pruning scans */
-    double *zs = COMPACT ? inten : (double *)Z + 128;     /* [512]: in place, or after the 1 KB index list */
-    double *ss = COMPACT ? (double *)Z + 128 : zs + PACX_MAX_PEAKS;
+    /* COMPACT: masker p goes to the intensity slots 2p, 2p+1 (it comes from bins i_p - 1, i_p
+       with i_p >= 2p + 1, and a round of 64 reads its bins before it writes: no slot is read
+       after it has been overwritten); otherwise two lists after the 1 KB index list */
+    constexpr int ZS = COMPACT ? 2 : 1;                    /* stride of the Bark / SPL lists */
+    double *zs = COMPACT ? inten : (double *)Z + 128;
+    double *ss = COMPACT ? inten + 1 : zs + PACX_MAX_PEAKS;
     for (int p = lane; p < count; p += 64) {
         const int i = idx[p];
         const PacxPeak q = make_peak(inten[i - 1], inten[i], i, T.fstep_long);
-        zs[p] = q.z;
-        ss[p] = q.spl;
+        zs[ZS * p] = q.z;
+        ss[ZS * p] = q.spl;
     }
     wave_lds_fence();
     SIDE_T(5);
@@ -327,8 +331,8 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
         for (int i = 0; i < 8; ++i) {
             const int p = 8 * lane + i;
             const bool ok = p < count;
-            zz[i] = ok ? zs[p] : 0.0;
-            sv[i] = ok ? ss[p] : -INFINITY;
+            zz[i] = ok ? zs[ZS * p] : 0.0;
+            sv[i] = ok ? ss[ZS * p] : -INFINITY;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                       /* exclusive, inside the lane */
