@@ -669,6 +669,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
 #ifdef PACX_PSY_DEBUG
     const bool dbg_on = blockIdx.x == 5;
     long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = 0;
+    unsigned long long st_pairs = 0, st_surv = 0, st_live = 0, st_batches = 0;
     PSY_T(7);
     dbg_acc[7] = 0;
 #endif
@@ -702,8 +703,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
         PSY_T(0);
         for (int pb = 0; pb < np; pb += 64) {
 #ifdef PACX_PSY_DEBUG
-            if (lane == 0 && M == PACX_M_LONG)
-                atomicAdd((unsigned long long *)&g_psy_dbg[163], 1ull);
+            st_batches += 1;
 #endif
             const PacxPeak q = qn;
             qn.z = 0.0; qn.spl = -1000.0; qn.slope = 0.0;
@@ -748,31 +748,48 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 const bool live = (q.slope > 0.0 && q.spl > -1000.0) || (lvl + ub > need);
                 unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
 #ifdef PACX_PSY_DEBUG
-                if (lane == 0 && M == PACX_M_LONG) {      /* screen statistics */
-                    atomicAdd((unsigned long long *)&g_psy_dbg[160], 1ull);
-                    atomicAdd((unsigned long long *)&g_psy_dbg[161], (unsigned long long)__popcll(todo));
-                    atomicAdd((unsigned long long *)&g_psy_dbg[162], todo ? 1ull : 0ull);
-                }
+                st_pairs += 1;                            /* screen statistics, per wave */
+                st_surv += __popcll(todo);
+                st_live += todo ? 1 : 0;
 #endif
                 if (!todo)
                     continue;
                 const double zj = bark_s[lane + 64 * j];
                 double bj = buf[lane + 64 * j];
+                /* survivors four at a time: their broadcast reads are issued together and
+                   waited for once (the read latency, not the arithmetic, was what a survivor
+                   cost); a short last group repeats its last masker -- max is idempotent */
                 while (todo) {
-                    const int b = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const double2 zs = *(const double2 *)mk[b];          /* broadcast reads */
-                    const double pz = zs.x, ps = zs.y, pu = mk[b][2];
-                    /* gain = -27 a below the masker, pu a above, 0 inside +-0.5 Bark
-                       (a = |dz| - 0.5): select the slope by the sign of dz and clamp a
-                       at 0 -- same products as the reference's masked assignments
-                       (coder/psychoac.py:92-94), no divergent branches */
-                    const double dz = zj - pz;
-                    const double a = fmax(fabs(dz) - 0.5, 0.0);
-                    const double gain = (dz < 0.0 ? -27.0 : pu) * a;
-                    /* bare v_max_f64 (no NaNs here): fmax() would re-canonicalise bj every turn */
-                    const double cand = (ps + gain) - 16.0;
-                    asm("v_max_f64 %0, %1, %2" : "=v"(bj) : "v"(bj), "v"(cand));
+                    int bs[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bs[u] = __builtin_ctzll(todo);
+                        if (todo & (todo - 1))
+                            todo &= todo - 1;
+                        else if (u == 3)
+                            todo = 0;
+                    }
+                    double2 zs[4];
+                    double pus[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        zs[u] = *(const double2 *)mk[bs[u]];             /* broadcast reads */
+                        pus[u] = mk[bs[u]][2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double pz = zs[u].x, ps = zs[u].y, pu = pus[u];
+                        /* gain = -27 a below the masker, pu a above, 0 inside +-0.5 Bark
+                           (a = |dz| - 0.5): select the slope by the sign of dz and clamp a
+                           at 0 -- same products as the reference's masked assignments
+                           (coder/psychoac.py:92-94), no divergent branches */
+                        const double dz = zj - pz;
+                        const double a = fmax(fabs(dz) - 0.5, 0.0);
+                        const double gain = (dz < 0.0 ? -27.0 : pu) * a;
+                        /* bare v_max_f64 (no NaNs here): fmax() would re-canonicalise bj every turn */
+                        const double cand = (ps + gain) - 16.0;
+                        asm("v_max_f64 %0, %1, %2" : "=v"(bj) : "v"(bj), "v"(cand));
+                    }
                 }
                 buf[lane + 64 * j] = bj;
             }
@@ -842,6 +859,12 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     if (dbg_on && lane == 0 && M == PACX_M_LONG)
         for (int k = 0; k < 8; ++k)
             g_psy_dbg[wv * 16 + k] = dbg_acc[k];
+    if (lane == 0 && M == PACX_M_LONG) {
+        atomicAdd((unsigned long long *)&g_psy_dbg[160], st_pairs);
+        atomicAdd((unsigned long long *)&g_psy_dbg[161], st_surv);
+        atomicAdd((unsigned long long *)&g_psy_dbg[162], st_live);
+        atomicAdd((unsigned long long *)&g_psy_dbg[163], st_batches);
+    }
 #endif
 }
 
