@@ -629,13 +629,13 @@ def test_full_size_properties(A, torch):
 
 
 def test_gather_body_small_and_large_paths(A):
-    """pacx_gather_body: the single-block scan (<= 32768 records) and the chunked
-    scan give the '<L nBytes' + payload stream NumPy builds, dropped hops
-    (n_bytes 0) leaving no trace."""
+    """pacx_gather_body: the one-launch gather (<= 32768 records; record counts that are
+    not a multiple of its 8 records per workgroup included) and the chunked scan give the
+    '<L nBytes' + payload stream NumPy builds, dropped hops (n_bytes 0) leaving no trace."""
     import torch
     enc = A.engine.Encoder(48000, 128 / 48.0)
     rng = np.random.default_rng(3)
-    for n in (1, 777, 32768, 40001):
+    for n in (1, 7, 777, 32768, 40001):
         nb = rng.integers(0, 700, size=n).astype(np.int32)
         nb[rng.integers(0, n, size=max(1, n // 50))] = 0
         pay = rng.integers(0, 256, size=(n, enc.payload_stride), dtype=np.uint8)
