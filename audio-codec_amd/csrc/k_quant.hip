@@ -849,15 +849,29 @@ __global__ __launch_bounds__(256) void k_tail_short(PacxTables T, const uint8_t 
         const long long loff = cf * PACX_M_LONG + sb * PACX_M_SHORT;
         const double2 v = *(const double2 *)(lines + loff + 2 * lane);
         const double x0 = v.x * up, x1 = v.y * up;
-        for (int b = 0; b < nb; ++b) {
-            double m = 0.0;
-            if (band0 == b)
-                m = fmax(m, fabs(x0));
-            if (band1 == b)
-                m = fmax(m, fabs(x1));
-            m = wave_max(m);
-            if (lane == b)
-                sf_s[sb][b] = pacx_scale_factor(m, T.n_scale_bits, ba_s[sb][b]);
+        {
+            /* ScaleFactor is non-increasing in the magnitude, so a band's scale factor is the
+               minimum of its lines' own scale factors: small integers, whose wave minimum
+               per band is a bisection with one ballot per bit -- no LDS round trips (a 64-bit
+               wave maximum per band was six dependent ones, for each of the six bands).  The
+               band's owner lane adds ScaleFactor(0), the value of a band without lines. */
+            const int nsb = T.n_scale_bits, big = 1 << nsb;          /* above every scale factor */
+            const int s0 = (band0 < nb) ? pacx_scale_factor(fabs(x0), nsb, ba_s[sb][band0]) : big;
+            const int s1 = (band1 < nb) ? pacx_scale_factor(fabs(x1), nsb, ba_s[sb][band1]) : big;
+            const int s_own = (lane < nb) ? pacx_scale_factor(0.0, nsb, ba_s[sb][lane]) : big;
+            for (int b = 0; b < nb; ++b) {
+                int c = (lane == b) ? s_own : big;
+                if (band0 == b)
+                    c = min(c, s0);
+                if (band1 == b)
+                    c = min(c, s1);
+                int lo = 0;
+                for (int bit = nsb; bit >= 0; --bit)
+                    if (!__builtin_amdgcn_ballot_w64(c < lo + (1 << bit)))
+                        lo += 1 << bit;
+                if (lane == b)
+                    sf_s[sb][b] = lo;
+            }
         }
         wave_lds_fence();
         const int a0 = ba_s[sb][band0], a1 = ba_s[sb][band1];
