@@ -826,21 +826,23 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
         wave_lds_fence();
         PSY_T(2);
         double *__restrict__ out = smr + cf * T.band_stride + sb * T.nb_short;
-        if (nb <= 32) {
-            /* all band maxima in one transposing reduction (wave_fft.h wave_max_32): six
+        constexpr int NBR = SHORT ? 8 : 32;               /* bands handled by the reduction */
+        if (nb <= NBR) {
+            /* all band maxima in one transposing reduction (wave_fft.h wave_max_n): six
                LDS round trips for the lot instead of six per band */
-            double m[32];
+            double m[NBR];
 #pragma unroll
-            for (int b = 0; b < 32; ++b) {
+            for (int b = 0; b < NBR; ++b) {
                 double v = -INFINITY;
                 const int lo = __builtin_amdgcn_readlane(lo_v, b), hi = __builtin_amdgcn_readlane(hi_v, b);
                 for (int k = lo + lane; k < hi; k += 64)          /* empty for b >= nb */
                     v = fmax(v, buf[k]);
                 m[b] = v;
             }
-            wave_max_32(m, lane);
-            if (!(lane & 1) && (lane >> 1) < nb)
-                out[lane >> 1] = m[0];
+            wave_max_n<NBR>(m, lane);
+            constexpr int PER_BAND = 64 / NBR;            /* lanes that end up with one band's maximum */
+            if (!(lane & (PER_BAND - 1)) && lane / PER_BAND < nb)
+                out[lane / PER_BAND] = m[0];
         } else {
             for (int b = 0; b < nb; ++b) {
                 const int lo = lower[b], hi = lo + count[b];

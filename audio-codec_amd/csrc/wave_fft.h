@@ -201,26 +201,29 @@ __device__ __forceinline__ double wave_max_upper(double v)
     return (double)__int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
-/* Maxima of up to 32 per-lane values over the wave, all at once: at every xor step a lane
- * keeps half of its values and hands the other half to its partner, so the exchange
+/* Maxima of N (8, 16 or 32) per-lane values over the wave, all at once: at every xor step a
+ * lane keeps half of its values and hands the other half to its partner, so the exchange
  * volume halves per step (16+8+4+2+1+1 values = 64 ds_bpermute for 32 maxima, six
- * dependent LDS round trips in all -- against six per maximum for wave_max).  On
- * return m[0] of lane l holds the wave maximum of value number l >> 1. */
-__device__ __forceinline__ void wave_max_32(double m[32], int lane)
+ * dependent LDS round trips in all -- against six per maximum for wave_max); once one value
+ * is left the remaining steps are plain.  On return m[0] of lane l holds the wave maximum
+ * of value number l / (64 / N). */
+template <int N>
+__device__ __forceinline__ void wave_max_n(double (&m)[N], int lane)
 {
-#define WM32_HALVE(OFF, N)                                                                        \
-    _Pragma("unroll") for (int i = 0; i < (N); ++i) {                                             \
-        const bool up = (lane & (OFF)) != 0;                                                      \
-        const double keep = up ? m[(N) + i] : m[i], send = up ? m[i] : m[(N) + i];                \
-        m[i] = fmax(keep, __shfl_xor(send, (OFF), 64));                                           \
+    static_assert(N == 8 || N == 16 || N == 32, "wave_max_n");
+    int off = 32;
+#pragma unroll
+    for (int n = N / 2; n >= 1; n >>= 1, off >>= 1) {
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            const double keep = up ? m[n + i] : m[i], send = up ? m[i] : m[n + i];
+            m[i] = fmax(keep, __shfl_xor(send, off, 64));
+        }
     }
-    WM32_HALVE(32, 16)
-    WM32_HALVE(16, 8)
-    WM32_HALVE(8, 4)
-    WM32_HALVE(4, 2)
-    WM32_HALVE(2, 1)
-#undef WM32_HALVE
-    m[0] = fmax(m[0], __shfl_xor(m[0], 1, 64));
+#pragma unroll
+    for (; off >= 1; off >>= 1)
+        m[0] = fmax(m[0], __shfl_xor(m[0], off, 64));
 }
 
 #endif
