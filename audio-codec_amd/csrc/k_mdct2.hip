@@ -112,6 +112,14 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_fence();
+        if (!DBUF && !mine) {
+            /* a short-coded frame (k_mdct_short's): nothing to transform, only the chain of
+               PCM fetches to keep going -- on a castanet stream that is more than half of
+               the frames */
+            if (cf + stride < total)
+                stage(cf + stride);
+            continue;
+        }
         const int Q = PACX_N_LONG / 4, M = PACX_M_LONG;
         cplx v[8];
         /* sine window: w[2047-i] = w[i], so two table values serve each n.

@@ -667,9 +667,12 @@ __global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *_
     /* two channel-frames per wave: BitAlloc is a half-wave job (lanes = bands), so the two
        halves run it for the two frames at once; scale factors, mantissas and payload
        then take the whole wave, one frame after the other */
-    const long long cf0 = 2 * (long long)blockIdx.x;
+    const int per_block = mixed ? 1 : 2;                  /* see pacx_launch_tail */
+    const long long cf0 = per_block * (long long)blockIdx.x;
     if (cf0 >= n_cf)
         return;
+    if (mixed && flags && (flags[cf0 / n_ch] & 2u))
+        return;                                           /* a short-coded frame: k_tail_short's */
     const int nb = T.nb_long;
 #ifdef PACX_TAIL_DEBUG
     long long tail_last = 0;
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *_
     {
         const long long cfh = cf0 + half;
         const unsigned flh = (flags && cfh < n_cf) ? flags[cfh / n_ch] : 0u;
-        const bool alive = cfh < n_cf && !(mixed && (flh & 2u));
+        const bool alive = half < per_block && cfh < n_cf && !(mixed && (flh & 2u));
         const long long boff = cfh * T.band_stride;
         const int32_t *__restrict__ n_lines = T.use_sbr ? T.band_lines_long_alloc : T.band_lines_long;
         const double budget = pacx_bit_budget(T.target_bps, PACX_M_LONG, 0, (flh & 5u) != 0, T.n_scale_bits,
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *_
             atomicOr(&status[cfh], 4u);
     }
     TAIL_T(0);
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < per_block; ++c) {
         const long long cf = cf0 + c;
         if (cf >= n_cf)
             break;
@@ -1163,7 +1166,11 @@ void pacx_launch_tail(const PacxTables &T, const uint8_t *flags, int n_ch, long 
     if (n_cf <= 0)
         return;
     const int mixed = flags ? 1 : 0;
-    hipLaunchKernelGGL(k_tail_long, dim3((unsigned)((n_cf + 1) / 2)), dim3(64), 0, st, T, flags, n_ch, n_cf, mixed, smr,
+    /* all-long batches: two frames per wave (BitAlloc of both on the two half waves).  Mixed
+       streams: one frame per wave -- the waves of short-coded frames leave at once, and the
+       long ones that remain fit the chip in one round, so the shorter chain per wave wins */
+    hipLaunchKernelGGL(k_tail_long, dim3((unsigned)(mixed ? n_cf : (n_cf + 1) / 2)), dim3(64), 0, st, T, flags, n_ch,
+                       n_cf, mixed, smr,
                        lines, overall, bit_alloc, scale_factor, mantissa, status, payload, payload_stride,
                        n_bytes);
     if (mixed && list_short && T.nb_short <= 8) {
