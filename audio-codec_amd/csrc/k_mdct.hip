@@ -153,14 +153,24 @@ __global__ __launch_bounds__(64) void k_mdct_short(PacxTables T, PacxPcmView in,
     const double s = 2.0 / PACX_N_SHORT;     /* 2^-7 */
     double *__restrict__ out = lines + cf * PACX_M_LONG + g * PACX_M_SHORT;
     double mx = 0.0;
+    /* X[2k] = a_k and X[2k+1] = X[M-1-2(63-k)] = b_(63-k): with k = r + 8 k3 the partner 63-k
+       sits in lane 7-r of the same 8-lane group, register 7-k3 -- one row_half_mirror DPP
+       away, so every store is a contiguous 16 bytes per lane (128 bytes per group) */
+    double a[8], b[8];
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) {
         const int k = fft64_out_index(lane, k3);
         const cplx y = c_mul(v[k3], T.tw_short[k]);
-        const double a = y.x * s, b = -(y.y * s);
-        out[2 * k] = a;
-        out[M - 1 - 2 * k] = b;
-        mx = fmax(mx, fmax(fabs(a), fabs(b)));
+        a[k3] = y.x * s;
+        b[k3] = -(y.y * s);
+        mx = fmax(mx, fmax(fabs(a[k3]), fabs(b[k3])));
+    }
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) {
+        const int k = fft64_out_index(lane, k3);
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(b[7 - k3]), 0x141, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(b[7 - k3]), 0x141, 0xf, 0xf, false);
+        *(double2 *)(out + 2 * k) = make_double2(a[k3], __hiloint2double(hi, lo));
     }
     if (scale_out) {
         mx = fmax(mx, __shfl_xor(mx, 1, 64));
