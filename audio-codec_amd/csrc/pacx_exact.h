@@ -255,8 +255,23 @@ PACX_HD double pacx_log10_pos(double x)
     double sq = f * rc;
     sq = fma(fma(-d, sq, f), rc, sq);
     const double z = sq * sq, w = z * z;
-    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    /* Horner steps with the addend in scalar registers (three-address v_fma_f64): from a
+       vector register the compiler takes the two-address v_fmac_f64 and copies the constant
+       into the accumulator first, every step of every line */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PACX_FMA_SC(r, a, b, c) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c))
+#else
+#define PACX_FMA_SC(r, a, b, c) (r) = fma((a), (b), (c))
+#endif
+    double h1, h2;
+    PACX_FMA_SC(h1, w, Lg6, Lg4);
+    PACX_FMA_SC(h1, w, h1, Lg2);
+    PACX_FMA_SC(h2, w, Lg7, Lg5);
+    PACX_FMA_SC(h2, w, h2, Lg3);
+    PACX_FMA_SC(h2, w, h2, Lg1);
+#undef PACX_FMA_SC
+    const double t1 = w * h1;
+    const double t2 = z * h2;
     const double r = sq * (hfsq + (t2 + t1));
     double hi = f - hfsq;
     memcpy(&bits, &hi, 8);
