@@ -371,13 +371,14 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
     for (; cfa < total; cfa += 2 * n_waves, cfb += 2 * n_waves) {
         const bool has_b = cfb < total;
         /* this pair's PCM must have landed; what was issued after its DMA -- the previous
-           pair's 16 line stores and 2 scale stores -- may stay in flight */
+           pair's 16 line stores (and 2 scale stores) -- may stay in flight.  Vector memory
+           operations complete in issue order, so a count that is not above the number of
+           younger operations is safe, a smaller one merely waits for more */
         if (first)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (scale_out)
-            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   /* the line stores; the 2 scale stores, when
+                                                                    there are any, only make the wait stricter */
         first = false;
         DBG_T(0);
         wave_lds_fence();
