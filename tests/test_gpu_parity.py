@@ -385,6 +385,48 @@ def test_encode_synthetic_vs_oracle(A, torch):
             assert r[0].tolist() == sf.tolist() and r[2].tolist() == mant.tolist()
 
 
+def _signal_zoo(n_hops):
+    """Short stereo streams that stress different corners of the path: digital silence,
+    a DC offset, a full-scale square wave (clipping codes, -32768 included), impulses, a
+    tone of a few LSB, white noise, a sweep with an attack in the middle, full scale at
+    Nyquist.  DC, square, impulses and Nyquist carry a dither of a few LSB: without it some
+    of their MDCT lines are exactly zero in exact arithmetic (DC, Nyquist, the periodic
+    square wave) or their FFT bins exactly equal (an impulse's flat spectrum), and what the
+    reference codes there -- the sign bit of a zero mantissa, which of two equal bins is a
+    peak -- is the rounding noise of its own FFT, which no other FFT reproduces (see
+    test_rounding_noise_frame; measured on the undithered square wave: 2 of 1024 mantissas
+    of one frame, lines agreeing to 6e-15)."""
+    n = n_hops * 1024
+    t = np.arange(n)
+    rng = np.random.default_rng(2024)
+    dither = lambda a: rng.integers(-a, a + 1, n)
+    clip = lambda x: np.clip(x, -32768, 32767).astype(np.int16)
+    sq = np.where((t // 37) % 2 == 0, 32767 - rng.integers(0, 3, n), -32768 + rng.integers(0, 3, n)).astype(np.int16)
+    imp = dither(8)
+    imp[[5, 1024 + 511, 3000, n - 1025]] = [32767, -32768, 12000, -9000]
+    quiet = np.rint(3.0 * np.sin(2 * np.pi * 440.0 * t / 48000)).astype(np.int16)
+    noise = rng.integers(-20000, 20000, n).astype(np.int16)
+    sweep = (8000 * np.sin(2 * np.pi * (200.0 + 6.0 * t / 48.0) * t / 48000)).astype(np.int16)
+    sweep[: n // 2] //= 64                                  # soft, then loud: transients for block switching
+    nyq = np.where(t % 2 == 0, 32760, -32760) + dither(3)
+    zoo = {
+        "silence": np.zeros(n, np.int16), "dc": clip(1234 + dither(2)), "square": sq, "impulses": clip(imp),
+        "quiet_tone": quiet, "noise": noise, "attack_sweep": sweep, "nyquist": clip(nyq),
+    }
+    names = list(zoo)
+    return {k: np.stack((zoo[k], zoo[names[(i + 3) % len(names)]]), axis=1) for i, k in enumerate(names)}
+
+
+@pytest.mark.parametrize("block_switching", [False, True])
+def test_signal_zoo_pac_bytes_vs_oracle(A, block_switching):
+    """Whole .pac streams of eight synthetic corner-case signals (paired into stereo) against
+    the oracle, byte for byte, without and with block switching."""
+    for name, pcm in _signal_zoo(8).items():
+        got = A.pacfile.encode_stream(pcm, 48000, 128, block_switching)
+        want = po.encode_stream(pcm, 48000, 128, block_switching)
+        assert got == want, name
+
+
 # ---------------------------------------------------------------- file level
 @pytest.mark.parametrize("name", EXCERPTS)
 @pytest.mark.parametrize("variant", ["long", "bs", "long96"])

@@ -80,6 +80,22 @@ def test_synthetic_stream_vs_oracle(A):
         assert got == want, describe_diff(got, want)
 
 
+def test_signal_zoo_vs_oracle(A):
+    """The corner-case signals of test_gpu_parity._signal_zoo (silence, DC, clipping square
+    wave, impulses, a few-LSB tone, noise, an attack, Nyquist; dithered where the exact
+    values would be zeros) through the gain-shape + SBR coder, byte for byte."""
+    import importlib.util
+    from oracle import pac_oracle_vq as pv
+    spec = importlib.util.spec_from_file_location(
+        "tp", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py"))
+    tp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tp)
+    for name, pcm in tp._signal_zoo(6).items():
+        want = pv.encode_stream_vq(pcm, 48000, 96)
+        got = A.pacfile.encode_stream(pcm, 48000, 96, block_switching=True, use_vq=True, use_sbr=True)
+        assert got == want, name + ": " + describe_diff(got, want)
+
+
 def test_status_and_final_alloc(A):
     """No band of real material reaches a case the reference cannot code, every
     coded band fills its slot exactly, and silent bands end with allocation 0."""
