@@ -291,3 +291,30 @@ def test_other_bit_rates_vs_oracle(A, kbps):
     got = A.pacfile.encode_stream(pcm, 48000, kbps, block_switching=True, use_vq=True, use_sbr=kbps < 128)
     assert got == want, describe_diff(got, want)
     assert np.array_equal(A.pacfile.decode_stream(got), pv.decode_stream_vq(want))
+
+
+@pytest.mark.parametrize("sr,kbps", [(44100, 96), (32000, 64), (44100, 128)])
+def test_other_sample_rates_vs_oracle(A, sr, kbps):
+    """The band layout (and with it the SBR cut, the PVQ dimensions and the table sizes)
+    follows the sample rate: encode bytes and decoded PCM against the oracle at rates other
+    than 48 kHz, on a short stream with a click."""
+    from oracle import pac_oracle_vq as pv
+    pcm = A.synth.stream(6, 2, sr, seed=5)
+    pcm[2 * 1024 + 100:2 * 1024 + 150] = -28000
+    want = pv.encode_stream_vq(pcm, sr, kbps)
+    got = A.pacfile.encode_stream(pcm, sr, kbps, block_switching=True, use_vq=True, use_sbr=kbps < 128)
+    assert got == want, describe_diff(got, want)
+    assert np.array_equal(A.pacfile.decode_stream(got), pv.decode_stream_vq(want))
+
+
+@pytest.mark.parametrize("n_ch", [1, 3])
+def test_other_channel_counts_vs_oracle(A, n_ch):
+    """Mono and three-channel streams (the block-switching flags are per hop, over all
+    channels; the channel-frames of a hop are coded independently)."""
+    from oracle import pac_oracle_vq as pv
+    pcm = A.synth.stream(5, n_ch, 48000, seed=3)
+    pcm[1024 + 300:1024 + 340, 0] = 25000
+    want = pv.encode_stream_vq(pcm, 48000, 96)
+    got = A.pacfile.encode_stream(pcm, 48000, 96, block_switching=True, use_vq=True, use_sbr=True)
+    assert got == want, describe_diff(got, want)
+    assert np.array_equal(A.pacfile.decode_stream(got), pv.decode_stream_vq(want))
