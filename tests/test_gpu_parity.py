@@ -427,6 +427,37 @@ def test_signal_zoo_pac_bytes_vs_oracle(A, block_switching):
         assert got == want, name
 
 
+def rich_stream(n_hops, n_ch=2, sr=48000, seed=99):
+    """A longer synthetic programme: amplitude-modulated band noise, chords that come and
+    go, level steps over 60 dB, clicks and a silent passage -- every hop different."""
+    rng = np.random.default_rng(seed)
+    n = n_hops * 1024
+    t = np.arange(n) / sr
+    out = np.zeros((n, n_ch))
+    for ch in range(n_ch):
+        x = np.zeros(n)
+        for k in range(6):                                            # chords with slow envelopes
+            f = rng.uniform(80, 9000)
+            env = np.clip(np.sin(2 * np.pi * rng.uniform(0.5, 3.0) * t + rng.uniform(0, 6.28)), 0, 1) ** 2
+            x += rng.uniform(0.02, 0.25) * env * np.sin(2 * np.pi * f * t + rng.uniform(0, 6.28))
+        noise = rng.standard_normal(n)
+        noise = np.convolve(noise, np.ones(8) / 8, mode="same") * 0.05   # low-passed noise bed
+        x += noise * (0.2 + 0.8 * (np.sin(2 * np.pi * 1.3 * t + ch) > 0))
+        x *= 10.0 ** (-3.0 * (np.arange(n) // (8 * 1024) % 3) / 2.0)     # 0 / -30 / -60 dB steps
+        for c in rng.integers(2048, n - 2048, 5):                       # clicks
+            x[c:c + rng.integers(8, 80)] += rng.choice([-0.9, 0.9])
+        x[n // 2:n // 2 + 3000] = 0.0                                   # a gap of digital silence
+        out[:, ch] = x
+    return np.clip(np.rint(out * 32767), -32768, 32767).astype(np.int16)
+
+
+def test_rich_synthetic_stream_vs_oracle(A):
+    """48 hops of the programme above, block switching on, whole .pac stream against the
+    oracle (scalar coder)."""
+    pcm = rich_stream(48)
+    assert A.pacfile.encode_stream(pcm, 48000, 128, True) == po.encode_stream(pcm, 48000, 128, True)
+
+
 # ---------------------------------------------------------------- file level
 @pytest.mark.parametrize("name", EXCERPTS)
 @pytest.mark.parametrize("variant", ["long", "bs", "long96"])

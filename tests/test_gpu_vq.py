@@ -318,3 +318,21 @@ def test_other_channel_counts_vs_oracle(A, n_ch):
     got = A.pacfile.encode_stream(pcm, 48000, 96, block_switching=True, use_vq=True, use_sbr=True)
     assert got == want, describe_diff(got, want)
     assert np.array_equal(A.pacfile.decode_stream(got), pv.decode_stream_vq(want))
+
+
+@pytest.mark.parametrize("kbps", [96, 128])
+def test_rich_synthetic_stream_vs_oracle(A, kbps):
+    """48 hops of test_gpu_parity.rich_stream (modulated noise, chords, 60 dB level steps,
+    clicks, a silent gap) through the gain-shape coder with block switching, bytes and
+    decoded PCM against the oracle."""
+    import importlib.util
+    from oracle import pac_oracle_vq as pv
+    spec = importlib.util.spec_from_file_location(
+        "tp", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py"))
+    tp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tp)
+    pcm = tp.rich_stream(48)
+    want = pv.encode_stream_vq(pcm, 48000, kbps)
+    got = A.pacfile.encode_stream(pcm, 48000, kbps, block_switching=True, use_vq=True, use_sbr=kbps < 128)
+    assert got == want, describe_diff(got, want)
+    assert np.array_equal(A.pacfile.decode_stream(got), pv.decode_stream_vq(want))
