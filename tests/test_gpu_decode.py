@@ -120,3 +120,20 @@ def test_block_api_decode(A, tmp_path):
     blk = A.codec.Decode(sf, ba, line_mant, ov, None, cpp)
     ref = po.decode_block(p, sf, ba, line_mant, ov, False, False, False)
     assert np.max(np.abs(blk - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("block_switching", [False, True])
+def test_decode_signal_zoo_and_programme_vs_oracle(A, block_switching):
+    """Scalar streams of the corner-case signals and of the longer synthetic programme
+    (test_gpu_parity._signal_zoo / rich_stream): the GPU decoder's int16 PCM against the
+    oracle's decoder, sample for sample."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "tp", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py"))
+    tp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tp)
+    streams = dict(tp._signal_zoo(6))
+    streams["programme"] = tp.rich_stream(24)
+    for name, pcm in streams.items():
+        pac = po.encode_stream(pcm, 48000, 128, block_switching)
+        assert np.array_equal(A.pacfile.decode_stream(pac), po.decode_stream(pac)), name
