@@ -60,7 +60,11 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
                                              (__attribute__((address_space(3))) void *)((char *)raw + 1024 * j),
                                              16, 0, 0);
     };
-    unsigned cf = blockIdx.x * MDCT2_WAVES + wv;
+    /* XCD-aware frame order (workgroup b runs on XCD b % 8): every XCD takes a contiguous
+       run of frames, so the hop two consecutive frames share stays in one XCD's L2
+       (k_mdct3.hip, k_mdct_long_x2p) */
+    const unsigned vb = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    unsigned cf = vb * MDCT2_WAVES + wv;
     if (cf < total)
         stage(cf);                    /* first frame's PCM flies while the tables load */
     for (int i = tid; i < 512; i += 64 * MDCT2_WAVES)

@@ -280,7 +280,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
                      "global_load_lds_dwordx4 %0, off offset:3072"
                      :: "v"(src + lane), "s"(lds) : "memory", "m0");
     };
-    const unsigned g = blockIdx.x * WAVES + wv;
+    /* XCD-aware frame order: workgroups are handed to the 8 XCDs round-robin, so workgroup b
+       runs on XCD b % 8.  Consecutive frames share a hop of PCM; giving every XCD a CONTIGUOUS
+       run of workgroups' worth of frames keeps that shared hop in one XCD's L2 instead of
+       fetching it from HBM once per XCD (a quarter of the hops were read twice) */
+    const unsigned vb = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const unsigned g = vb * WAVES + wv;
     unsigned cfa = g, cfb = g + n_waves;
     if (cfa < total)
         stage(cfa, 0);

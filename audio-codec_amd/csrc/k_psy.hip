@@ -440,7 +440,15 @@ __global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
 {
     __shared__ __attribute__((aligned(16))) char regA[SideLongLds<DT, COMPACT>::A_BYTES];
     __shared__ __attribute__((aligned(16))) char regB[SideLongLds<DT, COMPACT>::B_BYTES];
-    const long long cf = blockIdx.x;
+    /* XCD-aware block order: block b runs on XCD b % 8, and the MDCT kernel, which reads the
+       same PCM at the same time on the other stream, gives XCD x the frames with
+       (cf / 256) % 8 == x (k_mdct3.hip): the same assignment here, so that the hop is in
+       this XCD's L2 whichever of the two kernels asks first */
+    long long cf = blockIdx.x;
+    if ((n_cf & 2047) == 0 && gridDim.x == (unsigned)n_cf) {
+        const unsigned b = blockIdx.x, idx = b >> 3;
+        cf = (long long)(idx >> 8) * 2048 + (b & 7u) * 256 + (idx & 255u);
+    }
     if (cf >= n_cf)
         return;
     const unsigned fl = flags ? flags[cf / in.n_ch] : 0u;
