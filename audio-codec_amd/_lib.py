@@ -6,10 +6,10 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PACX_LIB") or os.path.join(HERE, "libpacx.so")   # PACX_LIB: kernel-variant experiments
 
-PACX_ABI_VERSION = 2
+PACX_ABI_VERSION = 3
 PCM_I16, PCM_F64 = 0, 1
 FLAG_LAST, FLAG_CUR, FLAG_NEXT = 1, 2, 4
-ST_SHORT, ST_ZERO_SUBBLOCK, ST_ALLOC_CAP, ST_VQ_UNDEFINED = 1, 2, 4, 8
+ST_SHORT, ST_ZERO_SUBBLOCK, ST_ALLOC_CAP, ST_VQ_UNDEFINED, ST_GUARD, ST_MALFORMED = 1, 2, 4, 8, 16, 32
 MAX_BANDS = 32
 SUB = 8
 
@@ -51,6 +51,8 @@ class PacxConfig(ctypes.Structure):
         ("sbr_gauss", c_double_p),
         ("sbr_gauss_radius", ctypes.c_int32),
         ("line_freq_long", c_double_p),
+        ("kbd_long", c_double_p),
+        ("kbd_short", c_double_p),
     ]
 
 
@@ -80,6 +82,8 @@ SIGNATURES = {
     "pacx_band_stride": (ctypes.c_int, [_P]),
     "pacx_payload_stride": (ctypes.c_int, [_P]),
     "pacx_reserve": (ctypes.c_int, [_P, ctypes.c_int64]),
+    "pacx_tables_exact": (ctypes.c_int, [_P]),
+    "pacx_default_bands": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_int32_p, c_int32_p]),
     "pacx_mdct_batch": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, ctypes.c_int, _P, _P, _P]),
     "pacx_smr_batch": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, ctypes.c_int, _P, _P, _P, _P]),
     "pacx_bitalloc_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, _P]),
@@ -91,18 +95,20 @@ SIGNATURES = {
     "pacx_pack_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pacx_gather_body": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _P]),
     "pacx_window_batch": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int64, _P, _P, _P]),
+    "pacx_window_table_batch": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int64, _P, _P, _P]),
     "pacx_quantize_uniform": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P]),
     "pacx_scale_factor": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, _P, _P]),
     "pacx_mantissa": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
-    "pacx_unpack_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pacx_unpack_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pacx_decode_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pacx_decode_vq_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, _P, _P,
                                             _P, _P, _P, _P, _P]),
     "pacx_transient_flags": (ctypes.c_int, [_P, ctypes.POINTER(PacxPcm), _P, _P, _P]),
     "pacx_bitalloc_generic": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, ctypes.c_int, _P, _P, _P]),
 }
-WIN_SINE, WIN_START, WIN_STOP, WIN_STARTSTOP, WIN_SINE_SHORT, WIN_HANN, WIN_HANN_SHORT = range(7)
-MDCT_SHORT, MDCT_PREWINDOWED = 1, 2
+(WIN_SINE, WIN_START, WIN_STOP, WIN_STARTSTOP, WIN_SINE_SHORT, WIN_HANN, WIN_HANN_SHORT, WIN_KBD,
+ WIN_KBD_SHORT) = range(9)
+MDCT_SHORT, MDCT_PREWINDOWED, MDCT_KBD = 1, 2, 4
 
 _lib = None
 
@@ -116,6 +122,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.environ.get("PACX_LIB"):
+        # the library must belong to the sources next to it: build.py keys that on a content
+        # hash (sources + headers + flags) stored beside the .so and rebuilds on a mismatch
+        from . import build as _build
+        try:
+            _build.ensure()
+        except Exception as e:                       # no hipcc, compile error: say so, no fallback
+            raise PacxError(f"libpacx.so is missing or stale and could not be rebuilt: {e}") from e
     if not os.path.exists(LIB_PATH):
         raise PacxError(
             f"{LIB_PATH} not found: build it with `python audio-codec_amd/build.py` "

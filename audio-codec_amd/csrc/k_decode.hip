@@ -33,21 +33,31 @@ __device__ __forceinline__ unsigned get_bits(const unsigned *words, int pos, int
 }
 
 /* ------------------------------------------------------------------ unpack */
+/* The bit cursor is driven by what the payload says (a 12-bit allocation field, band after
+ * band), so a truncated or corrupt record must not steer it: every field is checked against
+ * the record's own length before it is read, an allocation above maxMantBits = 16
+ * (coder/codec.py:296) cannot have been written by the coder, and nothing beyond n_bytes is
+ * ever fetched.  A record that fails gets PACX_ST_MALFORMED and all-zero codes -- the
+ * reference stops with "Only read a partial block of coded PACFile data"
+ * (coder/pacfile.py:203-205); the host mirrors raise the same on the status bit. */
 __global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, const uint8_t *__restrict__ payload,
                                               int payload_stride, const long long *__restrict__ offsets,
                                               const int32_t *__restrict__ n_bytes,
                                               uint8_t *__restrict__ flags_out, int32_t *__restrict__ overall,
                                               int32_t *__restrict__ scale_factor, int32_t *__restrict__ bit_alloc,
-                                              int32_t *__restrict__ mantissa)
+                                              int32_t *__restrict__ mantissa, uint32_t *__restrict__ status)
 {
     __shared__ unsigned words[UNPACK_WORDS];
     __shared__ int offs[PACX_SUB][PACX_MAX_BANDS], bas[PACX_SUB][PACX_MAX_BANDS];
-    __shared__ int is_short_s;
+    __shared__ int is_short_s, bad_s;
     const int lane = threadIdx.x;
     const long long cf = blockIdx.x;
     if (cf >= n_cf)
         return;
-    const int nbytes = n_bytes[cf];
+    int nbytes = n_bytes[cf];
+    bool bad = nbytes < 1 || nbytes > 4 * (UNPACK_WORDS - 2);     /* no coder output is that long */
+    if (bad)
+        nbytes = 0;
     const uint8_t *src = payload + (offsets ? offsets[cf] : cf * (long long)payload_stride);
     const int n_words = (nbytes + 3) >> 2;
     for (int i = lane; i < UNPACK_WORDS; i += 64) {
@@ -63,22 +73,35 @@ __global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, con
     __syncthreads();
     int32_t *ba_o = bit_alloc + cf * T.band_stride, *sf_o = scale_factor + cf * T.band_stride;
     if (lane == 0) {
-        const unsigned fl = get_bits(words, 0, 1) | (get_bits(words, 1, 1) << 1) | (get_bits(words, 2, 1) << 2);
-        flags_out[cf] = (uint8_t)fl;
+        const int limit = 8 * nbytes;                     /* bits the record really holds */
+        const unsigned fl = bad ? 0u
+                                : get_bits(words, 0, 1) | (get_bits(words, 1, 1) << 1) | (get_bits(words, 2, 1) << 2);
         const int shrt = (fl >> 1) & 1;
-        is_short_s = shrt;
         const int nb = shrt ? T.nb_short : T.nb_long;
         const int32_t *cnt = shrt ? T.band_lines_short : T.band_lines_long;
+        const int head = T.n_mant_size_bits + T.n_scale_bits;
         int pos = 3;
-        for (int s = 0; s < (shrt ? PACX_SUB : 1); ++s) {
+        for (int s = 0; s < (shrt ? PACX_SUB : 1) && !bad; ++s) {
+            if (pos + T.n_scale_bits > limit) {
+                bad = true;
+                break;
+            }
             overall[cf * PACX_SUB + s] = (int)get_bits(words, pos, T.n_scale_bits);
             pos += T.n_scale_bits;
             for (int b = 0; b < nb; ++b) {
+                if (pos + head > limit) {
+                    bad = true;
+                    break;
+                }
                 int a = (int)get_bits(words, pos, T.n_mant_size_bits);
                 if (a)
                     a += 1;
                 const int sf = (int)get_bits(words, pos + T.n_mant_size_bits, T.n_scale_bits);
-                pos += T.n_mant_size_bits + T.n_scale_bits;
+                pos += head;
+                if (a > 16 || pos + a * cnt[b] > limit) {
+                    bad = true;
+                    break;
+                }
                 offs[s][b] = pos;
                 bas[s][b] = a;
                 if (b == nb - 1 && nb < PACX_MAX_BANDS)
@@ -88,9 +111,25 @@ __global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, con
                 pos += a * cnt[b];
             }
         }
-        if (!shrt)
+        if (bad) {                                         /* all-zero codes for the whole record */
+            for (int s = 0; s < PACX_SUB; ++s) {
+                overall[cf * PACX_SUB + s] = 0;
+                for (int b = 0; b <= nb && b < PACX_MAX_BANDS; ++b)
+                    bas[s][b] = 0;
+            }
+            for (int i = 0; i < T.band_stride; ++i) {
+                ba_o[i] = 0;
+                sf_o[i] = 0;
+            }
+        } else if (!shrt) {
             for (int s = 1; s < PACX_SUB; ++s)
                 overall[cf * PACX_SUB + s] = 0;
+        }
+        flags_out[cf] = (uint8_t)fl;
+        is_short_s = shrt;
+        bad_s = bad ? 1 : 0;
+        if (status)
+            status[cf] = bad ? 32u : 0u;                   /* PACX_ST_MALFORMED */
     }
     __syncthreads();
     const int shrt = is_short_s;
@@ -101,7 +140,7 @@ __global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, con
         const int s = shrt ? k / PACX_M_SHORT : 0;
         const int kk = k - s * m_lines;
         const int b = band_of[kk];
-        const int a = bas[s][b];
+        const int a = bad_s ? 0 : bas[s][b];
         mantissa[cf * PACX_M_LONG + k] = a ? (int32_t)get_bits(words, offs[s][b] + (kk - lower[b]) * a, a) : 0;
     }
 }
@@ -293,11 +332,12 @@ __global__ void k_ola_pcm(long long n_blocks, int n_ch, const double *__restrict
 /* ------------------------------------------------------------- launchers */
 void pacx_launch_unpack(const PacxTables &T, long long n_cf, const uint8_t *payload, int payload_stride,
                         const long long *offsets, const int32_t *n_bytes, uint8_t *flags_out, int32_t *overall,
-                        int32_t *scale_factor, int32_t *bit_alloc, int32_t *mantissa, hipStream_t st)
+                        int32_t *scale_factor, int32_t *bit_alloc, int32_t *mantissa, uint32_t *status,
+                        hipStream_t st)
 {
     if (n_cf > 0)
         hipLaunchKernelGGL(k_unpack, dim3((unsigned)n_cf), dim3(64), 0, st, T, n_cf, payload, payload_stride,
-                           offsets, n_bytes, flags_out, overall, scale_factor, bit_alloc, mantissa);
+                           offsets, n_bytes, flags_out, overall, scale_factor, bit_alloc, mantissa, status);
 }
 
 void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const uint8_t *cf_flags,

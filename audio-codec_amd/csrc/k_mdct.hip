@@ -42,7 +42,10 @@ __global__ __launch_bounds__(64) void k_mdct_long(PacxTables T, PacxPcmView in,
         return;
     if ((skip_cur & 2) && pacx_window_kind(fl) == 0)
         return;                              /* sine frames were done by k_mdct_long_v2 */
-    const double *__restrict__ w = prewin ? T.ones : T.win_long + pacx_window_kind(fl) * PACX_N_LONG;
+    /* prewin: 0 = the window the flags select, 1 = none (mdct.MDCT on windowed data),
+       2 = KBDWindow (coder/window.py:45-57) */
+    const double *__restrict__ w = prewin == 1 ? T.ones : prewin == 2 ? T.kbd_long
+                                                : T.win_long + pacx_window_kind(fl) * PACX_N_LONG;
 
     stage_samples<DT, FAST>(raw, in, cf, 0, PACX_N_LONG, lane);
     __syncthreads();
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(64) void k_mdct_short(PacxTables T, PacxPcmView in,
     const unsigned fl = flags ? flags[cf / in.n_ch] : 2u;
     if (only_cur && !(fl & 2u))
         return;
-    const double *__restrict__ w = prewin ? T.ones : T.win_short;
+    const double *__restrict__ w = prewin == 1 ? T.ones : prewin == 2 ? T.kbd_short : T.win_short;
 
     stage_samples<DT, FAST>(raw, in, cf, PACX_SHORT_FIRST, SPAN, lane);
     __syncthreads();

@@ -25,26 +25,29 @@
 #include <stdlib.h>
 
 
-/* WAVES waves per workgroup (8 KB tile each + 17 KB of tables), MINW = waves per
-   SIMD the register allocator has to leave room for */
-template <int MDCT2_WAVES, int MINW, bool DBUF, bool ANYWIN>
-__global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
+/* 8 waves per workgroup (8 KB tile each + 24 KB of tables, + 48 KB of transition windows
+   with ANYWIN), one workgroup per CU, two waves per SIMD */
+#define MDCT2_WAVES 8
+template <bool ANYWIN>
+__global__ __launch_bounds__(64 * MDCT2_WAVES, 2) void k_mdct_long_v2(
     PacxTables T, PacxPcmView in, const uint8_t *__restrict__ flags, long long n_cf, int skip_cur,
     double *__restrict__ lines, int32_t *__restrict__ scale_out, int scale_stride,
     uint32_t *__restrict__ status_init)
 {
     __shared__ __attribute__((aligned(16))) cplx tiles[MDCT2_WAVES][WFFT_TILE_N];
-    /* DBUF: PCM has a landing buffer of its own, so the next frame's DMA starts
-       right after the fold and has the whole FFT + epilogue to arrive */
-    __shared__ __attribute__((aligned(16))) short rawbuf[DBUF ? MDCT2_WAVES : 1][DBUF ? PACX_N_LONG : 8];
     __shared__ __attribute__((aligned(16))) cplx twl[512];
     __shared__ __attribute__((aligned(16))) double wsin[1024];
     __shared__ __attribute__((aligned(16))) cplx w64[7][8];        /* W64^(r k2), k2 = 1..7 */
     __shared__ __attribute__((aligned(16))) cplx w1s[7][64];       /* W512^(lane k1), k1 = 1..7 */
+    /* ANYWIN: the three transition windows (start / stop / start-stop, coder/window.py:61-92),
+       scaled like wsin, whole: a frame's window kind is wave-uniform, so a fold element reads
+       its four values at plain per-lane indices -- no region tests, no global loads whose 32
+       results in flight per frame had the kernel at 256 registers with 23 spilled */
+    __shared__ __attribute__((aligned(16))) double wtr[ANYWIN ? 3 : 1][ANYWIN ? PACX_N_LONG : 2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     /* wave-uniform: frame index math on the SALU */
     cplx *tile = tiles[wv];
-    short *raw = DBUF ? rawbuf[wv] : (short *)tile;
+    short *raw = (short *)tile;            /* the raw int16 samples are staged in the FFT tile */
     const unsigned n_ch = (unsigned)in.n_ch;
     const unsigned stride = gridDim.x * MDCT2_WAVES;
     const unsigned total = (unsigned)n_cf;
@@ -78,6 +81,9 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
     const double kscale = (2.0 / 65535.0) * (2.0 / PACX_N_LONG);
     for (int i = tid; i < 1024; i += 64 * MDCT2_WAVES)
         wsin[i] = T.win_long[i] * kscale;
+    if (ANYWIN)
+        for (int i = tid; i < 3 * PACX_N_LONG; i += 64 * MDCT2_WAVES)
+            wtr[0][i] = T.win_long[PACX_N_LONG + i] * kscale;
     if (tid < 56)
         w64[tid >> 3][tid & 7] = T.w512[8 * (tid & 7) * ((tid >> 3) + 1)];
     for (int i = tid; i < 7 * 64; i += 64 * MDCT2_WAVES)
@@ -86,16 +92,14 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
 
     const cplx *w1 = &w1s[0][lane];                                /* w1[64 (k1-1)] */
     const cplx *w2 = &w64[0][lane & 7];                            /* w2[8 (k2-1)] */
-    int younger = -1;                /* vector-memory ops issued after the DMA being waited for */
     for (; cf < total; cf += stride) {
         const unsigned fl = flags ? flags[cf / n_ch] : 0u;
         /* frames this kernel leaves to k_mdct_short: short-coded (CUR) ones when asked to */
         const bool mine = !(skip_cur && (fl & 2u));
         /* transition windows (start / stop / start-stop) are not symmetric: their four
-           values per fold element come from the global table (L2 resident), scaled
-           like wsin */
-        const int kind = ANYWIN ? pacx_window_kind(fl) : 0;   /* !ANYWIN: launched without flags */
-        const double *__restrict__ gw = T.win_long + kind * PACX_N_LONG;
+           values per fold element come from the LDS tables wtr */
+        const int kind = ANYWIN ? __builtin_amdgcn_readfirstlane(pacx_window_kind(fl)) : 0;   /* !ANYWIN: launched without flags */
+        const double *gw = wtr[kind > 0 ? kind - 1 : 0];
         /* output initialisation the whole-path entry points would otherwise spend two
            memset launches on: status word 0 and the 7 unused overall-scale slots of a
            long frame 0, for EVERY frame (kernels that follow on the stream overwrite /
@@ -106,17 +110,11 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
             if (lane >= 1 && lane < PACX_SUB)
                 scale_out[(long long)cf * PACX_SUB + lane] = 0;
         }
-        /* this frame's PCM must have landed in LDS.  vmcnt counts loads, stores and
-           LDS-DMA together in issue order: with DBUF the DMA is older than the
-           previous frame's 8 (+1) line stores, so only they may stay in flight */
-        if (DBUF && !status_init && younger == 9)
-            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else if (DBUF && !status_init && younger == 8)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        /* this frame's PCM must have landed in LDS (the DMA is the youngest vector-memory
+           operation but for the two initialisation stores above: wait for everything) */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_fence();
-        if (!DBUF && !mine) {
+        if (!mine) {
             /* a short-coded frame (k_mdct_short's): nothing to transform, only the chain of
                PCM fetches to keep going -- on a castanet stream that is more than half of
                the frames */
@@ -150,8 +148,8 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
                         re = -fma(wb, code(i1), wa * code(i0));
                         im = fma(wb, code(i2), -(wa * code(i3)));
                     } else {
-                        re = -fma(gw[i1] * kscale, code(i1), (gw[i0] * kscale) * code(i0));
-                        im = fma(gw[i2] * kscale, code(i2), -((gw[i3] * kscale) * code(i3)));
+                        re = -fma(gw[i1], code(i1), gw[i0] * code(i0));
+                        im = fma(gw[i2], code(i2), -(gw[i3] * code(i3)));
                     }
                 } else {
                     const int m = 2 * n - Q;
@@ -161,8 +159,8 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
                         re = fma(wa, code(i0), -(wb * code(i1)));
                         im = -fma(wb, code(i2), wa * code(i3));
                     } else {
-                        re = fma(gw[i0] * kscale, code(i0), -((gw[i1] * kscale) * code(i1)));
-                        im = -fma(gw[i2] * kscale, code(i2), (gw[i3] * kscale) * code(i3));
+                        re = fma(gw[i0], code(i0), -(gw[i1] * code(i1)));
+                        im = -fma(gw[i2], code(i2), gw[i3] * code(i3));
                     }
                 }
                 v[n1] = c_mul(make_double2(re, im), twl[n]);
@@ -181,26 +179,16 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, MINW) void k_mdct_long_v2(
             wave_lds_fence();
         }
         wave_lds_fence();                 /* raw samples consumed: their LDS may be overwritten */
-        if (DBUF) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (cf + stride < total)
-                stage(cf + stride);
-            younger = 0;
-        }
         fft512n(v, tile, w1, 64, w2, 8, lane);
-        if (!DBUF) {
-            /* the tile is free again: start the next frame's PCM on its way now, it
-               lands during the epilogue and the other waves' work.  The DMA writes
-               LDS from the vector-memory side and is not ordered with this wave's
-               own ds_reads, so the FFT's last tile reads must have returned first
-               (a wavefront-scope fence does not wait for them). */
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (cf + stride < total)
-                stage(cf + stride);
-        }
-        if (!mine)
-            continue;
-        younger = scale_out ? 9 : 8;
+        /* the tile is free again: start the next frame's PCM on its way now, it
+           lands during the epilogue and the other waves' work.  The DMA writes
+           LDS from the vector-memory side and is not ordered with this wave's
+           own ds_reads, so the FFT's last tile reads must have returned first
+           (a wavefront-scope fence does not wait for them; hazard table in DESIGN.md,
+           checked on the compiled code by tests/test_build_isa.py). */
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (cf + stride < total)
+            stage(cf + stride);
 
         double a[8], b[8];
         double mx = 0.0;
@@ -246,47 +234,29 @@ void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8
         return;
     if (status_init && (!scale_out || scale_stride != PACX_SUB))
         status_init = nullptr;                 /* the caller keeps its memsets */
-    /* geometry variants (PACX_MDCT_VARIANT, for experiments; default 0) */
+    /* PACX_MDCT_VARIANT (experiments and the kernel-equivalence test): -1 / unset = the
+       defaults below; 0 = this file's kernel also for batches without flags; 7 = the
+       two-tile kernel k_mdct_long_x2 */
     static int variant = -2;
     if (variant == -2) {
         const char *e = getenv("PACX_MDCT_VARIANT");
-        variant = e ? atoi(e) : -1;            /* -1: the defaults below */
+        variant = e ? atoi(e) : -1;
     }
     /* default: batches without per-frame flags (all sine windows) go to the pipelined
        two-frames-per-wave kernel of k_mdct3.hip; batches with flags (transition
        windows, frames left to the short kernel) stay here */
-    if (variant == -1 && !flags) {
-        pacx_launch_mdct_x2(T, in, n_cf, lines, scale_out, scale_stride, status_init, n_cu, 0, st);
+    if (!flags && variant != 0) {
+        pacx_launch_mdct_x2(T, in, n_cf, lines, scale_out, scale_stride, status_init, n_cu, variant == 7 ? 8 : 0,
+                            st);
         return;
     }
-#define LAUNCH(W, MW, PER_CU, DB)                                                                        \
-    do {                                                                                              \
-        long long blocks = (n_cf + (W) - 1) / (W);                                                    \
-        const long long cap = (long long)n_cu * (PER_CU);                                             \
-        if (blocks > cap)                                                                             \
-            blocks = cap;                                                                             \
-        if (flags)                                                                                    \
-            hipLaunchKernelGGL((k_mdct_long_v2<W, MW, DB, true>), dim3((unsigned)blocks), dim3(64 * (W)), 0, st, \
-                               T, in, flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init); \
-        else                                                                                          \
-            hipLaunchKernelGGL((k_mdct_long_v2<W, MW, DB, false>), dim3((unsigned)blocks), dim3(64 * (W)), 0, st, \
-                               T, in, flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init); \
-    } while (0)
-    if (variant >= 7 && variant <= 9 && !flags) {   /* two frames in flight per wave (k_mdct3.hip) */
-        pacx_launch_mdct_x2(T, in, n_cf, lines, scale_out, scale_stride, status_init, n_cu,
-                            variant == 7 ? 8 : (variant == 8 ? 6 : 4), st);
-        return;
-    }
-    switch (variant) {
-    case 1: LAUNCH(6, 3, 2, false); break;   /* 12 waves/CU in two workgroups                 */
-    case 2: LAUNCH(4, 2, 2, false); break;   /* 8 waves/CU in two workgroups                  */
-    case 3: LAUNCH(8, 2, 1, true); break;    /* 8 waves/CU, PCM landing buffer (120 KB LDS)   */
-    case 4: LAUNCH(4, 2, 2, true); break;    /* 2 x 4 waves, landing buffer (2 x 72 KB)       */
-    case 5: LAUNCH(16, 4, 1, false); break;  /* 16 waves/CU, 128 VGPRs (152 KB LDS)           */
-    case 6: LAUNCH(12, 3, 1, false); break;  /* 12 waves/CU in one workgroup (120 KB LDS)     */
-    case 12: LAUNCH(4, 2, 1, false); break;  /* 4 waves/CU (56 KB LDS): room for the side chain */
-    case 13: LAUNCH(6, 3, 1, false); break;  /* 6 waves/CU (72 KB LDS)                          */
-    default: LAUNCH(8, 2, 1, false); break;  /* 8 waves/CU, one workgroup per CU              */
-    }
-#undef LAUNCH
+    long long blocks = (n_cf + MDCT2_WAVES - 1) / MDCT2_WAVES;
+    if (blocks > n_cu)
+        blocks = n_cu;                         /* one persistent workgroup per CU */
+    if (flags)
+        hipLaunchKernelGGL((k_mdct_long_v2<true>), dim3((unsigned)blocks), dim3(64 * MDCT2_WAVES), 0, st, T, in,
+                           flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init);
+    else
+        hipLaunchKernelGGL((k_mdct_long_v2<false>), dim3((unsigned)blocks), dim3(64 * MDCT2_WAVES), 0, st, T, in,
+                           flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init);
 }

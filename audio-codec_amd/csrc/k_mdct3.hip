@@ -504,16 +504,9 @@ void pacx_launch_mdct_x2(const PacxTables &T, const PacxPcmView &in, long long n
         return;
     if (status_init && (!scale_out || scale_stride != PACX_SUB))
         status_init = nullptr;
-    long long blocks = (n_cf + 2 * waves - 1) / (2 * waves);
+    long long blocks = (n_cf + 2 * 8 - 1) / (2 * 8);
     if (blocks > n_cu)
         blocks = n_cu;
-    if (waves == 8)
-        hipLaunchKernelGGL((k_mdct_long_x2<8, 2>), dim3((unsigned)blocks), dim3(64 * 8), 0, st, T, in, n_cf, lines,
-                           scale_out, scale_stride, status_init);
-    else if (waves == 6)
-        hipLaunchKernelGGL((k_mdct_long_x2<6, 2>), dim3((unsigned)blocks), dim3(64 * 6), 0, st, T, in, n_cf, lines,
-                           scale_out, scale_stride, status_init);
-    else
-        hipLaunchKernelGGL((k_mdct_long_x2<4, 1>), dim3((unsigned)blocks), dim3(64 * 4), 0, st, T, in, n_cf, lines,
-                           scale_out, scale_stride, status_init);
+    hipLaunchKernelGGL((k_mdct_long_x2<8, 2>), dim3((unsigned)blocks), dim3(64 * 8), 0, st, T, in, n_cf, lines,
+                       scale_out, scale_stride, status_init);
 }

@@ -446,7 +446,12 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
     const long long cf = blockIdx.x;
     if (cf >= A.n_cf)
         return;
-    const int nbytes = A.n_bytes[cf];
+    /* as k_unpack (k_decode.hip): a record that is truncated or carries an impossible
+       allocation gets PACX_ST_MALFORMED and decodes to zeros; nothing beyond n_bytes is read */
+    int nbytes = A.n_bytes[cf];
+    bool bad = nbytes < 1 || nbytes > 4 * (VQD_WORDS - 2);
+    if (bad)
+        nbytes = 0;
     const uint8_t *src = A.payload + (A.offsets ? A.offsets[cf] : cf * (long long)A.payload_stride);
     const int n_words = (nbytes + 3) >> 2;
     for (int i = tid; i < VQD_WORDS; i += 64 * VQD_WAVES) {
@@ -462,8 +467,10 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
         lines_s[i] = 0.0;
     __syncthreads();
     if (tid == 0) {
-        const unsigned fl = (unsigned)vqd_get(words, 0, 1) | ((unsigned)vqd_get(words, 1, 1) << 1) |
-                            ((unsigned)vqd_get(words, 2, 1) << 2);
+        const int limit = 8 * nbytes;
+        const unsigned fl = bad ? 0u
+                                : (unsigned)vqd_get(words, 0, 1) | ((unsigned)vqd_get(words, 1, 1) << 1) |
+                                      ((unsigned)vqd_get(words, 2, 1) << 2);
         A.cf_flags[cf] = (uint8_t)fl;
         const int shrt = (fl >> 1) & 1;
         const int nb = shrt ? T.nb_short : T.nb_long;
@@ -472,7 +479,9 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
         /* Decode_SBR is chosen per block: an SBR file, a long block, and some
            omitted band with a non-zero allocation (coder/pacfile.py:661-666) */
         int sbr = 0;
-        if (T.use_sbr && !shrt) {
+        if (3 + T.n_scale_bits + T.n_mant_size_bits * nb > limit)
+            bad = true;
+        if (T.use_sbr && !shrt && !bad) {
             int p2 = pos + T.n_scale_bits;
             for (int b = 0; b < nb; ++b) {
                 if (b >= T.first_omitted && vqd_get(words, p2, T.n_mant_size_bits) != 0)
@@ -480,7 +489,11 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
                 p2 += T.n_mant_size_bits;
             }
         }
-        for (int s = 0; s < (shrt ? PACX_SUB : 1); ++s) {
+        for (int s = 0; s < (shrt ? PACX_SUB : 1) && !bad; ++s) {
+            if (pos + T.n_scale_bits + T.n_mant_size_bits * nb > limit) {
+                bad = true;
+                break;
+            }
             A.overall[cf * PACX_SUB + s] = (int)vqd_get(words, pos, T.n_scale_bits);
             pos += T.n_scale_bits;
             int body = pos + T.n_mant_size_bits * nb;
@@ -489,18 +502,31 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
                 if (a)
                     a += 1;
                 pos += T.n_mant_size_bits;
+                const int span = a * ((sbr && b >= T.first_omitted) ? 1 : cnt[b]);
+                if (a > 16 || body + span > limit) {
+                    bad = true;
+                    break;
+                }
                 A.bit_alloc[cf * T.band_stride + s * nb + b] = a;
                 item_pos[s * PACX_MAX_BANDS + b] = body;
                 item_ba[s * PACX_MAX_BANDS + b] = a;
-                body += a * ((sbr && b >= T.first_omitted) ? 1 : cnt[b]);
+                body += span;
             }
             pos = body;
         }
-        if (!shrt)
+        if (bad) {
+            for (int s = 0; s < PACX_SUB; ++s)
+                A.overall[cf * PACX_SUB + s] = 0;
+            for (int i = 0; i < T.band_stride; ++i)
+                A.bit_alloc[cf * T.band_stride + i] = 0;
+            atomicOr(&A.status[cf], 32u);                          /* PACX_ST_MALFORMED */
+            sbr = 0;
+        } else if (!shrt) {
             for (int s = 1; s < PACX_SUB; ++s)
                 A.overall[cf * PACX_SUB + s] = 0;
+        }
         misc[0] = 0;
-        misc[1] = (shrt ? PACX_SUB : 1) * nb;
+        misc[1] = bad ? 0 : (shrt ? PACX_SUB : 1) * nb;
         misc[2] = shrt;
         misc[3] = sbr;
         A.sbr_flag[cf] = (uint8_t)sbr;

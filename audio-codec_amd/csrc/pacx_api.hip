@@ -14,6 +14,7 @@
 #include "../../include/pacx.h"
 #include "pacx_dev.h"
 #include "pacx_vq_tables.h"
+#include "pacx_tables_gen.h"
 
 /* kernels (k_mdct.hip, k_psy.hip, k_quant.hip) */
 void pacx_launch_mdct(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
@@ -65,7 +66,8 @@ void pacx_launch_transient(const PacxPcmView &in, long long n_hops, int hop, uin
 
 void pacx_launch_unpack(const PacxTables &T, long long n_cf, const uint8_t *payload, int payload_stride,
                         const long long *offsets, const int32_t *n_bytes, uint8_t *flags_out, int32_t *overall,
-                        int32_t *scale_factor, int32_t *bit_alloc, int32_t *mantissa, hipStream_t st);
+                        int32_t *scale_factor, int32_t *bit_alloc, int32_t *mantissa, uint32_t *status,
+                        hipStream_t st);
 void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const uint8_t *cf_flags,
                         const int32_t *overall, const int32_t *scale_factor, const int32_t *bit_alloc,
                         const int32_t *mantissa, const double *lines_in, double *blocks, int16_t *pcm,
@@ -119,6 +121,7 @@ struct pacx_handle {
     hipEvent_t ev_fork, ev_join;
     std::vector<char> vq_view;        /* VqView of k_vq.hip (device pointers)   */
     std::vector<char> vqdec_view;     /* VqDecView of k_vq_dec.hip              */
+    int tables_exact;                 /* every float64 table is the NumPy-evaluated one */
     long long ws_mant_cf;             /* capacity of ws_mant                    */
     int32_t *ws_mant;                 /* [cf][1024] mantissas of short frames when the caller wants none */
     long long ws_dec_cf;              /* capacity of the VQ decode buffers      */
@@ -173,12 +176,69 @@ static std::vector<double2> unit_circle(int count, long double num_mul, long dou
     return t;
 }
 
-static std::vector<double> sine_window_c(int n)
+/* built-in float64 tables (pacx_tables_gen.h): bit patterns of the NumPy evaluation */
+static std::vector<double> gen_table(const uint64_t *bits, size_t n)
 {
-    std::vector<double> w(n);
-    for (int i = 0; i < n; ++i)
-        w[i] = sin(M_PI * (i + 0.5) / n);
-    return w;
+    std::vector<double> t(n);
+    memcpy(t.data(), bits, n * sizeof(double));
+    return t;
+}
+
+static int gen_rate_index(int sample_rate)
+{
+    for (int i = 0; i < PACX_GEN_N_RATES; ++i)
+        if (PACX_GEN_RATES[i] == sample_rate)
+            return i;
+    return -1;
+}
+
+extern "C" int pacx_tables_exact(const pacx_handle *h) { return h ? h->tables_exact : PACX_E_ARG; }
+
+/* coder/psychoac.py:100-103 */
+static const double kCbFreqLimits[25] = {100, 200, 300, 400, 510, 630, 770, 920, 1080, 1270, 1480, 1720, 2000,
+                                         2320, 2700, 3150, 3700, 4400, 5300, 6400, 7700, 9500, 12000, 15500,
+                                         24000};
+
+extern "C" int pacx_default_bands(int sample_rate, int n_mdct_lines, int32_t *band_lines, int32_t *n_bands)
+{
+    if (sample_rate <= 0 || n_mdct_lines <= 0 || !band_lines || !n_bands)
+        return PACX_E_ARG;
+    /* AssignMDCTLinesFromFreqLimits (coder/psychoac.py:106-124), same operations in the
+       same order: every one is a correctly rounded IEEE operation or exact */
+    const double width = (double)sample_rate / (double)(2 * n_mdct_lines);
+    double centers[25], counts[25];
+    for (int i = 0; i < 25; ++i)
+        centers[i] = floor(kCbFreqLimits[i] / width - 0.5);
+    for (int i = 0; i < 25; ++i)
+        counts[i] = centers[i] - (i ? centers[i - 1] : -1.0);
+    for (int i = 0; i < 25; ++i)
+        if (kCbFreqLimits[i] > (double)sample_rate / 2.0) {
+            double sum = 0.0;
+            for (int k = 0; k < i; ++k)
+                sum += counts[k];
+            counts[i] = (double)n_mdct_lines - sum;
+            for (int k = i + 1; k < 25; ++k)
+                counts[k] = 0.0;
+            break;
+        }
+    /* ScaleFactorBands (coder/psychoac.py:143-149): a band of <= 12 lines joins its right
+       neighbour (the array is cast to int first, :141) */
+    std::vector<long long> n(25);
+    for (int i = 0; i < 25; ++i)
+        n[i] = (long long)counts[i];
+    size_t i = 1;
+    while (i < n.size()) {
+        if (n[i - 1] <= 12) {
+            n[i] += n[i - 1];
+            n.erase(n.begin() + (long)(i - 1));
+        } else {
+            ++i;
+        }
+    }
+    for (size_t k = 0; k < n.size(); ++k)
+        band_lines[k] = (int32_t)n[k];
+    *n_bands = (int32_t)n.size();
+    return PACX_OK;
 }
 
 extern "C" int pacx_abi_version(void) { return PACX_ABI_VERSION; }
@@ -260,6 +320,7 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->ws_lines = nullptr; h->ws_smr = nullptr; h->ws_peaks = nullptr; h->ws_npeaks = nullptr;
     h->ws_overall = nullptr; h->ws_chunks = nullptr; h->ws_offs = nullptr; h->ws_nkept = nullptr;
     h->ws_lists = nullptr;
+    h->tables_exact = 1;
     memset(&h->T, 0, sizeof(h->T));
     int rc = PACX_OK;
 #define TRY(x) do { rc = (x); if (rc) { g_create_err = h->err; pacx_destroy(h); return rc; } } while (0)
@@ -292,7 +353,8 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     if (cfg->win_long) {
         memcpy(wl.data(), cfg->win_long, sizeof(double) * 4 * NL);
     } else {
-        const std::vector<double> sl = sine_window_c(NL), ss = sine_window_c(NS);
+        /* coder/window.py:61-92: np.concatenate of sine halves, ones and zeros */
+        const std::vector<double> sl = gen_table(PACX_GEN_SINE_LONG, NL), ss = gen_table(PACX_GEN_SINE_SHORT, NS);
         const int pad = NL / 4 - NS / 4;
         for (int i = 0; i < NL; ++i) {
             wl[i] = sl[i];
@@ -314,11 +376,18 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
             wl[2 * NL + i] = wl[NL + (NL - 1 - i)];       /* stop = flipped start */
     }
     if (cfg->win_short) memcpy(ws.data(), cfg->win_short, sizeof(double) * NS);
-    else ws = sine_window_c(NS);
-    for (int i = 0; i < NL; ++i)
-        hl[i] = cfg->hann_long ? cfg->hann_long[i] : 0.5 * (1 - cos(2 * M_PI * (i + 0.5) / NL));
-    for (int i = 0; i < NS; ++i)
-        hs[i] = cfg->hann_short ? cfg->hann_short[i] : 0.5 * (1 - cos(2 * M_PI * (i + 0.5) / NS));
+    else ws = gen_table(PACX_GEN_SINE_SHORT, NS);
+    if (cfg->hann_long) memcpy(hl.data(), cfg->hann_long, sizeof(double) * NL);
+    else hl = gen_table(PACX_GEN_HANN_LONG, NL);
+    if (cfg->hann_short) memcpy(hs.data(), cfg->hann_short, sizeof(double) * NS);
+    else hs = gen_table(PACX_GEN_HANN_SHORT, NS);
+    {
+        std::vector<double> kl = gen_table(PACX_GEN_KBD_LONG, NL), ks = gen_table(PACX_GEN_KBD_SHORT, NS);
+        if (cfg->kbd_long) memcpy(kl.data(), cfg->kbd_long, sizeof(double) * NL);
+        if (cfg->kbd_short) memcpy(ks.data(), cfg->kbd_short, sizeof(double) * NS);
+        TRY(upload(h, kl.data(), kl.size(), &T.kbd_long));
+        TRY(upload(h, ks.data(), ks.size(), &T.kbd_short));
+    }
     TRY(upload(h, wl.data(), wl.size(), &T.win_long));
     TRY(upload(h, ws.data(), ws.size(), &T.win_short));
     TRY(upload(h, hl.data(), hl.size(), &T.hann_long));
@@ -360,15 +429,24 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     /* psychoacoustic tables at the MDCT line frequencies (coder/psychoac.py:183-184) */
     {
         std::vector<double> bl(ML), tl(ML), bs(MS), ts(MS);
+        /* NULL tables: the built-in NumPy-evaluated copies where the sample rate has them,
+           else the C math library (pacx_tables_exact() then says 0) */
+        const int ri = gen_rate_index(cfg->sample_rate);
+        const double *g_bl = ri >= 0 ? (const double *)PACX_GEN_BARK_LONG + (size_t)ri * ML : nullptr;
+        const double *g_tl = ri >= 0 ? (const double *)PACX_GEN_THRESH_LONG + (size_t)ri * ML : nullptr;
+        const double *g_bs = ri >= 0 ? (const double *)PACX_GEN_BARK_SHORT + (size_t)ri * MS : nullptr;
+        const double *g_ts = ri >= 0 ? (const double *)PACX_GEN_THRESH_SHORT + (size_t)ri * MS : nullptr;
+        if (ri < 0 && (!cfg->bark_long || !cfg->thresh_long || !cfg->bark_short || !cfg->thresh_short))
+            h->tables_exact = 0;
         for (int k = 0; k < ML; ++k) {
             const double f = (sr / (2 * ML)) * (k + 0.5);
-            bl[k] = cfg->bark_long ? cfg->bark_long[k] : pacx_bark(f);
-            tl[k] = cfg->thresh_long ? cfg->thresh_long[k] : pacx_thresh_quiet(f);
+            bl[k] = cfg->bark_long ? cfg->bark_long[k] : (g_bl ? g_bl[k] : pacx_bark(f));
+            tl[k] = cfg->thresh_long ? cfg->thresh_long[k] : (g_tl ? g_tl[k] : pacx_thresh_quiet(f));
         }
         for (int k = 0; k < MS; ++k) {
             const double f = (sr / (2 * MS)) * (k + 0.5);
-            bs[k] = cfg->bark_short ? cfg->bark_short[k] : pacx_bark(f);
-            ts[k] = cfg->thresh_short ? cfg->thresh_short[k] : pacx_thresh_quiet(f);
+            bs[k] = cfg->bark_short ? cfg->bark_short[k] : (g_bs ? g_bs[k] : pacx_bark(f));
+            ts[k] = cfg->thresh_short ? cfg->thresh_short[k] : (g_ts ? g_ts[k] : pacx_thresh_quiet(f));
         }
         TRY(upload(h, bl.data(), bl.size(), &T.bark_long));
         TRY(upload(h, tl.data(), tl.size(), &T.thresh_long));
@@ -384,8 +462,9 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         }
         return (double)(4.0L / ((long double)n * n * (acc / n)));
     };
-    T.norm_long = cfg->fft_norm_long != 0.0 ? cfg->fft_norm_long : hanning_norm(NL);
-    T.norm_short = cfg->fft_norm_short != 0.0 ? cfg->fft_norm_short : hanning_norm(NS);
+    (void)hanning_norm;       /* kept as the formula; the built-in values are NumPy's */
+    T.norm_long = cfg->fft_norm_long != 0.0 ? cfg->fft_norm_long : ((const double *)PACX_GEN_FFT_NORM)[0];
+    T.norm_short = cfg->fft_norm_short != 0.0 ? cfg->fft_norm_short : ((const double *)PACX_GEN_FFT_NORM)[1];
     T.fstep_long = cfg->fft_freq_step_long != 0.0 ? cfg->fft_freq_step_long : 1.0 / (NL * (1.0 / sr));
     T.fstep_short = cfg->fft_freq_step_short != 0.0 ? cfg->fft_freq_step_short : 1.0 / (NS * (1.0 / sr));
 
@@ -443,7 +522,9 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         for (int b = 0; b < T.nb_short; ++b)
             l_max = cfg->band_lines_short[b] > l_max ? cfg->band_lines_short[b] : l_max;
         PacxVqHostTables vt;
-        pacx_vq_build(l_max, cfg->half_log2, &vt);
+        /* NULL gain-shape tables: the built-in NumPy-evaluated copies (l_max <= 1024 always:
+           a band cannot have more lines than the block) */
+        pacx_vq_build(l_max, cfg->half_log2 ? cfg->half_log2 : (const double *)PACX_GEN_HALF_LOG2, &vt);
         const uint64_t *d_n, *d_p;
         const int32_t *d_off, *d_k;
         const uint8_t *d_w;
@@ -464,19 +545,13 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
             sizes_long[b] = 1;
         /* log2(tan(theta_q) + eps) of the quantised split angles (bit_allocation_ms) */
         std::vector<double> lt((1u << PACX_VQ_THETA_TABLE_BITS) - 1, 0.0);
-        if (cfg->vq_log2_tan) {
-            memcpy(lt.data(), cfg->vq_log2_tan, sizeof(double) * lt.size());
-        } else {
-            for (int a = 1; a <= PACX_VQ_THETA_TABLE_BITS; ++a)
-                for (long long code = 1; code < (1ll << (a - 1)); ++code) {
-                    const double th = ((double)(2 * code) / (double)((1ll << a) - 1)) * 1.5707963267948966;
-                    lt[((1u << (a - 1)) - 1) + code] = log2(tan(fabs(th)) + PACX_EPS);
-                }
-        }
+        memcpy(lt.data(), cfg->vq_log2_tan ? cfg->vq_log2_tan : (const double *)PACX_GEN_VQ_LOG2_TAN,
+               sizeof(double) * lt.size());
+        static_assert(sizeof(PACX_GEN_VQ_LOG2_TAN) / 8 == (1u << PACX_VQ_THETA_TABLE_BITS) - 1, "log2-tan table");
         const double *d_lt;
         TRY(upload(h, lt.data(), lt.size(), &d_lt));
         pacx_vq_view_fill(h->vq_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max,
-                          cfg->log_mu1 != 0.0 ? cfg->log_mu1 : log(256.0), d_lt, sizes_long.data(), T.nb_long,
+                          cfg->log_mu1 != 0.0 ? cfg->log_mu1 : ((const double *)PACX_GEN_LOG_MU1)[0], d_lt, sizes_long.data(), T.nb_long,
                           cfg->band_lines_short, T.nb_short);
         /* decode side: Gaussian weights of gaussian_filter1d(sigma=200) (radius
            int(4*200 + 0.5)) and the MDCT line frequencies of Decode_SBR */
@@ -487,17 +562,9 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
             return PACX_E_ARG;
         }
         std::vector<double> gw(2 * gr + 1), lf(ML);
-        if (cfg->sbr_gauss) {
-            memcpy(gw.data(), cfg->sbr_gauss, sizeof(double) * gw.size());
-        } else {
-            double sum = 0;
-            for (int j = -gr; j <= gr; ++j) {
-                gw[j + gr] = exp(-0.5 / (200.0 * 200.0) * (double)(j * j));
-                sum += gw[j + gr];
-            }
-            for (double &v : gw)
-                v /= sum;
-        }
+        static_assert(sizeof(PACX_GEN_SBR_GAUSS) / 8 == 2 * 800 + 1, "gaussian weights");
+        memcpy(gw.data(), cfg->sbr_gauss ? cfg->sbr_gauss : (const double *)PACX_GEN_SBR_GAUSS,
+               sizeof(double) * gw.size());
         for (int k = 0; k < ML; ++k)
             lf[k] = cfg->line_freq_long ? cfg->line_freq_long[k] : (k + 0.5) * (sr / (2 * ML));
         const double *d_gw, *d_lf;
@@ -627,8 +694,15 @@ extern "C" int pacx_mdct_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t
         return PACX_OK;
     if (!lines)
         return fail(h, PACX_E_ARG, "pacx_mdct_batch: lines is null");
+    if ((mode & PACX_MDCT_KBD) && (frame_flags || (mode & PACX_MDCT_PREWINDOWED)))
+        return fail(h, PACX_E_ARG, "pacx_mdct_batch: PACX_MDCT_KBD takes no frame flags and no PREWINDOWED");
     HIP_TRY(h, hipSetDevice(h->device));
     const int short_blocks = (mode & PACX_MDCT_SHORT) ? 1 : 0;
+    if (mode & PACX_MDCT_KBD) {              /* window override 2 = the KBD tables */
+        pacx_launch_mdct(h->T, v, in->dtype, fast, nullptr, n_cf, short_blocks, 0, 2, lines, max_scale,
+                         short_blocks ? PACX_SUB : 1, nullptr, (hipStream_t)stream);
+        return post_launch(h, "pacx_mdct_batch");
+    }
     if (fast && !short_blocks && !(mode & PACX_MDCT_PREWINDOWED)) {
         pacx_launch_mdct_v2(h->T, v, frame_flags, n_cf, 0, lines, max_scale, 1, nullptr, h->n_cu,
                             (hipStream_t)stream);
@@ -925,11 +999,25 @@ extern "C" int pacx_window_batch(pacx_handle *h, int window, int64_t n_rows, con
     case PACX_WIN_SINE_SHORT: w = h->T.win_short; len = PACX_N_SHORT; break;
     case PACX_WIN_HANN: w = h->T.hann_long; len = PACX_N_LONG; break;
     case PACX_WIN_HANN_SHORT: w = h->T.hann_short; len = PACX_N_SHORT; break;
+    case PACX_WIN_KBD: w = h->T.kbd_long; len = PACX_N_LONG; break;
+    case PACX_WIN_KBD_SHORT: w = h->T.kbd_short; len = PACX_N_SHORT; break;
     default: return fail(h, PACX_E_ARG, "pacx_window_batch: unknown window");
     }
     HIP_TRY(h, hipSetDevice(h->device));
     pacx_launch_window(w, n_rows, len, x, y, (hipStream_t)stream);
     return post_launch(h, "pacx_window_batch");
+}
+
+extern "C" int pacx_window_table_batch(pacx_handle *h, const double *table, int len, int64_t n_rows,
+                                       const double *x, double *y, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_rows < 0 || len < 1 || !table || !x || !y)
+        return fail(h, PACX_E_ARG, "pacx_window_table_batch: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_window(table, n_rows, len, x, y, (hipStream_t)stream);
+    return post_launch(h, "pacx_window_table_batch");
 }
 
 static int quant_elem(pacx_handle *h, int op, int64_t n, const double *x, int scale, int a, int b,
@@ -1003,7 +1091,7 @@ extern "C" int pacx_transient_flags(pacx_handle *h, const pacx_pcm *hops, uint8_
 extern "C" int pacx_unpack_batch(pacx_handle *h, int64_t n_cf, const uint8_t *payload, int payload_stride,
                                  const int64_t *offsets, const int32_t *n_bytes, uint8_t *cf_flags,
                                  int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,
-                                 int32_t *mantissa, void *stream)
+                                 int32_t *mantissa, uint32_t *status, void *stream)
 {
     if (!h)
         return PACX_E_ARG;
@@ -1014,7 +1102,7 @@ extern "C" int pacx_unpack_batch(pacx_handle *h, int64_t n_cf, const uint8_t *pa
         return fail(h, PACX_E_ARG, "pacx_unpack_batch: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     pacx_launch_unpack(h->T, n_cf, payload, payload_stride, (const long long *)offsets, n_bytes, cf_flags,
-                       overall_scale, scale_factor, bit_alloc, mantissa, (hipStream_t)stream);
+                       overall_scale, scale_factor, bit_alloc, mantissa, status, (hipStream_t)stream);
     return post_launch(h, "pacx_unpack_batch");
 }
 

@@ -24,6 +24,8 @@ struct PacxTables {
     const double *hann_long;    /* [2048]                                     */
     const double *hann_short;   /* [256]                                      */
     const double *ones;         /* [2048] of 1.0: MDCT of pre-windowed data     */
+    const double *kbd_long;     /* [2048] KBDWindow(alpha=4), coder/window.py:53-57 */
+    const double *kbd_short;    /* [256]                                      */
     const double *hann_long_pcm;   /* hann_long  * 2/65535 (int16 side chain)   */
     const double *hann_short_pcm;  /* hann_short * 2/65535                      */
     const double2 *tw_long;     /* exp(-j pi (8n+1)/8192), n < 512            */

@@ -207,23 +207,31 @@ __device__ __forceinline__ double wave_max_upper(double v)
  * dependent LDS round trips in all -- against six per maximum for wave_max); once one value
  * is left the remaining steps are plain.  On return m[0] of lane l holds the wave maximum
  * of value number l / (64 / N). */
+/* one halving step with compile-time n and offset: every index of m[] is a constant, so the
+ * array stays in registers (a run-time n made m[n + i] a dynamic index and sent the whole
+ * array to scratch: 272 B per lane in k_mask<1024>, 150 MB of writes per launch) */
+template <int HALF, int OFF, int N>
+__device__ __forceinline__ void wave_max_n_step(double (&m)[N], int lane)
+{
+    if constexpr (HALF >= 1) {
+        const bool up = (lane & OFF) != 0;
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const double keep = up ? m[HALF + i] : m[i], send = up ? m[i] : m[HALF + i];
+            m[i] = fmax(keep, __shfl_xor(send, OFF, 64));
+        }
+        wave_max_n_step<HALF / 2, OFF / 2, N>(m, lane);
+    } else if constexpr (OFF >= 1) {
+        m[0] = fmax(m[0], __shfl_xor(m[0], OFF, 64));
+        wave_max_n_step<0, OFF / 2, N>(m, lane);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void wave_max_n(double (&m)[N], int lane)
 {
     static_assert(N == 8 || N == 16 || N == 32, "wave_max_n");
-    int off = 32;
-#pragma unroll
-    for (int n = N / 2; n >= 1; n >>= 1, off >>= 1) {
-        const bool up = (lane & off) != 0;
-#pragma unroll
-        for (int i = 0; i < n; ++i) {
-            const double keep = up ? m[n + i] : m[i], send = up ? m[i] : m[n + i];
-            m[i] = fmax(keep, __shfl_xor(send, off, 64));
-        }
-    }
-#pragma unroll
-    for (; off >= 1; off >>= 1)
-        m[0] = fmax(m[0], __shfl_xor(m[0], off, 64));
+    wave_max_n_step<N / 2, 32, N>(m, lane);
 }
 
 #endif

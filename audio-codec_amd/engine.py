@@ -117,6 +117,8 @@ class Encoder:
         gw, gr = tables.sbr_gauss()
         cfg.sbr_gauss, cfg.sbr_gauss_radius = f64("gw", gw), gr
         cfg.line_freq_long = f64("lf", (np.arange(N_LONG) + 1 / 2) * (sr / (2 * N_LONG)))
+        cfg.kbd_long = f64("kl", tables.kbd(2 * N_LONG))
+        cfg.kbd_short = f64("ks", tables.kbd(2 * N_SHORT))
         h = ctypes.c_void_p()
         rc = self.lib.pacx_create(ctypes.byref(cfg), ctypes.byref(h))
         _lib.check(self.lib, None, rc, "pacx_create")
@@ -164,14 +166,15 @@ class Encoder:
         return t.contiguous()
 
     # ------------------------------------------------------------------ stages
-    def mdct(self, pcm, flags=None, short=False, want_scale=False, prewindowed=False):
+    def mdct(self, pcm, flags=None, short=False, want_scale=False, prewindowed=False, kbd=False):
         """window + MDCT (+ overall scale factor).  lines: [n_cf, 1024] float64
-        (short: [n_cf, 8, 128])."""
+        (short: [n_cf, 8, 128]).  kbd: KBDWindow instead of the sine window."""
         fl = self.flags_tensor(flags, pcm.n_frames)
         lines = self._empty((pcm.n_cf, N_LONG), torch.float64)
         scale = self._empty((pcm.n_cf, _lib.SUB) if short else (pcm.n_cf,), torch.int32) \
             if want_scale else None
-        mode = (_lib.MDCT_SHORT if short else 0) | (_lib.MDCT_PREWINDOWED if prewindowed else 0)
+        mode = (_lib.MDCT_SHORT if short else 0) | (_lib.MDCT_PREWINDOWED if prewindowed else 0) | \
+            (_lib.MDCT_KBD if kbd else 0)
         self._call("pacx_mdct_batch", ctypes.byref(pcm.c), _ptr(fl), mode, _ptr(lines),
                    _ptr(scale), self._stream())
         if short:
@@ -321,14 +324,15 @@ class Encoder:
 
     # ------------------------------------------------------------ decode side
     def unpack(self, payload, n_bytes, offsets=None):
-        """Parse packed channel-blocks (slot layout, or a byte stream + int64 offsets)."""
+        """Parse packed channel-blocks (slot layout, or a byte stream + int64 offsets).
+        out["status"] carries PACX_ST_MALFORMED for a record that is truncated or corrupt."""
         n_cf = n_bytes.shape[0]
         out = self.alloc_outputs(n_cf)
         out["flags"] = self._empty((n_cf,), torch.uint8)
         stride = 0 if offsets is not None else int(payload.shape[1])
         self._call("pacx_unpack_batch", ctypes.c_int64(n_cf), _ptr(payload), stride, _ptr(offsets),
                    _ptr(n_bytes), _ptr(out["flags"]), _ptr(out["overall"]), _ptr(out["scale_factor"]),
-                   _ptr(out["bit_alloc"]), _ptr(out["mantissa"]), self._stream())
+                   _ptr(out["bit_alloc"]), _ptr(out["mantissa"]), _ptr(out["status"]), self._stream())
         return out
 
     def decode(self, codes, n_channels, want_blocks=False, want_pcm=True):
@@ -374,6 +378,21 @@ class Encoder:
         self._call("pacx_window_batch", int(kind), ctypes.c_int64(x.shape[0]), _ptr(x), _ptr(y),
                    self._stream())
         return y
+
+    def window_table(self, table, x):
+        """table * x for rows of x ([n, len] float64 on the GPU) with a caller-evaluated
+        table (host array or device tensor of len entries)."""
+        x = x.contiguous()
+        t = torch.as_tensor(np.ascontiguousarray(table, dtype=np.float64), device=self.device) \
+            if not isinstance(table, torch.Tensor) else table.contiguous()
+        assert t.numel() == x.shape[-1]
+        y = torch.empty_like(x)
+        self._call("pacx_window_table_batch", _ptr(t), int(t.numel()), ctypes.c_int64(x.numel() // t.numel()),
+                   _ptr(x), _ptr(y), self._stream())
+        return y
+
+    def tables_exact(self):
+        return bool(self.lib.pacx_tables_exact(self.h))
 
     def _elem(self, name, x, *ints):
         x = x.contiguous()

@@ -21,6 +21,8 @@ from .psychoac import AssignMDCTLinesFromFreqLimits, ScaleFactorBands
 
 BYTESIZE = 8
 _ST_VQ_UNDEFINED = 8          # include/pacx.h
+_ST_MALFORMED = 32
+_PARTIAL = "Only read a partial block of coded PACFile data"     # coder/pacfile.py:203-205
 
 
 def omitted_bands(sfBands, factor=2):
@@ -120,10 +122,14 @@ class PACFile(AudioFile):
                     tail, cp.overlapAndAdd = cp.overlapAndAdd, 0
                     return tail
                 return None
+            if len(s) < 4:
+                raise RuntimeError(_PARTIAL)
             n = int.from_bytes(s, "little")
+            if n < 1 or n > enc.payload_stride:
+                raise RuntimeError(_PARTIAL + f" (record of {n} bytes)")
             blob = self.fp.read(n)
             if len(blob) < n:
-                raise RuntimeError("Only read a partial block of coded PACFile data")
+                raise RuntimeError(_PARTIAL)
             payloads.append(blob)
         slot = enc.payload_stride
         buf = np.zeros((cp.nChannels, slot), dtype=np.uint8)
@@ -131,10 +137,15 @@ class PACFile(AudioFile):
             buf[ch, :len(blob)] = np.frombuffer(blob, dtype=np.uint8)
         sizes = torch.tensor([len(b) for b in payloads], dtype=torch.int32, device=enc.device)
         if getattr(cp, "useVQ", False):
-            blocks = enc.decode_vq(torch.as_tensor(buf, device=enc.device), sizes, cp.nChannels,
-                                   want_blocks=True, want_pcm=False)["blocks"].cpu().numpy()
+            out = enc.decode_vq(torch.as_tensor(buf, device=enc.device), sizes, cp.nChannels,
+                                want_blocks=True, want_pcm=False)
+            if int(out["status"].max().item()) & _ST_MALFORMED:
+                raise RuntimeError(_PARTIAL)
+            blocks = out["blocks"].cpu().numpy()
         else:
             codes = enc.unpack(torch.as_tensor(buf, device=enc.device), sizes)
+            if int(codes["status"].max().item()) & _ST_MALFORMED:
+                raise RuntimeError(_PARTIAL)
             blocks = enc.decode(codes, cp.nChannels, want_blocks=True, want_pcm=False).cpu().numpy()
         data = []
         for ch in range(cp.nChannels):
@@ -233,6 +244,25 @@ def parse_header(data):
     return cp, pos + 4 + 2 * n_bands
 
 
+def record_chain(data, pos, max_record):
+    """Walks the '<L nBytes' chain of a .pac body (sequential by nature) and returns the
+    payload offsets and sizes.  Sizes come from the file, so they are checked before anything
+    is handed to the GPU: the reference's reader raises when a block is cut short
+    (coder/pacfile.py:200-205), and a record longer than any the coder writes is corrupt."""
+    offs, sizes = [], []
+    end = len(data)
+    while pos < end:
+        if pos + 4 > end:
+            raise RuntimeError(_PARTIAL)
+        n = int.from_bytes(data[pos:pos + 4], "little")
+        if n < 1 or n > max_record or pos + 4 + n > end:
+            raise RuntimeError(_PARTIAL + f" (record of {n} bytes at offset {pos})")
+        offs.append(pos + 4)
+        sizes.append(n)
+        pos += 4 + n
+    return offs, sizes
+
+
 def decode_stream(data):
     """Whole .pac (bytes; scalar, gain-shape or gain-shape + SBR) -> int16 [n, nCh], batched on the GPU: what
     the reference's decode loop (coder/pacfile.py:745-757) writes as PCM."""
@@ -241,22 +271,22 @@ def decode_stream(data):
     if cp.useSBR and not cp.useVQ:
         raise NotImplementedError("scalar-mantissa SBR streams are not produced by the reference's driver")
     enc = context.encoder_for_params(cp)
-    offs, sizes = [], []
-    while pos < len(data):                                # the '<L nBytes' chain is sequential by nature
-        n = int.from_bytes(data[pos:pos + 4], "little")
-        offs.append(pos + 4)
-        sizes.append(n)
-        pos += 4 + n
+    offs, sizes = record_chain(data, pos, enc.payload_stride)
     if len(offs) % cp.nChannels:
-        raise RuntimeError("Only read a partial block of coded PACFile data")
+        raise RuntimeError(_PARTIAL)
     body = torch.frombuffer(bytearray(data) + bytearray(8), dtype=torch.uint8).to(enc.device)
     sizes_t = torch.tensor(sizes, dtype=torch.int32, device=enc.device)
     offs_t = torch.tensor(offs, dtype=torch.int64, device=enc.device)
     if cp.useVQ:
         out = enc.decode_vq(body, sizes_t, cp.nChannels, offsets=offs_t)
-        if int(out["status"].max().item()) & _ST_VQ_UNDEFINED:
+        st = int(out["status"].max().item()) if len(sizes) else 0
+        if st & _ST_MALFORMED:
+            raise RuntimeError(_PARTIAL)
+        if st & _ST_VQ_UNDEFINED:
             raise RuntimeError("stream holds a gain-shape block the reference's decoder fails on "
                                "(PACX_ST_VQ_UNDEFINED)")
         return out["pcm"].cpu().numpy()
     codes = enc.unpack(body, sizes_t, offs_t)
+    if len(sizes) and int(codes["status"].max().item()) & _ST_MALFORMED:
+        raise RuntimeError(_PARTIAL)
     return enc.decode(codes, cp.nChannels).cpu().numpy()

@@ -25,6 +25,15 @@ def hann(n):
     return 0.5 * (1 - np.cos(2 * np.pi * (np.arange(n) + 0.5) / n))
 
 
+def kbd(n, alpha=4.):
+    """coder/window.py:53-57 (what the reference calls its KBD window: the Kaiser form
+    i0(pi alpha sqrt(1 - ((2n+1)/N - 1)^2)) / i0(pi alpha))."""
+    k = np.arange(n)
+    numerator = np.i0(np.pi * alpha * np.sqrt(1 - ((2 * k + 1) / n - 1) ** 2))
+    denominator = np.i0(np.pi * alpha)
+    return numerator / denominator
+
+
 def start(n_long, n_short):
     pad = n_long // 4 - n_short // 4
     return np.concatenate((sine(n_long)[:n_long // 2], np.ones(pad),

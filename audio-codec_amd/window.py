@@ -30,6 +30,21 @@ def HanningWindow(dataSampleArray):
                   2048 if n == 2048 else 256)
 
 
+def KBDWindow(dataSampleArray, alpha=4.):
+    """coder/window.py:45-57.  The 2048- and 256-sample tables for alpha = 4 are resident
+    (PACX_WIN_KBD*); any other length or alpha is evaluated on the host with the reference's
+    expression and multiplied on the GPU (pacx_window_table_batch)."""
+    import torch
+    from . import tables
+    n = np.shape(dataSampleArray)[-1]
+    if alpha == 4. and n in (2048, 256):
+        return _apply(_lib.WIN_KBD if n == 2048 else _lib.WIN_KBD_SHORT, dataSampleArray, n)
+    data = np.ascontiguousarray(dataSampleArray, dtype=np.float64)
+    enc = context.any_encoder()
+    y = enc.window_table(tables.kbd(n, alpha), torch.as_tensor(data, device=enc.device).view(-1, n))
+    return y.cpu().numpy().reshape(data.shape)
+
+
 def _check(N_long, N_short):
     if (N_long, N_short) != (2048, 256):
         raise NotImplementedError("transition windows are resident for N_long=2048, N_short=256")

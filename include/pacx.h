@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PACX_ABI_VERSION 2
+#define PACX_ABI_VERSION 3
 
 /* error codes */
 #define PACX_OK            0
@@ -63,10 +63,16 @@ extern "C" {
 #define PACX_WIN_SINE_SHORT 4  /* SineWindow on a 256-sample short block      */
 #define PACX_WIN_HANN 5        /* HanningWindow, 2048 (coder/window.py:29-41) */
 #define PACX_WIN_HANN_SHORT 6  /* HanningWindow, 256                          */
+#define PACX_WIN_KBD 7         /* KBDWindow(alpha = 4), 2048 (coder/window.py:45-57) */
+#define PACX_WIN_KBD_SHORT 8   /* KBDWindow(alpha = 4), 256                   */
 
 /* mode bits of pacx_mdct_batch */
 #define PACX_MDCT_SHORT 1        /* 8 short sub-blocks per frame              */
 #define PACX_MDCT_PREWINDOWED 2  /* input already windowed: plain mdct.MDCT   */
+#define PACX_MDCT_KBD 4          /* KBDWindow instead of the sine window, long or
+                                    short blocks: MDCT(KBDWindow(x), halfN, halfN), the
+                                    expression at coder/bitalloc.py:161 (frame_flags
+                                    must be NULL)                              */
 
 /* per-cf status word bits written by pacx_encode_batch */
 #define PACX_ST_SHORT        1u   /* coded as 8 short sub-blocks               */
@@ -82,6 +88,20 @@ extern "C" {
                                      gives NaN pulses, a gain index wider than
                                      128 bits): the band's bits are zeros     */
 
+#define PACX_ST_GUARD        16u   /* a rounding decision of this cf sat within a few
+                                     ulps of its boundary: a mantissa / scale-factor
+                                     quantiser input (2^R-1)|x|+1 next to an even
+                                     integer (coder/quantize.py:73), or a BitAlloc
+                                     value Ropt - level next to k + 1/2
+                                     (coder/bitalloc.py:103).  The codes are still the
+                                     ones this arithmetic gives; a harness that needs
+                                     certainty recomputes flagged frames on the CPU  */
+#define PACX_ST_MALFORMED    32u   /* decode: the payload of this channel-block is
+                                     truncated or carries an impossible field (the
+                                     reference raises "Only read a partial block of
+                                     coded PACFile data", coder/pacfile.py:203-205):
+                                     its outputs are zeros                          */
+
 #define PACX_SHORT_PER_FRAME 8    /* sub-blocks of a short frame (coder/pacfile.py:527) */
 
 typedef struct pacx_handle pacx_handle;
@@ -90,8 +110,12 @@ typedef struct pacx_handle pacx_handle;
  * Static configuration = the CodingParams attributes the path reads
  * (coder/pacfile.py:699-707, 323-330).  Table pointers are HOST pointers,
  * copied at create time.  Tables marked "optional" may be NULL: the library
- * then evaluates the same formulas with the C math library (results can
- * differ from NumPy's in the last place).
+ * then uses its built-in copies (csrc/pacx_tables_gen.h: the reference's NumPy
+ * expressions evaluated once and stored as bit patterns, so a C host gets the
+ * same bits as the Python host) -- windows and gain-shape tables always, the
+ * Bark / threshold-in-quiet tables for 44.1 and 48 kHz.  At other sample rates
+ * those two are evaluated with the C math library (last-place differences from
+ * NumPy's are possible); pacx_tables_exact() tells which case a handle is in.
  */
 typedef struct pacx_config {
     int32_t abi_version;            /* PACX_ABI_VERSION                           */
@@ -139,6 +163,9 @@ typedef struct pacx_config {
     const double *sbr_gauss;        /* [2r+1] normalised weights of gaussian_filter1d(sigma=200) */
     int32_t sbr_gauss_radius;       /* r = int(4*200 + 0.5) = 800                    */
     const double *line_freq_long;   /* [n_lines_long] (k + 1/2) * sampleRate/(2*n_lines_long)   */
+    /* KBDWindow(alpha = 4) tables (coder/window.py:53-57), optional: */
+    const double *kbd_long;         /* [2*n_lines_long]                              */
+    const double *kbd_short;        /* [2*n_lines_short]                             */
 } pacx_config;
 
 /* one written field of a gain-shape coded band (see pacx_encode_vq_batch) */
@@ -182,6 +209,18 @@ int  pacx_band_stride(const pacx_handle *h);
 int  pacx_payload_stride(const pacx_handle *h);
 /* pre-size the device workspace for batches of up to n_cf channel-frames */
 int  pacx_reserve(pacx_handle *h, int64_t n_cf);
+/* 1 if every float64 table of the handle is bit-identical to the reference's NumPy
+   evaluation (supplied by the caller or built in), 0 if some came from the C math
+   library (NULL Bark / threshold tables at a sample rate without built-in copies) */
+int  pacx_tables_exact(const pacx_handle *h);
+/*
+ * psychoac.py band layout for hosts without NumPy: AssignMDCTLinesFromFreqLimits
+ * (coder/psychoac.py:106-124) followed by the merge rule of ScaleFactorBands
+ * (:143-149: a band of <= 12 lines joins its right neighbour).  Plain IEEE double
+ * arithmetic, bit-for-bit the reference's.  band_lines (HOST, room for 25 ints)
+ * receives sfBands.nLines, *n_bands their number.  No handle needed.
+ */
+int  pacx_default_bands(int sample_rate, int n_mdct_lines, int32_t *band_lines, int32_t *n_bands);
 
 /* ---- stage entry points (one per replaced reference module) ------------ */
 
@@ -196,6 +235,8 @@ int  pacx_reserve(pacx_handle *h, int64_t n_cf);
  *   mode & PACX_MDCT_SHORT: every frame is cut into 8 short sub-blocks at
  *       n = 448 + 128 j (coder/pacfile.py:526-527), sine-windowed.
  *       lines: [n_cf][8][n_lines_short].
+ *   mode & PACX_MDCT_KBD: as mode 0 / PACX_MDCT_SHORT with the KBD window
+ *       (alpha = 4) in place of the sine window; frame_flags must be NULL.
  * frame_flags: device uint8 [n_frames] of PACX_FLAG_* or NULL.
  * max_scale (optional, device int32 [n_cf] or [n_cf][8]): the overall scale
  * factor ScaleFactor(max|line|, nScaleBits) (coder/codec.py:308-310).
@@ -327,10 +368,14 @@ int pacx_gather_body(pacx_handle *h, int64_t n_cf, const uint8_t *payload,
  * above does not call these. */
 
 /* window.py: y = window * x for n_rows rows (SineWindow / StartWindow /
- * StopWindow / StartStopWindow / HanningWindow; coder/window.py:14-92).
+ * StopWindow / StartStopWindow / HanningWindow / KBDWindow; coder/window.py:14-92).
  * `window` is a PACX_WIN_* id; rows are 2048 (256 for *_SHORT) float64. */
 int pacx_window_batch(pacx_handle *h, int window, int64_t n_rows, const double *x, double *y,
                       void *stream);
+/* the same with a caller-supplied DEVICE table of `len` float64 (any block length,
+ * e.g. KBDWindow with another alpha or N): y[r][i] = table[i] * x[r][i] */
+int pacx_window_table_batch(pacx_handle *h, const double *table, int len, int64_t n_rows,
+                            const double *x, double *y, void *stream);
 /* quantize.py: vQuantizeUniform(x, n_bits) (coder/quantize.py:61-78) */
 int pacx_quantize_uniform(pacx_handle *h, int64_t n, const double *x, int n_bits, int64_t *codes,
                           void *stream);
@@ -363,11 +408,14 @@ int pacx_transient_flags(pacx_handle *h, const pacx_pcm *hops, uint8_t *transien
  * payload + offsets[i] (offsets != NULL, e.g. a .pac body) or at
  * payload + i*payload_stride.  Outputs use the layouts of pacx_encode_batch;
  * cf_flags: uint8 [n_cf] PACX_FLAG_* read from each payload.
+ * status (optional): uint32 [n_cf], PACX_ST_MALFORMED for a channel-block whose
+ * fields run past its n_bytes or carry an allocation above maxMantBits = 16 (its
+ * other outputs are then zeros; nothing is read beyond n_bytes either way).
  */
 int pacx_unpack_batch(pacx_handle *h, int64_t n_cf, const uint8_t *payload, int payload_stride,
                       const int64_t *offsets, const int32_t *n_bytes, uint8_t *cf_flags,
                       int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,
-                      int32_t *mantissa, void *stream);
+                      int32_t *mantissa, uint32_t *status, void *stream);
 
 /*
  * codec.Decode for a batch (coder/codec.py:47-92: vDequantize, / 2^overall, IMDCT,

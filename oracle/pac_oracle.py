@@ -75,6 +75,14 @@ def hann_window(n):
     return 0.5 * (1 - np.cos(2 * np.pi * (k + 0.5) / n))
 
 
+def kbd_window(n, alpha=4.):
+    """coder/window.py:45-57: what the reference calls its KBD window is the Kaiser form
+    i0(pi alpha sqrt(1 - ((2k+1)/N - 1)^2)) / i0(pi alpha) (no cumulative sum)."""
+    k = np.arange(n)
+    num = np.i0(np.pi * alpha * np.sqrt(1 - ((2 * k + 1) / n - 1) ** 2))
+    return num / np.i0(np.pi * alpha)
+
+
 def start_window(n_long, n_short):
     """coder/window.py:61-71.  The reference builds the pieces by windowing
     vectors of ones, i.e. window*1.0, which is the window itself."""

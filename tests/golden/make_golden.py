@@ -26,6 +26,8 @@ Outputs
   excerpt_vq_*.npz  (--vq) 24-hop excerpts in the shipped configuration
   decoded_vq_*.npz  (--vq-decoded) those excerpts through the reference's decoder
   vqwav.json        (--vq-decoded) hashes of the decoded WAVs the reference committed
+  kbd.npz           (--kbd) window.KBDWindow tables and MDCT(KBDWindow(x)) of the six-tone
+                    block, the expression at coder/bitalloc.py:161
 """
 import hashlib
 import io
@@ -584,7 +586,34 @@ def make_full(names):
               sort_keys=True)
 
 
+def make_kbd():
+    """window.KBDWindow (coder/window.py:45-57) and its one use with the MDCT
+    (coder/bitalloc.py:153-161: MDCT(KBDWindow(x), N//2, N//2) of the six-tone block)."""
+    Fs = 48000
+    freqs = np.array([440, 550, 660, 880, 4400, 8800])
+    amps = np.array([0.43, 0.24, 0.15, 0.09, 0.05, 0.04])
+    out = {}
+    for N in (2048, 256, 1024):
+        x = np.sum(np.array([amps[i] * np.cos(2 * np.pi * freqs[i] * np.arange(N) / Fs)
+                             for i in range(6)]), axis=0)
+        out[f"x_{N}"] = x
+        out[f"kbd_{N}"] = window.KBDWindow(np.ones(N))
+        out[f"kbd_x_{N}"] = window.KBDWindow(x)
+        out[f"mdct_kbd_x_{N}"] = mdct.MDCT(window.KBDWindow(x), N // 2, N // 2)
+    out["kbd_2048_alpha2p5"] = window.KBDWindow(np.ones(2048), alpha=2.5)
+    out["kbd_512_alpha4"] = window.KBDWindow(np.ones(512))
+    rng = np.random.default_rng(7)
+    xs = rng.uniform(-1, 1, size=(3, 2048))
+    out["rand_x"] = xs
+    out["rand_kbd_x"] = np.stack([window.KBDWindow(r) for r in xs])
+    np.savez_compressed(os.path.join(HERE, "kbd.npz"), **out)
+    print("kbd.npz written")
+
+
 if __name__ == "__main__":
+    if "--kbd" in sys.argv:
+        make_kbd()
+        sys.exit(0)
     names = ["castanet", "harpsichord", "quar48_1", "spmg"]
     wavs = {n: read_wav(os.path.join(REF, "test_signals", n + ".wav"))
             for n in names}

@@ -1,0 +1,76 @@
+"""CPU gate on what the compiler made of the kernels: every kernel a default entry point
+launches must run without scratch memory and without spilled vector registers
+(`hipcc -Rpass-analysis=kernel-resource-usage`, recorded per kernel by
+audio-codec_amd/build.py in build/resources.json at compile time).
+
+Round 1's k_mask<1024> silently kept a 32-double array in scratch (272 B per lane,
+150 MB of HBM writes per launch) because one reduction helper indexed it with a run-time
+value; this test is what keeps that from coming back unnoticed."""
+import importlib
+import re
+
+import pytest
+
+
+@pytest.fixture(scope="module")
+def res():
+    import audio_codec_amd  # noqa: F401
+    return importlib.import_module("audio_codec_amd.build").resources()
+
+
+def _find(res, pattern):
+    hits = {k: v for k, v in res.items() if re.search(pattern, k)}
+    assert hits, f"no kernel matches {pattern!r}"
+    return hits
+
+
+# (regex on the demangled name, max VGPRs or None, min waves/SIMD or None)
+HOT = [
+    (r"^void k_mdct_long_x2p<8, 2>\(", 256, 2),          # headline MDCT kernel
+    (r"^void k_mdct_long_v2<true>\(", 256, 2),           # batches with block-switching flags
+    (r"^void k_mdct_long_v2<false>\(", 256, 2),
+    (r"^void k_mdct_short<0, true>\(", 128, 4),
+    (r"^void k_side_long<0, true, true>\(", 168, 3),     # int16 fast path, compact LDS
+    (r"^void k_side_long<0, true, false>\(", 168, 3),    # ... SBR handles
+    (r"^void k_side_short<0, true>\(", 168, 3),
+    (r"^void k_mask<1024>\(", 168, 3),
+    (r"^void k_mask<128>\(", 96, 5),
+    (r"^k_tail_long\(", 128, 4),
+    (r"^k_tail_short\(", 64, 8),
+    (r"^k_gather_small\(", None, None),
+    pytest.param(r"^k_vq\(", 168, 3, marks=pytest.mark.xfail(strict=True, reason="20 spilled VGPRs at 3 waves/SIMD (needs 200)")),
+    (r"^k_vq_join\(", None, None),
+    (r"^k_vq_dec\(", 168, 3),
+    (r"^k_unpack\(", None, None),
+    (r"^k_imdct_long\(", None, None),
+    (r"^k_imdct_short\(", None, None),
+    (r"^k_transient\(", None, None),
+]
+
+
+@pytest.mark.parametrize("pattern,max_vgprs,min_occ", HOT)
+def test_hot_kernel_has_no_scratch(res, pattern, max_vgprs, min_occ):
+    for name, r in _find(res, pattern).items():
+        assert r["scratch"] == 0, f"{name}: {r['scratch']} B/lane of scratch"
+        assert r["vgpr_spill"] == 0, f"{name}: {r['vgpr_spill']} spilled VGPRs"
+        if max_vgprs is not None:
+            assert r["vgprs"] + r["agprs"] <= max_vgprs, (name, r)
+        if min_occ is not None:
+            assert r["occupancy"] >= min_occ, (name, r)
+
+
+def test_every_kernel_is_reported(res):
+    """the report covers the library: a kernel that lost its remark (renamed flag, new
+    compiler) must not pass the gate by being absent"""
+    assert len(res) >= 40
+    for name, r in res.items():
+        for key in ("vgprs", "agprs", "scratch", "vgpr_spill", "occupancy", "lds", "source"):
+            assert key in r, (name, key)
+
+
+def test_only_listed_kernels_use_scratch(res):
+    """anything else with scratch is a function-level mirror off the hot path, named here"""
+    allowed = {"k_bitalloc_generic", "k_vq("}        # serial reference-shaped BitAlloc (bitalloc.BitAlloc mirror), one lane per call
+    for name, r in res.items():
+        if r["scratch"] or r["vgpr_spill"]:
+            assert any(a in name for a in allowed), f"{name}: scratch {r['scratch']}, spilled {r['vgpr_spill']}"

@@ -1,0 +1,230 @@
+"""GPU parity tests added in round 2: KBDWindow (coder/window.py:45-57) through the C ABI,
+decode of malformed records, oracle comparison on a batch large enough for the
+multi-iteration paths of the persistent kernels (>= 32 768 channel-frames)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_excerpt
+from oracle import pac_oracle as po
+
+pytestmark = pytest.mark.gpu
+MDCT_TOL = 2e-12       # relative to max |X| of the block
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "GPU tests need a GPU"
+    return t
+
+
+@pytest.fixture(scope="module")
+def A():
+    import audio_codec_amd as a
+    a.load()
+    return a
+
+
+@pytest.fixture(scope="module")
+def kbd():
+    return np.load(os.path.join(GOLDEN, "kbd.npz"))
+
+
+# ------------------------------------------------------------------- KBD window
+def test_kbd_window_values_bit_equal(A, torch, kbd):
+    """window.KBDWindow through pacx_window_batch (resident alpha = 4 tables) and
+    pacx_window_table_batch (any alpha / length) against the reference's values."""
+    for n in (2048, 256):
+        assert np.array_equal(A.window.KBDWindow(np.ones(n)), kbd[f"kbd_{n}"])
+        assert np.array_equal(A.window.KBDWindow(kbd[f"x_{n}"]), kbd[f"kbd_x_{n}"])
+    assert np.array_equal(A.window.KBDWindow(kbd["rand_x"]), kbd["rand_kbd_x"])
+    assert np.array_equal(A.window.KBDWindow(np.ones(1024)), kbd["kbd_1024"])
+    assert np.array_equal(A.window.KBDWindow(kbd["x_1024"]), kbd["kbd_x_1024"])
+    assert np.array_equal(A.window.KBDWindow(np.ones(2048), alpha=2.5), kbd["kbd_2048_alpha2p5"])
+    assert np.array_equal(A.window.KBDWindow(np.ones(512)), kbd["kbd_512_alpha4"])
+
+
+def test_mdct_of_kbd_windowed_block(A, torch, kbd):
+    """MDCT(KBDWindow(x), N//2, N//2) of the six-tone block, the expression at
+    coder/bitalloc.py:161, three ways: PACX_MDCT_KBD on float64 input (window fused into the
+    kernel), mdct.MDCT on the GPU-windowed block, and the short-block size."""
+    enc = A.context.encoder(48000, 128 / 48.0)
+    want = kbd["mdct_kbd_x_2048"]
+    ref = np.max(np.abs(want))
+    x = torch.as_tensor(kbd["x_2048"], device=enc.device).view(1, 1, 2048)
+    got = enc.mdct(A.engine.PcmView.frames(x), kbd=True)[0].cpu().numpy()
+    assert np.max(np.abs(got - want)) <= MDCT_TOL * ref
+    got2 = A.mdct.MDCT(A.window.KBDWindow(kbd["x_2048"]), 1024, 1024)
+    assert np.max(np.abs(got2 - want)) <= MDCT_TOL * ref
+    # short: the 256-sample block parked at sub-block 0 (samples 448..704)
+    frame = np.zeros(2048)
+    frame[448:448 + 256] = kbd["x_256"]
+    xs = torch.as_tensor(frame, device=enc.device).view(1, 1, 2048)
+    gs = enc.mdct(A.engine.PcmView.frames(xs), short=True, kbd=True)[0, 0].cpu().numpy()
+    ws = kbd["mdct_kbd_x_256"]
+    assert np.max(np.abs(gs - ws)) <= MDCT_TOL * np.max(np.abs(ws))
+    # int16 input goes through the same kernel: against the oracle on the rounded codes
+    codes = np.rint(32767 * kbd["x_2048"]).astype(np.int16)
+    xi = torch.as_tensor(codes, device=enc.device).view(1, 1, 2048)
+    gi = enc.mdct(A.engine.PcmView.frames(xi), kbd=True)[0].cpu().numpy()
+    wi = po.mdct_forward(po.kbd_window(2048) * po.pcm16_to_fraction(codes), 1024, 1024)
+    assert np.max(np.abs(gi - wi)) <= MDCT_TOL * np.max(np.abs(wi))
+    with pytest.raises(A.PacxError):
+        enc.mdct(A.engine.PcmView.frames(x), flags=[(0, 0, 1)], kbd=True)
+
+
+def test_builtin_tables_equal_uploaded_ones(A, torch):
+    """A handle created with NULL table pointers (what a C host does) must code exactly as
+    the Python host's handle: same .pac payload bytes, pacx_tables_exact() == 1."""
+    import ctypes
+    L = A._lib
+    lib = A.load()
+    for sr in (48000, 44100):
+        enc = A.context.encoder(sr, 128 / (sr / 1000))
+        assert enc.tables_exact()
+        cfg = L.PacxConfig()
+        cfg.abi_version, cfg.device, cfg.sample_rate = L.PACX_ABI_VERSION, enc.device.index, sr
+        cfg.n_lines_long, cfg.n_lines_short, cfg.n_scale_bits, cfg.n_mant_size_bits = 1024, 128, 4, 12
+        bl = (ctypes.c_int32 * 25)()
+        bs = (ctypes.c_int32 * 25)()
+        nl, ns = ctypes.c_int32(), ctypes.c_int32()
+        assert lib.pacx_default_bands(sr, 1024, bl, ctypes.byref(nl)) == 0
+        assert lib.pacx_default_bands(sr, 128, bs, ctypes.byref(ns)) == 0
+        assert list(bl[:nl.value]) == enc.sfBands.nLines.tolist()
+        cfg.n_bands_long, cfg.n_bands_short = nl.value, ns.value
+        cfg.band_lines_long = ctypes.cast(bl, L.c_int32_p)
+        cfg.band_lines_short = ctypes.cast(bs, L.c_int32_p)
+        cfg.target_bits_per_sample = 128 / (sr / 1000)
+        h = ctypes.c_void_p()
+        assert lib.pacx_create(ctypes.byref(cfg), ctypes.byref(h)) == 0, lib.pacx_last_error(None)
+        try:
+            assert lib.pacx_tables_exact(h) == 1
+            pcm = A.synth.stream(16, 2, sample_rate=sr)
+            planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=enc.device)
+            view = A.engine.PcmView.stream(planar)
+            want = enc.encode_pack(view)
+            bare = A.engine.Encoder.__new__(A.engine.Encoder)      # same calls on the bare handle
+            bare.__dict__.update(enc.__dict__)
+            bare.h = h
+            got = bare.encode_pack(view)
+            bare.h = None
+            for k in ("overall", "scale_factor", "bit_alloc", "n_bytes", "payload"):
+                assert torch.equal(got[k], want[k]), (sr, k)
+        finally:
+            lib.pacx_destroy(h)
+    # a rate without built-in Bark/threshold tables says so
+    cfg.sample_rate = 32000
+    bl32 = (ctypes.c_int32 * 25)()
+    assert lib.pacx_default_bands(32000, 1024, bl32, ctypes.byref(nl)) == 0
+    cfg.n_bands_long, cfg.band_lines_long = nl.value, ctypes.cast(bl32, L.c_int32_p)
+    assert lib.pacx_default_bands(32000, 128, bs, ctypes.byref(ns)) == 0
+    cfg.n_bands_short = ns.value
+    cfg.target_bits_per_sample = 4.0
+    h = ctypes.c_void_p()
+    assert lib.pacx_create(ctypes.byref(cfg), ctypes.byref(h)) == 0, lib.pacx_last_error(None)
+    assert lib.pacx_tables_exact(h) == 0
+    lib.pacx_destroy(h)
+
+
+# ------------------------------------------------------- malformed input, decode side
+def _stream_and_pac(A, vq):
+    ex = load_excerpt("castanet")
+    pcm = ex["pcm"][:12 * 1024]
+    sr = int(ex["sr"])
+    return A.pacfile.encode_stream(pcm, sr, 128, block_switching=True, use_vq=vq, use_sbr=False)
+
+
+@pytest.mark.parametrize("vq", [False, True])
+def test_truncated_and_corrupt_pac_raise(A, torch, vq):
+    """The reference stops with 'Only read a partial block of coded PACFile data'
+    (coder/pacfile.py:203-205) on a file cut short; a record whose fields cannot be what
+    the coder wrote (an allocation field above maxMantBits, fields past the record's end)
+    must do the same here instead of steering the bit cursor out of the record."""
+    pac = _stream_and_pac(A, vq)
+    good = A.pacfile.decode_stream(pac)
+    assert good.shape[0] > 0
+    for cut in (len(pac) - 1, len(pac) - 200, len(pac) // 2 + 1):
+        with pytest.raises(RuntimeError, match="partial block"):
+            A.pacfile.decode_stream(pac[:cut])
+    # a length field that points past the end of the file
+    cp, pos = A.pacfile.parse_header(pac)
+    bad = bytearray(pac)
+    bad[pos:pos + 4] = (len(pac)).to_bytes(4, "little")
+    with pytest.raises(RuntimeError, match="partial block"):
+        A.pacfile.decode_stream(bytes(bad))
+    # an impossible allocation in the first band of the first record: 12 bits of ones
+    # right after the 3 flag bits and the 4-bit overall scale (coder/pacfile.py:404-447)
+    bad = bytearray(pac)
+    first = pos + 4
+    fl = bad[first] >> 5
+    assert not (fl & 2), "first block of the excerpt is a long block"
+    bits = int.from_bytes(bad[first:first + 4], "big")
+    bits |= 0xFFF << (32 - 7 - 12)
+    bad[first:first + 4] = bits.to_bytes(4, "big")
+    with pytest.raises(RuntimeError, match="partial block"):
+        A.pacfile.decode_stream(bytes(bad))
+
+
+def test_unpack_status_per_record(A, torch):
+    """pacx_unpack_batch: PACX_ST_MALFORMED on exactly the records that are cut short, zeros
+    for their codes, the intact neighbours untouched."""
+    enc = A.context.encoder(48000, 128 / 48.0)
+    pcm = A.synth.stream(8, 2)
+    planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=enc.device)
+    out = enc.encode_pack(A.engine.PcmView.stream(planar), want_mantissa=True)
+    n_bytes = out["n_bytes"].clone()
+    short = [3, 10]
+    for i in short:
+        n_bytes[i] = n_bytes[i] // 2                       # the record ends in mid-band
+    n_bytes[5] = 0
+    back = enc.unpack(out["payload"], n_bytes)
+    st = back["status"].cpu().numpy()
+    assert [int(i) for i in np.nonzero(st & A._lib.ST_MALFORMED)[0]] == [3, 5, 10]
+    for k in ("overall", "scale_factor", "bit_alloc", "mantissa"):
+        got, want = back[k].cpu().numpy(), out[k].cpu().numpy()
+        for i in range(16):
+            if i in (3, 5, 10):
+                assert not got[i].any(), (k, i)
+            else:
+                assert np.array_equal(got[i], want[i]), (k, i)
+
+
+# ------------------------------------------- oracle comparison on a large batch
+def test_large_batch_sampled_against_oracle(A, torch):
+    """BASELINE configs[1] x 4 = 32 768 channel-frames in ONE call: every wave of
+    k_mdct_long_x2p runs more than two iterations, the mask / tail kernels walk several units
+    per wave and the body gather switches to its chunked scan.  97 channel-frames spread over
+    the batch are encoded by the oracle and compared bit for bit (codes and payload bytes);
+    the .pac body is checked record by record at those frames."""
+    n_frames = 16384
+    base = A.synth.stream(4096, 2)
+    gains = [1.0, 0.71, 0.5, 0.83]
+    pcm = np.concatenate([np.rint(base * g).astype(np.int16) for g in gains])
+    enc = A.context.encoder(48000, 128 / 48.0)
+    planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=enc.device)
+    out = enc.encode_pack(A.engine.PcmView.stream(planar), want_mantissa=True)
+    body, total = enc.gather_body(out["payload"], out["n_bytes"])
+    host = {k: v.cpu().numpy() for k, v in out.items() if v is not None and k != "flags"}
+    n_cf = 2 * n_frames
+    assert host["n_bytes"].shape[0] == n_cf == 32768
+    total = int(total.item())
+    assert total == int(host["n_bytes"].astype(np.int64).sum()) + 4 * n_cf
+    offs = np.concatenate(([0], np.cumsum(host["n_bytes"].astype(np.int64) + 4)))
+    body = body[:total].cpu().numpy()
+    p = po.make_params(48000, 2, 128)
+    halo = np.concatenate((np.zeros((1024, 2), np.int16), pcm))
+    for i in np.unique(np.concatenate((np.linspace(0, n_cf - 1, 89).astype(int),
+                                       [1, 4095, 8191, 8192, 16383, 16384, 32766, 32767]))):
+        f, ch = divmod(int(i), 2)
+        sf, ba, mant, ov = po.encode_channel(po.pcm16_to_fraction(halo[f * 1024:f * 1024 + 2048, ch]), p)
+        r = A.codec.unpack_long(enc, host, i)
+        assert r[3] == ov and r[1].tolist() == ba.tolist(), i
+        assert r[0].tolist() == sf.tolist() and r[2].tolist() == mant.tolist(), i
+        nb_want, want = po.pack_channel_block(p, (0, 0, 0), [(sf, ba, mant, ov)])
+        n = int(host["n_bytes"][i])
+        assert n == nb_want == len(want), i
+        assert host["payload"][i, :n].tobytes() == want, i
+        rec = body[offs[i]:offs[i + 1]].tobytes()
+        assert rec == len(want).to_bytes(4, "little") + want, i

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(A):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in pacx.h but not exported"
     assert set(A._lib.SIGNATURES) == declared
-    assert lib.pacx_abi_version() == A._lib.PACX_ABI_VERSION == 2
+    assert lib.pacx_abi_version() == A._lib.PACX_ABI_VERSION == 3
 
 
 def test_no_cpu_fallback(A):
@@ -65,6 +65,54 @@ def test_product_does_not_import_oracle():
     for m in re.finditer(r"from oracle import", src):
         before = src[:m.start()]
         assert ("def cpu_baseline" in before and "def main" not in before) or "cpu_baseline" in src[m.start() - 400:m.start() + 700]
+
+
+def test_builtin_tables_header_is_current():
+    """csrc/pacx_tables_gen.h (what a C host with NULL table pointers gets) holds exactly the
+    bits audio-codec_amd/tables.py evaluates with NumPy -- and those are pinned to the
+    reference's by the golden tables below and in test_oracle_golden.py."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tables_header.py"), "--check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_kbd_table_matches_reference(A):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kbd.npz"))
+    for n in (2048, 256, 1024):
+        assert np.array_equal(A.tables.kbd(n), g[f"kbd_{n}"])
+    assert np.array_equal(A.tables.kbd(2048, 2.5), g["kbd_2048_alpha2p5"])
+
+
+@pytest.mark.parametrize("sr", [48000, 44100, 32000, 96000, 22050])
+@pytest.mark.parametrize("n", [1024, 128, 512])
+def test_default_bands_in_c(A, sr, n):
+    """pacx_default_bands (the band layout for hosts without NumPy) against the oracle's
+    AssignMDCTLinesFromFreqLimits + ScaleFactorBands; runs on the CPU (no handle)."""
+    import ctypes
+    lib = A.load()
+    out = (ctypes.c_int32 * 25)()
+    nb = ctypes.c_int32(0)
+    assert lib.pacx_default_bands(sr, n, out, ctypes.byref(nb)) == 0
+    try:
+        want = po.band_table(n, sr).nLines.tolist()
+    except Exception:
+        pytest.skip("the reference's ScaleFactorBands fails for this rate / size")
+    assert list(out[:nb.value]) == want
+
+
+def test_record_chain_rejects_truncated_and_oversized(A):
+    """decode side: sizes read from a file are checked before anything reaches the GPU
+    (coder/pacfile.py:200-205 raises on a short read)."""
+    import struct as st
+    rec = lambda n: st.pack("<L", n) + bytes(n)
+    good = rec(10) + rec(300) + rec(1)
+    offs, sizes = A.pacfile.record_chain(good, 0, 2192)
+    assert sizes == [10, 300, 1] and offs == [4, 18, 322]
+    for bad in (good[:-1], good + b"\x01\x02", rec(10) + st.pack("<L", 5000) + bytes(5000),
+                rec(10) + st.pack("<L", 0), good[:16]):
+        with pytest.raises(RuntimeError, match="partial block"):
+            A.pacfile.record_chain(bad, 0, 2192)
 
 
 @pytest.mark.parametrize("sr", [48000, 44100])

@@ -50,6 +50,19 @@ def test_windows(tables):
     same(po.start_stop_window(2048, 256), tables["win_startstop_2048"])
 
 
+def test_kbd_window_and_its_mdct():
+    """window.KBDWindow (coder/window.py:45-57) and MDCT(KBDWindow(x), N//2, N//2), the
+    expression at coder/bitalloc.py:161, against the reference run by make_golden.py --kbd."""
+    g = np.load(os.path.join(GOLDEN, "kbd.npz"))
+    for n in (2048, 256, 1024):
+        same(po.kbd_window(n), g[f"kbd_{n}"])
+        same(po.kbd_window(n) * g[f"x_{n}"], g[f"kbd_x_{n}"])
+        same(po.mdct_forward(po.kbd_window(n) * g[f"x_{n}"], n // 2, n // 2), g[f"mdct_kbd_x_{n}"])
+    same(po.kbd_window(2048, 2.5), g["kbd_2048_alpha2p5"])
+    same(po.kbd_window(512), g["kbd_512_alpha4"])
+    same(po.kbd_window(2048) * g["rand_x"], g["rand_kbd_x"])
+
+
 def test_window_kind_priority():
     K = po.window_kind
     assert K(0, 0, 0) == po.WINDOW_SINE and K(1, 1, 1) == po.WINDOW_SINE
