@@ -92,6 +92,11 @@ class BitstreamGather:
         self.recv = [[torch.empty(self.slot, dtype=torch.uint8, device=device) for _ in range(self.world)]
                      if self.rank == dst else None for _ in range(depth)]
         self.work = [None] * depth
+        self.sent = [None] * depth          # valid-byte counts of the bodies handed to launch()
+
+    def capacity(self):
+        """bytes a body may hold"""
+        return self.slot - HEADER
 
     def body(self, k):
         """Where the encoder writes its records of step k (after the header)."""
@@ -99,13 +104,28 @@ class BitstreamGather:
 
     def launch(self, k, total):
         """total: int64 device tensor [1] = valid bytes in body(k) (device-side, no .item())."""
+        if not total.is_cuda and int(total.item()) > self.capacity():
+            # a host-side count can be checked before anything is sent
+            raise RuntimeError(f"rank {self.rank}: body of {int(total.item())} bytes overflows its "
+                               f"{self.capacity()}-byte gather slot")
         self.send[k][:HEADER].copy_(total.view(torch.uint8))
+        self.sent[k] = total.clone()        # device-side copy: read by check() outside the timed loop
         self.work[k] = dist.gather(self.send[k], self.recv[k], dst=self.dst, group=self.group, async_op=True)
 
     def wait(self, k):
         if self.work[k] is not None:
             self.work[k].wait()
             self.work[k] = None
+
+    def check(self, k):
+        """On the SENDING rank, after wait(k): the body this rank handed to launch(k) must have
+        fitted its slot (pacx_gather_body skips records that do not fit but still counts them,
+        so the count tells).  Synchronises with the device; call it outside timed regions."""
+        if self.sent[k] is not None:
+            n = int(self.sent[k].item())
+            if n > self.capacity():
+                raise RuntimeError(f"rank {self.rank}: body of {n} bytes overflowed its "
+                                   f"{self.capacity()}-byte gather slot")
 
     def unpack(self, k):
         """Rank dst, after wait(k): the concatenated bodies in rank order (uint8 tensor)."""

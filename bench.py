@@ -11,6 +11,18 @@ GPU -> window, MDCT, psychoacoustic SMR, bit allocation, scale factors +
 mantissas, .pac bit packing and body assembly; with N > 1 the packed bitstream
 of every rank is then gathered to rank 0 over RCCL.  Weak scaling: every rank
 encodes its own 4096-frame shard.  Prints ONE JSON line on rank 0.
+
+Timing: after W warm-up steps the K-step region (barrier + synchronize on both sides,
+maximum over ranks) is timed --repeats times; `value` and `ms_per_step` come from the
+MEDIAN region, the spread is reported in config.  After the timing, outside it, 32
+channel-frames spread over the batch are re-encoded by the oracle (the CPU restatement of
+the reference) and their payload bytes compared with what the timed kernels left in the
+output buffers: `verified_cf`.  The body must also have fitted its buffer.
+
+--corpus: BASELINE configs[4]: the config-2 stream tiled, tile t scaled
+by 0.5 + 0.5 (t mod 16)/16, 1 048 576 stereo frames in all (--corpus-frames), sharded into
+contiguous hop ranges with a one-hop halo: STRONG scaling (total work fixed), `value` with
+the final gather inside the step and, in config, without it.
 """
 import argparse
 import json
@@ -29,32 +41,121 @@ SAMPLE_RATE = 48000
 KBPS = 128
 MDCT_BYTES_PER_CF = 1024 * 2 + 1024 * 8      # int16 hop in + float64 lines out
 HBM_PEAK_GBS = 8000.0
+CORPUS_FRAMES = 1 << 20        # configs[4]: 1 048 576 stereo frames
 
 
-def cpu_baseline(n_frames=768, vq_kbps=None):
-    """The oracle (NumPy restatement of the reference, kind 'port') on the first
-    n_frames stereo frames of the same workload, one host core."""
+# ------------------------------------------------------------------ CPU baseline
+def _cpu_worker(job):
+    """one process: encode `per` stereo frames of a synthetic stream (seed offset i) with the
+    oracle.  Only per + 1 hops are generated: a worker's memory stays at a few tens of MB."""
+    i, per, vq_kbps = job
     from oracle import pac_oracle as po
     import audio_codec_amd as A
-    pcm = A.synth.stream(n_frames, N_CH)
+    pcm = A.synth.stream(per, N_CH, seed=A.synth.SEED + i)
     halo = np.concatenate((np.zeros((1024, N_CH), np.int16), pcm))
     if vq_kbps:
         from oracle import pac_oracle_vq as pv
         p = pv.make_params_vq(SAMPLE_RATE, N_CH, vq_kbps)
         fn = pv.encode_channel_sbr_vq if p.useSBR else pv.encode_channel_vq
-        what = "oracle/pac_oracle_vq.py " + fn.__name__
     else:
         p = po.make_params(SAMPLE_RATE, N_CH, KBPS)
         fn = po.encode_channel
-        what = "oracle/pac_oracle.py encode_channel"
     t0 = time.perf_counter()
-    for f in range(n_frames):
+    for f in range(per):
         for ch in range(N_CH):
             fn(po.pcm16_to_fraction(halo[f * 1024:f * 1024 + 2048, ch]), p)
-    dt = time.perf_counter() - t0
-    return {"value": n_frames * N_CH / dt, "unit": "channel-frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_frames} stereo frames ({n_frames * N_CH} cf) of the same synthetic stream, "
-                      f"{what}, {dt:.1f} s"}
+    return time.perf_counter() - t0
+
+
+def usable_cores():
+    """host cores this process may run on: the scheduler affinity (a GPU box hands a job a
+    share of its cores), never more than os.cpu_count(), capped at 32 workers"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, os.cpu_count() or 1, 32))
+
+
+def cpu_baseline(vq_kbps=None, frames_per_core=None):
+    """The oracle (NumPy restatement of the reference, kind 'port') on the same synthetic
+    workload: ALL usable host cores (one process per core, each its own run of hops -- the
+    reference parallelises the same way, over independent encodes with Pool(8),
+    coder/pacfile.py:780-781), one core alone, and BASELINE configs[0]'s excerpt
+    (harpsichord, 44.1 kHz, the committed 64-hop fixture) through the oracle's file loop."""
+    import subprocess
+    from oracle import pac_oracle as po
+    cores = usable_cores()
+    per = frames_per_core or (96 if vq_kbps else 160)
+    what = "oracle/pac_oracle_vq.py" if vq_kbps else "oracle/pac_oracle.py encode_channel"
+    dt1 = _cpu_worker((0, per, vq_kbps))
+    # one plain child process per core (no fork of a process that holds the GPU, no
+    # multiprocessing start-method subtleties): each imports this file and runs _cpu_worker
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "print(bench._cpu_worker((int(sys.argv[1]), %d, %r)))" % (ROOT, per, vq_kbps))
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for i in range(cores)]
+    for pr in procs:
+        so, se = pr.communicate(timeout=600)
+        if pr.returncode != 0:
+            raise RuntimeError("cpu_baseline worker failed: " + se[-400:])
+    wall = time.perf_counter() - t0
+    out = {"value": cores * per * N_CH / wall, "unit": "channel-frames/s", "cores": cores, "kind": "port",
+           "sample": f"{cores} processes (usable cores: {cores}, os.cpu_count() = {os.cpu_count()}) x {per} stereo "
+                     f"frames of the same kind of synthetic stream, {what}, {wall:.1f} s wall including process start-up",
+           "one_core": {"value": per * N_CH / dt1, "cores": 1,
+                        "sample": f"{per} stereo frames ({per * N_CH} cf), {dt1:.1f} s"}}
+    if not vq_kbps:
+        ex = np.load(os.path.join(ROOT, "tests", "golden", "excerpt_harpsichord.npz"))
+        pcm = ex["pcm"][:64 * 1024]
+        t0 = time.perf_counter()
+        po.encode_stream(pcm, int(ex["sr"]), KBPS, block_switching=False)
+        dtc = time.perf_counter() - t0
+        out["config1_excerpt"] = {"value": (len(pcm) // 1024 + 2) * pcm.shape[1] / dtc, "cores": 1,
+                                  "sample": "BASELINE configs[0]: 64-hop excerpt of harpsichord.wav (44.1 kHz "
+                                            f"stereo, tests/golden), long blocks, 128 kb/s, whole file loop, {dtc:.1f} s"}
+    return out
+
+
+# ------------------------------------------------------------------ verification
+def verify_against_oracle(pcm, sample_rate, kbps, vq_kbps, flags, payload_rows, n_bytes, picks, halo=None):
+    """The hops `picks` of the batch (2 channel-frames each) through the oracle; their .pac
+    payload bytes must equal what the timed run left in its slots.  pcm: the rank's int16
+    stream [n_hops*1024, nCh]; halo: int16 [1024, nCh], the hop before it (None = zeros, the
+    start of a file); flags: uint8 per frame or None; payload_rows: {cf: uint8 slot}.
+    Returns the number of channel-frames verified."""
+    from oracle import pac_oracle as po
+    if vq_kbps:
+        from oracle import pac_oracle_vq as pv
+        p = pv.make_params_vq(sample_rate, pcm.shape[1], vq_kbps)
+    else:
+        p = po.make_params(sample_rate, pcm.shape[1], kbps)
+    n_ch = pcm.shape[1]
+    ok = 0
+    for f in picks:
+        before = pcm[(f - 1) * 1024:f * 1024] if f else (halo if halo is not None else np.zeros((1024, n_ch), np.int16))
+        prior = [po.pcm16_to_fraction(before[:, ch]) for ch in range(n_ch)]
+        hop = [po.pcm16_to_fraction(pcm[f * 1024:(f + 1) * 1024, ch]) for ch in range(n_ch)]
+        fl = int(flags[f]) if flags is not None else 0
+        fl3 = (fl & 1, (fl >> 1) & 1, (fl >> 2) & 1)
+        if flags is not None:
+            # the detector's own decision for this hop (coder/detect_transients.py:5-23): next flag of frame f
+            look = np.concatenate((np.array(hop), np.zeros((n_ch, 1024))), axis=1)
+            assert int(bool(po.transient_detect(look))) == fl3[2], f"transient flag of hop {f}"
+        parts = (pv.encode_hop_vq if vq_kbps else po.encode_hop)(p, prior, hop, fl3)
+        for ch in range(n_ch):
+            i = f * n_ch + ch
+            n = int(n_bytes[i])
+            if parts is None:                      # hop the reference drops (all-zero sub-block)
+                assert n == 0, f"cf {i}: dropped hop has a payload"
+                continue
+            nb, want = (pv.pack_channel_block_vq if vq_kbps else po.pack_channel_block)(p, fl3, parts[ch])
+            assert n == nb, f"cf {i}: {n} payload bytes, oracle {nb}"
+            got = payload_rows[i][:n].tobytes()
+            assert got == want, f"cf {i}: payload bytes differ from the oracle's"
+            ok += 1
+    return ok
 
 
 def main():
@@ -62,8 +163,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="stereo frames per GPU and step")
+    ap.add_argument("--repeats", type=int, default=10, help="timed K-step regions; value = median")
+    ap.add_argument("--frames", type=int, default=None, help="stereo frames per GPU and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--mdct-launches", type=int, default=50)
     ap.add_argument("--graph", action="store_true",
                     help="replay a captured hipGraph of the step instead of launching its kernels one by one "
@@ -71,8 +174,13 @@ def main():
     ap.add_argument("--workload", choices=["scalar128", "vq128", "vq96", "bs128"], default="scalar128",
                     help="scalar128 = BASELINE configs[1] (the headline); vq128 / vq96 = the gain-shape "
                          "coder of configs[3] (vq96 with SBR) on the same synthetic stream; bs128 = "
-                         "configs[2]: block switching on, the castanet excerpt of tests/golden tiled to "
-                         "--frames hops (44.1 kHz), transient detector inside the step")
+                         "configs[2]: block switching on, the castanet stream (the whole file as the "
+                         "reference's driver reads it, tests/golden/full_castanet.npz) tiled to --frames "
+                         "hops (44.1 kHz), transient detector inside the step")
+    ap.add_argument("--corpus", action="store_true",
+                    help="BASELINE configs[4]: the tiled, level-scaled corpus sharded over the ranks "
+                         "(strong scaling); --corpus-frames stereo frames in all")
+    ap.add_argument("--corpus-frames", type=int, default=CORPUS_FRAMES)
     args = ap.parse_args()
 
     import torch
@@ -99,21 +207,33 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     # ---- workload: device-resident before any timing
-    n_frames = args.frames
     vq_kbps = {"scalar128": None, "vq128": 128, "vq96": 96, "bs128": None}[args.workload]
     kbps = vq_kbps or KBPS
     block_switched = args.workload == "bs128"
     sample_rate = SAMPLE_RATE
-    if block_switched:
-        ex = np.load(os.path.join(ROOT, "tests", "golden", "excerpt_castanet.npz"))
-        sample_rate = int(ex["sr"])
-        reps = -(-n_frames * 1024 // len(ex["pcm"]))
-        pcm = np.ascontiguousarray(np.tile(ex["pcm"], (reps, 1))[:n_frames * 1024])
+    corpus = args.corpus
+    if corpus:
+        assert not block_switched, "--corpus is the synthetic 48 kHz corpus"
+        # this rank's contiguous hop range of the corpus, with its one-hop halo (no exchange)
+        lo, hi = A.dist.shard_bounds(args.corpus_frames, world, rank)
+        n_frames = hi - lo
+        shard = A.synth.corpus_shard(lo, hi)                       # planar [nCh, (n_frames+1)*1024]
+        pcm = None
     else:
-        pcm = A.synth.stream(n_frames, N_CH, seed=A.synth.SEED + rank)
+        n_frames = args.frames or FRAMES_PER_GPU
+        if block_switched:
+            full = np.load(os.path.join(ROOT, "tests", "golden", "full_castanet.npz"))
+            sample_rate = int(full["sr"])
+            src = full["pcm"]
+            src = src[:len(src) // 1024 * 1024]
+            reps = -(-n_frames * 1024 // len(src))
+            pcm = np.ascontiguousarray(np.tile(src, (reps, 1))[:n_frames * 1024])
+        else:
+            pcm = A.synth.stream(n_frames, N_CH, seed=A.synth.SEED + rank)
+        shard = A.synth.planar_with_halo(pcm)
     enc = A.engine.Encoder(sample_rate, kbps / (sample_rate / 1000), use_vq=bool(vq_kbps),
                            use_sbr=bool(vq_kbps and vq_kbps < 128))
-    planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=dev)
+    planar = torch.as_tensor(shard, device=dev)
     view = A.engine.PcmView.stream(planar)
     hop_view = None
     if block_switched:      # the hops as the transient detector sees them (hop h = planar hop h+1)
@@ -124,20 +244,22 @@ def main():
     n_cf = view.n_cf
     enc.reserve(n_cf)
     out = enc.alloc_outputs(n_cf, with_payload=True)
+    if corpus:
+        out["mantissa"] = None                 # 1 GB per 131 072 frames nobody reads
     total = torch.zeros(1, dtype=torch.int64, device=dev)
     gather = None
+    slot = A.dist.slot_bytes(n_cf, kbps / (sample_rate / 1000))      # bound on one rank's body
     if world > 1:
         # fixed-slot asynchronous gather of the packed bodies to rank 0 (RCCL): two send
         # buffers alternate, the gather of step i overlaps the encode of step i+1, no host
         # synchronisation and no size exchange inside a step
         on_host = dist.get_backend() == "gloo"          # rehearsal only
-        gather = A.dist.BitstreamGather(A.dist.slot_bytes(n_cf, kbps / (sample_rate / 1000)),
-                                        torch.device("cpu") if on_host else dev)
+        gather = A.dist.BitstreamGather(slot, torch.device("cpu") if on_host else dev)
         bodies = [gather.body(0), gather.body(1)]
         if on_host:
             host_bodies, bodies = bodies, [torch.empty_like(b, device=dev) for b in bodies]
     else:
-        bodies = [torch.empty(n_cf * 512, dtype=torch.uint8, device=dev)]
+        bodies = [torch.empty(slot, dtype=torch.uint8, device=dev)]
     cap = int(bodies[0].numel())
     step_no = [0]
     import ctypes
@@ -146,6 +268,7 @@ def main():
     vq_out = None
     if vq_kbps:
         vq_out = {k: out[k] for k in ("overall", "bit_alloc", "status", "payload", "n_bytes")}
+    do_gather = [True]
 
     def device_step():
         k = step_no[0] % len(bodies)
@@ -160,7 +283,7 @@ def main():
             enc.encode_pack(view, None, out)
         enc._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(out["payload"]), _ptr(out["n_bytes"]),
                   _ptr(bodies[k]), ctypes.c_int64(cap), _ptr(total), enc._stream())
-        if gather is not None:
+        if gather is not None and do_gather[0]:
             if dist.get_backend() == "gloo":            # rehearsal: stage through the host
                 host_bodies[k].copy_(bodies[k])
                 gather.launch(k, total.cpu())
@@ -168,7 +291,7 @@ def main():
                 gather.launch(k, total)
         step_no[0] += 1
 
-    # optional: the ~15 kernel launches of a step captured once into a hipGraph and replayed
+    # optional: the kernel launches of a step captured once into a hipGraph and replayed
     graph = None
     if args.graph and world == 1:
         device_step()
@@ -198,25 +321,58 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_region():
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     for _ in range(args.warmup):
         step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    regions = [timed_region() for _ in range(max(1, args.repeats))]
+    dt = float(np.median(regions))
+    regions_nogather = None
+    if corpus and world > 1:                   # with and without the gather
+        do_gather[0] = False
+        regions_nogather = [timed_region() for _ in range(max(1, args.repeats))]
+        do_gather[0] = True
+
+    # ---- what was timed, checked (outside the timed regions)
+    torch.cuda.synchronize()
+    if gather is not None:
+        for k in range(len(bodies)):
+            gather.check(k)                    # every rank: its own body fitted its slot
+    body_bytes = int(total.item())
+    assert 0 < body_bytes <= cap, f"body of {body_bytes} bytes does not fit its {cap}-byte buffer"
+    n_bytes_h = out["n_bytes"].cpu().numpy()
+    assert body_bytes == int(n_bytes_h.astype(np.int64).sum()) + 4 * int(np.count_nonzero(n_bytes_h)), \
+        "body size is not the sum of its records"
+    verified = 0
+    if not args.no_verify and rank == 0:
+        picks = sorted(set(np.linspace(0, n_frames - 1, 16).astype(int).tolist()))
+        rows = {f * N_CH + ch: out["payload"][f * N_CH + ch].cpu().numpy() for f in picks for ch in range(N_CH)}
+        flags_h = fl_buf[:n_frames].cpu().numpy() if block_switched else None
+        stream_h = pcm if pcm is not None else np.ascontiguousarray(shard[:, 1024:].T)
+        halo_h = None if pcm is not None else np.ascontiguousarray(shard[:, :1024].T)
+        verified = verify_against_oracle(stream_h, sample_rate, kbps, vq_kbps, flags_h, rows, n_bytes_h, picks, halo_h)
 
     # ---- MDCT kernel alone: HIP events on the stream the kernel runs on
-    lines = torch.empty((n_cf, 1024), dtype=torch.float64, device=dev)
-    scale = torch.empty((n_cf,), dtype=torch.int32, device=dev)
+    mdct_cf = min(n_cf, 2 * FRAMES_PER_GPU) if corpus else n_cf
+    mview = view
+    if mdct_cf != n_cf:
+        mview = A.engine.PcmView.stream(planar[:, :(mdct_cf // N_CH + 1) * 1024].contiguous())
+    lines = torch.empty((mdct_cf, 1024), dtype=torch.float64, device=dev)
+    scale = torch.empty((mdct_cf,), dtype=torch.int32, device=dev)
 
     def mdct_once():
-        enc._call("pacx_mdct_batch", ctypes.byref(view.c), None, 0, _ptr(lines), _ptr(scale), enc._stream())
+        enc._call("pacx_mdct_batch", ctypes.byref(mview.c), None, 0, _ptr(lines), _ptr(scale), enc._stream())
     for _ in range(5):
         mdct_once()
     torch.cuda.synchronize()
@@ -232,60 +388,83 @@ def main():
             mdct_once()
         b.record()
     torch.cuda.synchronize()
-    mdct_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / train
-    mdct_gbs = n_cf * MDCT_BYTES_PER_CF / (mdct_ms * 1e-3) / 1e9
+    trains = [a.elapsed_time(b) / train for a, b in ev]
+    mdct_ms = float(np.median(trains))
+    mdct_gbs = mdct_cf * MDCT_BYTES_PER_CF / (mdct_ms * 1e-3) / 1e9
 
-    # HBM bytes of the MDCT kernel from the PMC passes of this same command
-    # (profiles/r01_mdct_pmc.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950
-    # correction applied); only quoted when the launch geometry matches
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_mdct_pmc.json")))
-        if pmc["cf_per_launch"] == n_cf:
-            traffic = pmc["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    # HBM bytes of the MDCT kernel: NOT measured by this run (PMC counters need rocprofv3);
+    # the figure of the committed PMC passes of this same command is quoted, with its
+    # source, when the launch geometry matches
+    traffic, traffic_src = None, None
+    for name in ("r02_mdct_pmc.json", "r01_mdct_pmc.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if pmc["cf_per_launch"] == mdct_cf:
+                traffic, traffic_src = pmc["hbm_bytes_per_launch"], f"profiles/{name}"
+                break
+        except Exception:
+            pass
 
     if rank == 0:
+        total_cf = world * n_cf if not corpus else N_CH * args.corpus_frames
+        what = ("scalar mantissas" if not vq_kbps else "gain-shape PVQ" + (" + SBR" if kbps < 128 else ""))
+        if corpus:
+            wl = (f"BASELINE configs[4]: corpus of {args.corpus_frames} synthetic 48 kHz stereo frames "
+                  f"({total_cf} channel-frames: the configs[1] stream tiled, tile t scaled by 0.5+0.5(t mod 16)/16), "
+                  f"{world} contiguous hop shards with a one-hop halo, {n_cf} channel-frames on rank 0, ")
+        elif block_switched:
+            wl = (f"{n_frames} stereo frames per GPU of castanet.wav as the reference's driver reads it, tiled "
+                  f"({n_cf} channel-frames, 44.1 kHz), long + short blocks by the transient detector (inside the step), ")
+        else:
+            wl = (f"{n_frames} synthetic 48 kHz stereo frames per GPU ({n_cf} channel-frames), N=1024 long blocks, ")
         res = {
             "metric": "audio channel-frames/s encode (48 kHz, 1024-line long blocks, 128 kb/s/ch)"
                       if not (vq_kbps or block_switched)
-                      else "audio channel-frames/s encode, block switching on (castanet excerpt tiled, 44.1 kHz, "
+                      else "audio channel-frames/s encode, block switching on (castanet.wav tiled, 44.1 kHz, "
                            "128 kb/s/ch)" if block_switched
                       else f"audio channel-frames/s encode, gain-shape PVQ{' + SBR' if vq_kbps < 128 else ''} "
                            f"(48 kHz, 1024-line long blocks, {vq_kbps} kb/s/ch)",
-            "value": world * n_cf * args.steps / dt,
+            "value": total_cf * args.steps / dt,
             "unit": "channel-frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if corpus else "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "castanet excerpt of tests/golden, tiled" if block_switched else "synthetic",
-            "config": {"workload": (f"{n_frames} stereo frames per GPU of the castanet excerpt tiled "
-                                    f"({n_cf} channel-frames, 44.1 kHz), long + short blocks by the transient "
-                                    "detector (inside the step), " if block_switched else
-                                    f"{n_frames} synthetic 48 kHz stereo frames per GPU ({n_cf} channel-frames), "
-                                    "N=1024 long blocks, ") + f"{kbps} kb/s/ch, "
-                                   f"{'gain-shape PVQ' + (' + SBR' if kbps < 128 else '') if vq_kbps else 'scalar mantissas'}, "
-                                   "int16 PCM resident in HBM; step = encode + "
-                                   ".pac bit packing + body assembly" +
+            "data": "castanet.wav PCM of tests/golden, tiled" if block_switched else "synthetic",
+            "verified_cf": verified,
+            "config": {"workload": wl + f"{kbps} kb/s/ch, {what}, int16 PCM resident in HBM; step = encode + "
+                                        ".pac bit packing + body assembly" +
                                    (" + asynchronous RCCL gather of the bodies to rank 0" if world > 1 else ""),
-                       "stereo_frames_per_s": world * n_frames * args.steps / dt,
+                       "stereo_frames_per_s": total_cf / N_CH * args.steps / dt,
+                       "timing": f"median of {len(regions)} regions of {args.steps} steps",
+                       "value_min": total_cf * args.steps / max(regions),
+                       "value_max": total_cf * args.steps / min(regions),
+                       "ms_per_step_regions": [r / args.steps * 1e3 for r in regions],
+                       "body_bytes_per_step": body_bytes,
+                       "verified": f"{verified} channel-frames of the timed run's output re-encoded by the oracle, "
+                                   "payload bytes equal" if verified else "not verified",
                        "launch": "hipGraph replay of the captured step" if graph is not None else "direct launches",
                        "sharding": f"{world} x frame-range shards, no data-path collective"},
             "roofline": {"kernel": "k_mdct_long_x2p (window + MDCT, int16 in, float64 lines out; two frames per wave alternating on one FFT tile, PCM prefetched a whole iteration ahead)",
                          "bound": "hbm", "achieved": mdct_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": mdct_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
-                                         "profiles/r01_mdct_pmc.json",
-                         "algorithmic_bytes_per_launch": n_cf * MDCT_BYTES_PER_CF,
-                         "launch_ms": mdct_ms, "bytes_per_cf": MDCT_BYTES_PER_CF, "cf_per_launch": n_cf,
-                         "mdct_cf_per_s": n_cf / (mdct_ms * 1e-3)},
+                         "traffic_note": ("HBM bytes per launch from the COMMITTED rocprofv3 PMC passes of this "
+                                          f"command (2*FETCH_SIZE + WRITE_SIZE), {traffic_src}; not measured by this run")
+                                         if traffic else "no committed PMC profile for this launch geometry",
+                         "algorithmic_bytes_per_launch": mdct_cf * MDCT_BYTES_PER_CF,
+                         "launch_ms": mdct_ms, "launch_ms_min": float(min(trains)), "launch_ms_max": float(max(trains)),
+                         "timing": f"median of {len(trains)} HIP-event trains of {train} back-to-back launches",
+                         "bytes_per_cf": MDCT_BYTES_PER_CF, "cf_per_launch": mdct_cf,
+                         "mdct_cf_per_s": mdct_cf / (mdct_ms * 1e-3)},
         }
+        if regions_nogather is not None:
+            d2 = float(np.median(regions_nogather))
+            res["config"]["value_without_gather"] = total_cf * args.steps / d2
+            res["config"]["ms_per_step_without_gather"] = d2 / args.steps * 1e3
         if not args.no_cpu_baseline and world == 1:
             if block_switched:
                 from oracle import pac_oracle as po
@@ -298,7 +477,7 @@ def main():
                                        "sample": f"first {n_hops_cpu} hops of the same tiled stream through "
                                                  f"oracle/pac_oracle.py encode_stream (block switching on), {dtc:.1f} s"}
             else:
-                res["cpu_baseline"] = cpu_baseline(256, vq_kbps) if vq_kbps else cpu_baseline()
+                res["cpu_baseline"] = cpu_baseline(vq_kbps)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -104,14 +104,18 @@ def test_builtin_tables_equal_uploaded_ones(A, torch):
             pcm = A.synth.stream(16, 2, sample_rate=sr)
             planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=enc.device)
             view = A.engine.PcmView.stream(planar)
-            want = enc.encode_pack(view)
+            want = {k: (v.clone() if v is not None else None) for k, v in enc.encode_pack(view).items()}
             bare = A.engine.Encoder.__new__(A.engine.Encoder)      # same calls on the bare handle
             bare.__dict__.update(enc.__dict__)
             bare.h = h
             got = bare.encode_pack(view)
             bare.h = None
-            for k in ("overall", "scale_factor", "bit_alloc", "n_bytes", "payload"):
+            for k in ("overall", "scale_factor", "bit_alloc", "n_bytes"):
                 assert torch.equal(got[k], want[k]), (sr, k)
+            nb = want["n_bytes"].cpu().numpy()
+            pg, pw = got["payload"].cpu().numpy(), want["payload"].cpu().numpy()
+            for i in range(len(nb)):                   # a slot is only defined up to its n_bytes
+                assert pg[i, :nb[i]].tobytes() == pw[i, :nb[i]].tobytes(), (sr, i)
         finally:
             lib.pacx_destroy(h)
     # a rate without built-in Bark/threshold tables says so

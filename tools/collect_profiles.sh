@@ -6,7 +6,7 @@
 # in-kernel phase stamps (needs libpacx_dbg.so from `build.py --phase-debug`) and the
 # traffic-mix ceiling probe.
 set -e
-TAG=${1:-v10}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,13 +14,13 @@ cd /tmp && export TMPDIR=/tmp
 for w in scalar128 vq128 vq96 bs128; do
   python3 $R/bench.py --workload $w > $OUT/bench_$w.log 2>&1
   tail -1 $OUT/bench_$w.log > $OUT/bench_$w.json
-  rocprofv3 --kernel-trace --stats -d $OUT/stats_$w -o s --output-format csv -- python3 $R/bench.py --workload $w --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/stats_$w -o s --output-format csv -- python3 $R/bench.py --workload $w --no-cpu-baseline --no-verify > /dev/null 2>&1
   cp $OUT/stats_$w/s_kernel_stats.csv $OUT/${w}_kernel_stats.csv
   echo "done $w"
 done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/mdct_pmc.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
+python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/mdct_pmc.json $OUT/step_traffic.json
 cp $(ls $OUT/pmc_fetch/*/*counter_collection.csv | head -1) $OUT/pmc_fetch_size.csv
 cp $(ls $OUT/pmc_write/*/*counter_collection.csv | head -1) $OUT/pmc_write_size.csv
 echo "done pmc traffic"
