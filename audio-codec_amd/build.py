@@ -185,6 +185,23 @@ def resources():
         return json.load(f)
 
 
+def device_asm(source):
+    """gfx950 assembly text of one csrc/*.hip (device side only, the library's flags), cached
+    under build/ by content hash: what tests/test_build_isa.py checks the hand-counted
+    s_waitcnt / LDS-DMA orderings on."""
+    os.makedirs(OBJ, exist_ok=True)
+    want = source_hashes()[source]
+    out = os.path.join(OBJ, source.replace(".hip", ".s"))
+    if not os.path.exists(out) or _read(out + ".hash") != want:
+        flags = [f for f in FLAGS if not f.startswith("-Rpass")]
+        subprocess.check_call([_hipcc()] + flags + ["--offload-device-only", "-S", os.path.join(CSRC, source), "-o", out],
+                              stderr=subprocess.DEVNULL)
+        with open(out + ".hash", "w") as f:
+            f.write(want)
+    with open(out) as f:
+        return f.read()
+
+
 def build_phase_debug():
     """libpacx_dbg.so: the same library with k_mdct3.hip and k_psy.hip compiled with
     -DPACX_MDCT_DEBUG / -DPACX_PSY_DEBUG / -DPACX_TAIL_DEBUG (in-kernel s_memtime stamps per phase, read by

@@ -32,7 +32,8 @@ template <bool ANYWIN>
 __global__ __launch_bounds__(64 * MDCT2_WAVES, 2) void k_mdct_long_v2(
     PacxTables T, PacxPcmView in, const uint8_t *__restrict__ flags, long long n_cf, int skip_cur,
     double *__restrict__ lines, int32_t *__restrict__ scale_out, int scale_stride,
-    uint32_t *__restrict__ status_init)
+    uint32_t *__restrict__ status_init, const int32_t *__restrict__ cf_list,
+    const int32_t *__restrict__ cf_count)
 {
     __shared__ __attribute__((aligned(16))) cplx tiles[MDCT2_WAVES][WFFT_TILE_N];
     __shared__ __attribute__((aligned(16))) cplx twl[512];
@@ -50,7 +51,11 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 2) void k_mdct_long_v2(
     short *raw = (short *)tile;            /* the raw int16 samples are staged in the FFT tile */
     const unsigned n_ch = (unsigned)in.n_ch;
     const unsigned stride = gridDim.x * MDCT2_WAVES;
-    const unsigned total = (unsigned)n_cf;
+    /* mixed streams: walk the compacted list of the long-coded frames (k_frame_lists) instead
+       of every frame -- on a castanet stream half of the frames are short-coded, and staging
+       their PCM only to skip them was half of this kernel's time */
+    const unsigned total = cf_list ? (unsigned)*cf_count : (unsigned)n_cf;
+    auto frame_of = [&](unsigned i) -> unsigned { return cf_list ? (unsigned)cf_list[i] : i; };
     const short *base = (const short *)in.base;
     /* PCM goes HBM -> LDS without touching VGPRs (global_load_lds_dwordx4:
        wave-uniform LDS base + lane*16, per-lane global address) */
@@ -67,9 +72,10 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 2) void k_mdct_long_v2(
        run of frames, so the hop two consecutive frames share stays in one XCD's L2
        (k_mdct3.hip, k_mdct_long_x2p) */
     const unsigned vb = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    unsigned cf = vb * MDCT2_WAVES + wv;
-    if (cf < total)
-        stage(cf);                    /* first frame's PCM flies while the tables load */
+    unsigned it = vb * MDCT2_WAVES + wv;              /* position in the list (or the frame itself) */
+    unsigned cf_next = it < total ? frame_of(it) : 0u;
+    if (it < total)
+        stage(cf_next);               /* first frame's PCM flies while the tables load */
     for (int i = tid; i < 512; i += 64 * MDCT2_WAVES)
         twl[i] = T.tw_long[i];
     /* window table with the PCM scale 2/65535 (coder/pcmfile.py:89-99 mapping)
@@ -92,7 +98,10 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 2) void k_mdct_long_v2(
 
     const cplx *w1 = &w1s[0][lane];                                /* w1[64 (k1-1)] */
     const cplx *w2 = &w64[0][lane & 7];                            /* w2[8 (k2-1)] */
-    for (; cf < total; cf += stride) {
+    for (; it < total; it += stride) {
+        const unsigned cf = cf_next;
+        if (it + stride < total)
+            cf_next = frame_of(it + stride);          /* read one iteration ahead of its DMA */
         const unsigned fl = flags ? flags[cf / n_ch] : 0u;
         /* frames this kernel leaves to k_mdct_short: short-coded (CUR) ones when asked to */
         const bool mine = !(skip_cur && (fl & 2u));
@@ -118,8 +127,8 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 2) void k_mdct_long_v2(
             /* a short-coded frame (k_mdct_short's): nothing to transform, only the chain of
                PCM fetches to keep going -- on a castanet stream that is more than half of
                the frames */
-            if (cf + stride < total)
-                stage(cf + stride);
+            if (it + stride < total)
+                stage(cf_next);
             continue;
         }
         const int Q = PACX_N_LONG / 4, M = PACX_M_LONG;
@@ -187,8 +196,8 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 2) void k_mdct_long_v2(
            (a wavefront-scope fence does not wait for them; hazard table in DESIGN.md,
            checked on the compiled code by tests/test_build_isa.py). */
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (cf + stride < total)
-            stage(cf + stride);
+        if (it + stride < total)
+            stage(cf_next);
 
         double a[8], b[8];
         double mx = 0.0;
@@ -228,7 +237,8 @@ void pacx_launch_mdct_x2(const PacxTables &T, const PacxPcmView &in, long long n
 
 void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8_t *flags, long long n_cf,
                          int skip_cur, double *lines, int32_t *scale_out, int scale_stride,
-                         uint32_t *status_init, int n_cu, hipStream_t st)
+                         uint32_t *status_init, int n_cu, const int32_t *cf_list, const int32_t *cf_count,
+                         hipStream_t st)
 {
     if (n_cf <= 0)
         return;
@@ -255,8 +265,8 @@ void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8
         blocks = n_cu;                         /* one persistent workgroup per CU */
     if (flags)
         hipLaunchKernelGGL((k_mdct_long_v2<true>), dim3((unsigned)blocks), dim3(64 * MDCT2_WAVES), 0, st, T, in,
-                           flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init);
+                           flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init, cf_list, cf_count);
     else
         hipLaunchKernelGGL((k_mdct_long_v2<false>), dim3((unsigned)blocks), dim3(64 * MDCT2_WAVES), 0, st, T, in,
-                           flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init);
+                           flags, n_cf, skip_cur, lines, scale_out, scale_stride, status_init, cf_list, cf_count);
 }

@@ -248,6 +248,11 @@ extern "C" int pacx_debug_read(long long *out, int n)
 #else
 #define DBG_T(k) do { } while (0)
 #endif
+/* 16-byte line stores per epilogue (1024 lines = 64 lanes x 8 stores x 2 doubles).  The counted
+   wait of k_mdct_long_x2p is derived from it; tests/test_build_isa.py reads this constant and
+   checks the compiled code against it. */
+constexpr int EPI_STORES = 8;
+
 template <int WAVES, int MINW>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T, PacxPcmView in, long long n_cf,
                                                                    double *__restrict__ lines,
@@ -360,8 +365,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
                     lo += 1 << bit;
         }
         double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);
+        static_assert(EPI_STORES * 64 * 2 == PACX_M_LONG, "one epilogue = EPI_STORES 16-byte stores per lane");
 #pragma unroll
-        for (int k3 = 0; k3 < 8; ++k3)
+        for (int k3 = 0; k3 < EPI_STORES; ++k3)
             out[lane + 64 * k3] = make_double2(a[k3], odd[k3]);
         if (scale_out && lane == 0)
             scale_out[(long long)cf * scale_stride] = lo;
@@ -382,8 +388,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
         if (first)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   /* the line stores; the 2 scale stores, when
-                                                                    there are any, only make the wait stricter */
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * EPI_STORES) : "memory");   /* the two epilogues' line
+                                       stores; the 2 scale stores, when there are any, only make the wait stricter */
         first = false;
         DBG_T(0);
         wave_lds_fence();

@@ -28,6 +28,7 @@
 #include "wave_fft.h"
 #include "pcm_stage.h"
 #include "wave_np_sum.h"
+#include "quant_dev.h"
 
 
 /* Hann-windowed sample i of the staged block.  int16 input: the code enters as an
@@ -611,7 +612,17 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 #endif
 
 
-template <int M>
+/* TAIL (long blocks): what follows the SMRs in the reference's per-frame loop runs in the same
+ * wave, on the frame it has just finished -- BitAlloc (coder/codec.py:288-299, 321-328;
+ * coder/bitalloc.py:62-121) on the first half wave (lanes = bands), then, for the scalar coder,
+ * per-band scale factors + mantissas (coder/codec.py:362-377) and the .pac payload
+ * (coder/pacfile.py:404-447) -- instead of in k_tail_long behind a kernel boundary: the SMRs
+ * never go to HBM, the lines are read a second time while they are still in L2, and the 8 KB
+ * of per-line state the wave owns in LDS (dead once the band maxima are taken) hold the bit
+ * buffer and the band tables.  Gain-shape handles stop after BitAlloc (k_vq takes the
+ * allocation from HBM). */
+
+template <int M, bool TAIL>
 __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T, const uint8_t *__restrict__ flags,
                                                          int n_ch, long long n_units, int mixed,
                                                          const PacxPeak *__restrict__ peaks,
@@ -620,9 +631,11 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                                                          double *__restrict__ smr,
                                                          double *__restrict__ thr_out,
                                                          const int32_t *__restrict__ cf_list,
-                                                         const int32_t *__restrict__ cf_count)
+                                                         const int32_t *__restrict__ cf_count,
+                                                         MaskTail tail)
 {
     constexpr bool SHORT = (M == PACX_M_SHORT);
+    static_assert(!(TAIL && SHORT), "the fused tail is for long blocks");
     constexpr int PER = M / 64;
     constexpr bool BARK_LDS = (MASK_LDS_TABLES & 1) != 0, QUIET_LDS = (MASK_LDS_TABLES & 2) != 0;
     __shared__ __attribute__((aligned(16))) double bark_l[BARK_LDS ? M : 1];
@@ -833,9 +846,9 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
         }
         wave_lds_fence();
         PSY_T(2);
-        double *__restrict__ out = smr + cf * T.band_stride + sb * T.nb_short;
+        double *__restrict__ out = smr ? smr + cf * T.band_stride + sb * T.nb_short : nullptr;
         constexpr int NBR = SHORT ? 8 : 32;               /* bands handled by the reduction */
-        if (nb <= NBR) {
+        if (TAIL || nb <= NBR) {
             /* all band maxima in one transposing reduction (wave_fft.h wave_max_n): six
                LDS round trips for the lot instead of six per band */
             double m[NBR];
@@ -849,8 +862,119 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
             }
             wave_max_n<NBR>(m, lane);
             constexpr int PER_BAND = 64 / NBR;            /* lanes that end up with one band's maximum */
-            if (!(lane & (PER_BAND - 1)) && lane / PER_BAND < nb)
+            if (out && !(lane & (PER_BAND - 1)) && lane / PER_BAND < nb)
                 out[lane / PER_BAND] = m[0];
+            if constexpr (TAIL) {
+                wave_lds_fence();                         /* the band maxima are taken: buf is free */
+                /* the lane number of the tail is opaque per frame: everything the tail derives from
+                   it (band ids of the lane's 16 lines, table entries of "its" band) would otherwise
+                   be hoisted out of the frame loop and live in ~40 registers across the mask phase */
+                int tl = lane;
+                asm volatile("" : "+v"(tl));
+                /* the wave's 8 KB of per-line state now hold the tail's LDS (3.4 KB) */
+                char *base = (char *)buf;
+                unsigned *words = (unsigned *)base;                               /* 548 words       */
+                double *cp = (double *)(base + 2192);                             /* 2 x 32 doubles  */
+                unsigned long long *bmax = (unsigned long long *)(base + 2704);   /* 32              */
+                int *ba_s = (int *)(base + 2960), *sf_s = ba_s + PACX_MAX_BANDS;
+                int *offs = sf_s + PACX_MAX_BANDS, *lower_s = offs + PACX_MAX_BANDS + 1;
+                const int half = tl >> 5, l = tl & 31;
+                const unsigned fl = flags ? flags[cf / n_ch] : 0u;
+                const long long boff = cf * T.band_stride;
+                /* 1. BitAlloc: band l's SMR sits in lanes 2l, 2l+1 */
+                const double s_l = __shfl(m[0], (2 * l) & 63, 64);
+                const int32_t *__restrict__ n_lines = T.use_sbr ? T.band_lines_long_alloc : T.band_lines_long;
+                const double budget = pacx_bit_budget(T.target_bps, PACX_M_LONG, 0, (fl & 5u) != 0, T.n_scale_bits,
+                                                      T.n_mant_size_bits, nb, T.use_vq, T.use_sbr);
+                int max_mant = 1 << T.n_mant_size_bits;
+                if (max_mant > 16)
+                    max_mant = 16;
+                const bool has = half == 0 && l < nb;
+                const int nl = has ? n_lines[l] : 0;
+                int bits = 0, cap = 0;
+                bitalloc_half(half == 0, has, has ? s_l : 0.0, nl, budget, max_mant, cp + 32 * half, half, l, bits, cap);
+                if (has) {
+                    tail.bit_alloc[boff + l] = bits;
+                    ba_s[l] = bits;
+                }
+                if (tl == nb && nb < PACX_MAX_BANDS)
+                    ba_s[nb] = 0;                         /* dummy band of the lines no band covers */
+                if (cap && tail.status && tl == 0)
+                    atomicOr(&tail.status[cf], 4u);
+                PSY_T(4);
+                if (!T.use_vq) {
+                    /* 2. the payload's layout follows from the allocation alone: band header
+                       offsets (exclusive prefix over the bands), first mantissa bit of each band */
+                    const int ov = tail.overall[cf * PACX_SUB];
+                    const int k0 = 16 * tl;
+                    int my_off = 0, a_mine = 0, end = 0;
+                    if (tail.payload) {
+                        for (int i = tl; i < PACX_PACK_WORDS; i += 64)
+                            words[i] = 0u;
+                        wave_lds_fence();
+                        a_mine = (tl < nb) ? ba_s[tl] : 0;
+                        const int width = (tl < nb) ? T.n_mant_size_bits + T.n_scale_bits + a_mine * count[tl] : 0;
+                        int incl = width;
+#pragma unroll
+                        for (int off = 1; off < 32; off <<= 1) {
+                            const int t = __shfl_up(incl, off, 64);
+                            if (tl >= off)
+                                incl += t;
+                        }
+                        my_off = 3 + T.n_scale_bits + incl - width;
+                        end = __shfl(incl, nb - 1, 64) + 3 + T.n_scale_bits;
+                        if (tl < nb) {
+                            offs[tl] = my_off + T.n_mant_size_bits + T.n_scale_bits;
+                            lower_s[tl] = lower[tl];
+                        }
+                        if (tl == 0) {
+                            put_bits(words, 0, fl & 1u, 1);
+                            put_bits(words, 1, (fl >> 1) & 1u, 1);
+                            put_bits(words, 2, (fl >> 2) & 1u, 1);
+                            put_bits(words, 3, (unsigned)ov, T.n_scale_bits);
+                        }
+                    }
+                    /* 3. scale factors (lines: second read, still in L2) */
+                    double x[16];
+                    uint8_t band[16];
+                    long_scale_factors(T, lines + loff, (double)(1 << ov), bmax, ba_s, sf_s, tl, x, band);
+                    if (tl < nb) {
+                        tail.scale_factor[boff + tl] = sf_s[tl];
+                        if (tail.payload) {
+                            put_bits(words, my_off, (unsigned)(a_mine ? a_mine - 1 : 0), T.n_mant_size_bits);
+                            put_bits(words, my_off + T.n_mant_size_bits, (unsigned)sf_s[tl], T.n_scale_bits);
+                        }
+                    }
+                    PSY_T(5);
+                    /* 4. mantissas, written into the bit buffer (and to HBM when asked for) as they
+                       are made: four at a time, never all sixteen live */
+#pragma unroll
+                    for (int j4 = 0; j4 < 16; j4 += 4) {
+                        int mq[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int j = j4 + u;
+                            const int b = band[j];
+                            const int a = ba_s[b];
+                            mq[u] = a ? pacx_mantissa(x[j], sf_s[b], T.n_scale_bits, a) : 0;
+                            if (tail.payload && a)
+                                put_bits(words, offs[b] + (k0 + j - lower_s[b]) * a, (unsigned)mq[u], a);
+                        }
+                        if (tail.mantissa)
+                            *(int4 *)(tail.mantissa + loff + k0 + j4) = make_int4(mq[0], mq[1], mq[2], mq[3]);
+                    }
+                    if (tail.payload) {
+                        wave_lds_fence();
+                        const int nbytes = ((end - 3) + 4 + 7) >> 3;
+                        unsigned *dst = (unsigned *)(tail.payload + cf * (long long)tail.payload_stride);
+                        for (int i = tl; i < (nbytes + 3) / 4; i += 64)
+                            dst[i] = __builtin_bswap32(words[i]);
+                        if (tl == 0)
+                            tail.n_bytes[cf] = nbytes;
+                    }
+                    PSY_T(6);
+                }
+            }
         } else {
             for (int b = 0; b < nb; ++b) {
                 const int lo = lower[b], hi = lo + count[b];
@@ -918,7 +1042,7 @@ void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long 
                       int short_blocks, int mixed, const PacxPeak *peaks, const int32_t *n_peaks,
                       const double *lines, double *smr, double *thr_out, int n_cu,
                       const int32_t *list_long, const int32_t *list_short, const int32_t *counts,
-                      hipStream_t st)
+                      const MaskTail *tail, hipStream_t st)
 {
     if (n_cf <= 0)
         return;
@@ -928,17 +1052,22 @@ void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long 
         long long blocks = (n_cf + MASK_WAVES - 1) / MASK_WAVES;
         if (blocks > (long long)MASK_WG_PER_CU * n_cu)
             blocks = (long long)MASK_WG_PER_CU * n_cu;
-        hipLaunchKernelGGL((k_mask<PACX_M_LONG>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T, flags,
-                           n_ch, n_cf, mixed, peaks, n_peaks, lines, smr, thr_out, mixed ? list_long : nullptr,
-                           counts);
+        if (tail)           /* BitAlloc (+ quantisation and packing) of the long frames in the same wave */
+            hipLaunchKernelGGL((k_mask<PACX_M_LONG, true>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T,
+                               flags, n_ch, n_cf, mixed, peaks, n_peaks, lines, (double *)nullptr, thr_out,
+                               mixed ? list_long : nullptr, counts, *tail);
+        else
+            hipLaunchKernelGGL((k_mask<PACX_M_LONG, false>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T,
+                               flags, n_ch, n_cf, mixed, peaks, n_peaks, lines, smr, thr_out,
+                               mixed ? list_long : nullptr, counts, MaskTail{});
     }
     if (short_blocks || mixed) {
         const long long units = n_cf * PACX_SUB;
         long long blocks = (units + MASK_WAVES - 1) / MASK_WAVES;
         if (blocks > (32LL / MASK_WAVES) * n_cu)
             blocks = (32LL / MASK_WAVES) * n_cu;
-        hipLaunchKernelGGL((k_mask<PACX_M_SHORT>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T, flags,
-                           n_ch, units, mixed, peaks, n_peaks, lines, smr, thr_out, mixed ? list_short : nullptr,
-                           counts ? counts + 1 : nullptr);
+        hipLaunchKernelGGL((k_mask<PACX_M_SHORT, false>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T,
+                           flags, n_ch, units, mixed, peaks, n_peaks, lines, smr, thr_out,
+                           mixed ? list_short : nullptr, counts ? counts + 1 : nullptr, MaskTail{});
     }
 }

@@ -16,174 +16,7 @@
  */
 #include "pacx_dev.h"
 #include "wave_fft.h"   /* wave_max */
-
-/* ---------------------------------------------------------------- bitalloc */
-/* BitAlloc, cooperatively: lanes = bands, one (sub-)block per 32-lane half wave
- * (two per wave).  Same arithmetic, in the same order, as pacx_bit_alloc() in
- * pacx_exact.h (the serial statement of coder/bitalloc.py:77-121, checked on the
- * CPU against the oracle); tests compare the two on the GPU bit for bit.
- *   - np.sum(nLines[valid]*SMR[valid]): valid bands are compacted (prefix
- *     popcount of the ballot mask) into LDS and added in NumPy's pairwise order
- *     (8 running sums, fixed tree, scalar tail);
- *   - the rounding "ladder": the n_flip-th smallest positive fraction is found
- *     by an all-pairs rank count over the half wave instead of a sort;
- *   - np.round -> rint (half to even); the 200-pass guard is kept.
- */
-__device__ __forceinline__ int half_sum_i(int v)
-{
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1)
-        v += __shfl_xor(v, off, 32);
-    return v;
-}
-
-/* BitAlloc of one (sub-)block on one 32-lane half wave (lane l = band l).  Both
- * halves of the wave must call this together (a half without work passes
- * alive = false). */
-__device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, int nl, double budget,
-                                              int max_mant, double *c, int half, int l, int &bits_out,
-                                              int &cap_out)
-{
-    const unsigned lt_mask = (1u << l) - 1u;
-
-    int bits = 0, n_flip = 0, passes = 0, cap = 0;
-    unsigned dropped = 0;
-    bool done = !alive;
-    /* The reference's loop can oscillate for ever and then leaves through its
-       200-pass guard (coder/bitalloc.py:116-119; ~0.5 % of short blocks).  The
-       loop is a deterministic map of (bits, dropped, n_flip), so once a state
-       repeats with period L the state after the 201st pass is known: Brent's
-       cycle detection (snapshot at passes 1, 2, 4, ...) finds L, the loop then
-       runs only (201 - passes) mod L more passes.  Same result, ~10 passes. */
-    int snap_bits = -1, snap_flip = -1, snap_pass = 0, snap_next = 1, stop_at = -1;
-    unsigned snap_dropped = 0xFFFFFFFFu;
-    /* Everything up to the rounding ladder depends on the set of dropped bands only;
-       while the loop merely raises n_flip on a stable set it is reused, and the
-       all-pairs rank count behind ladder[n_flip-1] is made once per set. */
-    unsigned cache_key = 0xFFFFFFFEu;            /* never a value of `dropped` (bit 0 clear, rest set) */
-    bool valid = false, posf = false, have_rank = false;
-    unsigned pmask = 0;
-    int nd = 0, lt = 0, le = 0;
-    double want = 0.0, frac = 0.0;
-    while (__builtin_amdgcn_ballot_w64(!done)) {
-        if (__builtin_amdgcn_ballot_w64(dropped != cache_key)) {    /* wave-uniform: both halves recompute together */
-            cache_key = dropped;
-            have_rank = false;
-            valid = has && !((dropped >> l) & 1u);
-            const unsigned vmask = (unsigned)(__builtin_amdgcn_ballot_w64(valid) >> (32 * half));
-            const int nv = __popc(vmask);
-            const int pos = __popc(vmask & lt_mask);
-            const int total_i = half_sum_i(valid ? nl : 0);
-            double total = (double)total_i;
-            if (total_i == 0)
-                total = total + 1e-12;
-            if (valid)
-                c[pos] = (double)nl * s;
-            wave_lds_fence();
-            /* np.sum of c[0..nv) */
-            double sum;
-            if (nv < 8) {
-                sum = -0.0;
-                for (int i = 0; i < nv; ++i)
-                    sum = sum + c[i];
-            } else {
-                const int n8 = nv - (nv & 7);
-                double r = 0.0;
-                if (l < 8) {
-                    r = c[l];
-                    for (int i = 8; i < n8; i += 8)
-                        r = r + c[i + l];
-                }
-                double t = r + __shfl_down(r, 1, 32);           /* lanes 0,2,4,6: r0+r1, r2+r3, ... */
-                double u = t + __shfl_down(t, 2, 32);           /* lanes 0,4 */
-                sum = u + __shfl_down(u, 4, 32);                /* lane 0 */
-                for (int i = n8; i < nv; ++i)
-                    sum = sum + c[i];
-                sum = __shfl(sum, 0, 32);
-            }
-            wave_lds_fence();
-            const double mean = sum / total;
-            want = budget / total + (1.0 / PACX_DB_PER_BIT) * (s - mean);
-            frac = (want - floor(want)) - 0.5;
-            posf = valid && frac > 0.0;
-            pmask = (unsigned)(__builtin_amdgcn_ballot_w64(posf) >> (32 * half));
-            nd = __popc(pmask);
-        }
-        int new_bits = bits;
-        int new_flip = n_flip;
-        if (__builtin_amdgcn_ballot_w64(!have_rank && n_flip > 0 && n_flip <= nd)) {   /* ladder ranks of this set */
-            have_rank = true;
-            lt = 0;
-            le = 0;
-            for (int k = 0; k < 32; ++k) {
-                const double fk = __shfl(frac, k, 32);
-                if ((pmask >> k) & 1u) {
-                    lt += fk < frac;
-                    le += fk <= frac;
-                }
-            }
-        }
-        if (n_flip > nd) {
-            new_flip = n_flip - 1;                           /* bits keep their previous values */
-        } else {
-            double level = 0.0;
-            const bool sel = n_flip > 0 && posf && lt <= n_flip - 1 && n_flip - 1 < le;
-            const unsigned smask = (unsigned)(__builtin_amdgcn_ballot_w64(sel) >> (32 * half));
-            const double pick = __shfl(frac, smask ? __builtin_ctz(smask) : 0, 32);
-            if (n_flip > 0)
-                level = pick;                                /* ladder[n_flip-1] */
-            if (valid)
-                new_bits = (int)rint(want - level);
-        }
-        if (new_bits > max_mant)
-            new_bits = max_mant;
-        const bool drop = has && new_bits < 2;
-        if (drop || !has)
-            new_bits = 0;
-        const unsigned now = (unsigned)(__builtin_amdgcn_ballot_w64(drop) >> (32 * half));
-        const int spent = half_sum_i(new_bits * nl);
-        if (!done) {
-            const bool stable = (now == dropped);
-            bits = new_bits;
-            dropped = now;
-            n_flip = new_flip;
-            if (stable && (double)spent <= budget) {
-                done = true;
-            } else {
-                if (stable && (double)spent > budget)
-                    n_flip += 1;
-                ++passes;
-                if (passes > PACX_ALLOC_MAX_PASSES || passes == stop_at) {
-                    cap = 1;
-                    done = true;
-                }
-            }
-        }
-        /* cycle detection on the state after this pass (per half wave) */
-        {
-            const bool same_lane = (bits == snap_bits);
-            const unsigned eq = (unsigned)(__builtin_amdgcn_ballot_w64(same_lane || !has) >> (32 * half));
-            const bool same = (eq == 0xFFFFFFFFu) && dropped == snap_dropped && n_flip == snap_flip;
-            if (!done && stop_at < 0 && same) {
-                const int period = passes - snap_pass;
-                stop_at = passes + ((PACX_ALLOC_MAX_PASSES + 1 - passes) % period);
-                if (stop_at == passes) {            /* already at the state the guard would leave in */
-                    cap = 1;
-                    done = true;
-                }
-            }
-            if (passes == snap_next) {
-                snap_bits = bits;
-                snap_dropped = dropped;
-                snap_flip = n_flip;
-                snap_pass = passes;
-                snap_next *= 2;
-            }
-        }
-    }
-    bits_out = bits;
-    cap_out = cap;
-}
+#include "quant_dev.h"
 
 __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
                                                 long long n_cf, int short_blocks, int mixed, int skip_long,
@@ -223,98 +56,6 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
         bit_alloc[off + l] = bits;
     if (alive && cap && status && l == 0)
         atomicOr(&status[cf], 4u);
-}
-
-/* ---------------------------------------------------------------- quantize */
-/* One wave per (sub-)block.  Each lane owns M/64 CONSECUTIVE lines (coalesced
- * 16-byte loads and stores); band maxima go through LDS atomic max on the bit
- * pattern of |x| (non-negative doubles order like integers), so no per-band
- * loop and no dependent global loads; lanes < nBands then turn the maxima into
- * scale factors in parallel. */
-/* Long block: scale factors and mantissas of the 16 consecutive lines each lane
- * owns.  ba_s[nb] must be filled (and visible) by the caller; on return sf_s[nb]
- * holds the scale factors, x / band / mant this lane's lines. */
-__device__ __forceinline__ void quantize_long_core(const PacxTables &T, const double *__restrict__ lin,
-                                                   double up, unsigned long long *bmax, const int *ba_s,
-                                                   int *sf_s, int lane, double (&x)[16], uint8_t (&band)[16],
-                                                   int32_t (&mant)[16])
-{
-    constexpr int PER = 16;
-    const int nb = T.nb_long;
-    const int k0 = PER * lane;
-    if (lane < PACX_MAX_BANDS)
-        bmax[lane] = 0ull;
-#pragma unroll
-    for (int j = 0; j < PER; j += 2) {
-        const double2 v = *(const double2 *)(lin + k0 + j);
-        x[j] = v.x * up;
-        x[j + 1] = v.y * up;
-    }
-    {
-        const uint4 b16 = *(const uint4 *)(T.line_band_long + k0);
-        const unsigned w[4] = {b16.x, b16.y, b16.z, b16.w};
-#pragma unroll
-        for (int j = 0; j < PER; ++j)
-            band[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
-    }
-    __syncthreads();
-    /* Each lane owns runs of consecutive lines of one band.  The band maximum of
-       |x| is taken on the bit pattern (non-negative doubles order like unsigned
-       integers) with 32-bit LDS atomics in two rounds -- high words, then low
-       words among the lanes that hold the winning high word.  (64-bit ds_max_u64
-       gave wrong maxima on gfx950 / ROCm 7.2 once in ~1500 bands when several
-       lanes hit one address; 32-bit LDS atomics are used everywhere else too.) */
-    unsigned *hi_w = (unsigned *)bmax;                 /* [nb] high words, then [nb] low words */
-    unsigned *lo_w = hi_w + PACX_MAX_BANDS;
-    {
-        int cur = band[0];
-        double m = 0.0;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            if (band[j] != cur) {
-                atomicMax(&hi_w[cur], (unsigned)__double2hiint(m));
-                cur = band[j];
-                m = 0.0;
-            }
-            m = fmax(m, fabs(x[j]));
-        }
-        atomicMax(&hi_w[cur], (unsigned)__double2hiint(m));
-    }
-    __syncthreads();
-    {
-        int cur = band[0];
-        double m = 0.0;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            if (band[j] != cur) {
-                if ((unsigned)__double2hiint(m) == hi_w[cur])
-                    atomicMax(&lo_w[cur], (unsigned)__double2loint(m));
-                cur = band[j];
-                m = 0.0;
-            }
-            m = fmax(m, fabs(x[j]));
-        }
-        if ((unsigned)__double2hiint(m) == hi_w[cur])
-            atomicMax(&lo_w[cur], (unsigned)__double2loint(m));
-    }
-    __syncthreads();
-    unsigned hw = 0, lw = 0;
-    if (lane < nb) {
-        hw = hi_w[lane];
-        lw = lo_w[lane];
-    }
-    __syncthreads();
-    if (lane < nb) {
-        const double mx = __longlong_as_double((long long)(((unsigned long long)hw << 32) | lw));
-        sf_s[lane] = pacx_scale_factor(mx, T.n_scale_bits, ba_s[lane]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int b = band[j];
-        const int ba = ba_s[b];
-        mant[j] = ba ? pacx_mantissa(x[j], sf_s[b], T.n_scale_bits, ba) : 0;
-    }
 }
 
 template <int M>
@@ -471,25 +212,6 @@ __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__
 #pragma unroll
         for (int j = 0; j < PER; j += 4)
             *(int4 *)(mantissa + loff + k0 + j) = make_int4(mant[j], mant[j + 1], mant[j + 2], mant[j + 3]);
-    }
-}
-
-/* -------------------------------------------------------------------- pack */
-#define PACX_PACK_WORDS 548            /* 2192 bytes >= 3 + 8*(4+8*16) + 1024*16 bits */
-
-__device__ __forceinline__ void put_bits(unsigned *words, int pos, unsigned val, int width)
-{
-    /* stream bit p lives in word p>>5 at bit 31-(p&31) (MSB first) */
-    if (width <= 0)
-        return;
-    val &= (width >= 32) ? 0xFFFFFFFFu : ((1u << width) - 1u);
-    const int w = pos >> 5, o = pos & 31;
-    const int room = 32 - o;
-    if (width <= room) {
-        atomicOr(&words[w], val << (room - width));
-    } else {
-        atomicOr(&words[w], val >> (width - room));
-        atomicOr(&words[w + 1], val << (32 - (width - room)));
     }
 }
 
@@ -1118,15 +840,17 @@ __global__ __launch_bounds__(256) void k_gather_small(const int32_t *__restrict_
 
 /* ------------------------------------------------------------- launchers */
 void pacx_launch_bitalloc(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
-                          int short_blocks, int mixed, const double *smr, int32_t *bit_alloc,
+                          int short_blocks, int mixed, int skip_long, const double *smr, int32_t *bit_alloc,
                           uint32_t *status, hipStream_t st)
 {
     if (n_cf <= 0)
         return;
     const bool dense = !short_blocks && !(mixed && flags);
+    if (dense && skip_long)
+        return;                                 /* every frame is long and was allocated by the mask kernel */
     const long long units = dense ? n_cf : n_cf * PACX_SUB;       /* two units per wave */
     hipLaunchKernelGGL(k_bitalloc, dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st, T, flags, n_ch,
-                       n_cf, short_blocks, mixed, 0, smr, bit_alloc, status);
+                       n_cf, short_blocks, mixed, skip_long, smr, bit_alloc, status);
 }
 
 void pacx_launch_quantize(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
@@ -1161,18 +885,21 @@ void pacx_launch_pack(const PacxTables &T, const uint8_t *flags, int n_ch, long 
 void pacx_launch_tail(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf, const double *smr,
                       const double *lines, const int32_t *overall, int32_t *bit_alloc, int32_t *scale_factor,
                       int32_t *mantissa, uint32_t *status, uint8_t *payload, int payload_stride,
-                      int32_t *n_bytes, const int32_t *list_short, const int32_t *count_short, hipStream_t st)
+                      int32_t *n_bytes, const int32_t *list_short, const int32_t *count_short, int skip_long,
+                      hipStream_t st)
 {
     if (n_cf <= 0)
         return;
     const int mixed = flags ? 1 : 0;
-    /* all-long batches: two frames per wave (BitAlloc of both on the two half waves).  Mixed
-       streams: one frame per wave -- the waves of short-coded frames leave at once, and the
-       long ones that remain fit the chip in one round, so the shorter chain per wave wins */
-    hipLaunchKernelGGL(k_tail_long, dim3((unsigned)(mixed ? n_cf : (n_cf + 1) / 2)), dim3(64), 0, st, T, flags, n_ch,
-                       n_cf, mixed, smr,
-                       lines, overall, bit_alloc, scale_factor, mantissa, status, payload, payload_stride,
-                       n_bytes);
+    /* skip_long: the long frames were finished inside the mask kernel (k_psy.hip, k_mask<1024, true>).
+       Otherwise -- all-long batches: two frames per wave (BitAlloc of both on the two half
+       waves).  Mixed streams: one frame per wave -- the waves of short-coded frames leave at
+       once, and the long ones that remain fit the chip in one round, so the shorter chain per
+       wave wins */
+    if (!skip_long)
+        hipLaunchKernelGGL(k_tail_long, dim3((unsigned)(mixed ? n_cf : (n_cf + 1) / 2)), dim3(64), 0, st, T, flags,
+                           n_ch, n_cf, mixed, smr, lines, overall, bit_alloc, scale_factor, mantissa, status, payload,
+                           payload_stride, n_bytes);
     if (mixed && list_short && T.nb_short <= 8) {
         /* short frames: one fused workgroup each, over the compacted list */
         hipLaunchKernelGGL(k_tail_short, dim3((unsigned)n_cf), dim3(256), 0, st, T, flags, n_ch, list_short,

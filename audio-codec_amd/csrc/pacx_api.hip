@@ -6,6 +6,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -23,7 +24,8 @@ void pacx_launch_mdct(const PacxTables &T, const PacxPcmView &in, int dtype, int
                       hipStream_t st);
 void pacx_launch_mdct_v2(const PacxTables &T, const PacxPcmView &in, const uint8_t *flags, long long n_cf,
                          int skip_cur, double *lines, int32_t *scale_out, int scale_stride,
-                         uint32_t *status_init, int n_cu, hipStream_t st);
+                         uint32_t *status_init, int n_cu, const int32_t *cf_list, const int32_t *cf_count,
+                         hipStream_t st);
 void pacx_launch_side(const PacxTables &T, const PacxPcmView &in, int dtype, int fast,
                       const uint8_t *flags, long long n_cf, int short_blocks, int mixed,
                       PacxPeak *peaks, int32_t *n_peaks, int32_t *n_kept, double *sbr_mean,
@@ -32,11 +34,11 @@ void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long 
                       int short_blocks, int mixed, const PacxPeak *peaks, const int32_t *n_peaks,
                       const double *lines, double *smr, double *thr_out, int n_cu,
                       const int32_t *list_long, const int32_t *list_short, const int32_t *counts,
-                      hipStream_t st);
+                      const MaskTail *tail, hipStream_t st);
 void pacx_launch_frame_lists(const uint8_t *flags, long long n_frames, int n_ch, int32_t *list_long,
                              int32_t *list_short, int32_t *counts, hipStream_t st);
 void pacx_launch_bitalloc(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
-                          int short_blocks, int mixed, const double *smr, int32_t *bit_alloc,
+                          int short_blocks, int mixed, int skip_long, const double *smr, int32_t *bit_alloc,
                           uint32_t *status, hipStream_t st);
 void pacx_launch_quantize(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf,
                           int short_blocks, int mixed, const double *lines, const int32_t *overall,
@@ -49,7 +51,8 @@ void pacx_launch_pack(const PacxTables &T, const uint8_t *flags, int n_ch, long 
 void pacx_launch_tail(const PacxTables &T, const uint8_t *flags, int n_ch, long long n_cf, const double *smr,
                       const double *lines, const int32_t *overall, int32_t *bit_alloc, int32_t *scale_factor,
                       int32_t *mantissa, uint32_t *status, uint8_t *payload, int payload_stride,
-                      int32_t *n_bytes, const int32_t *list_short, const int32_t *count_short, hipStream_t st);
+                      int32_t *n_bytes, const int32_t *list_short, const int32_t *count_short, int skip_long,
+                      hipStream_t st);
 void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stride,
                         const int32_t *n_bytes, long long *chunk_buf, long long *offs_buf, uint8_t *body,
                         long long capacity, long long *total, hipStream_t st);
@@ -704,7 +707,7 @@ extern "C" int pacx_mdct_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t
         return post_launch(h, "pacx_mdct_batch");
     }
     if (fast && !short_blocks && !(mode & PACX_MDCT_PREWINDOWED)) {
-        pacx_launch_mdct_v2(h->T, v, frame_flags, n_cf, 0, lines, max_scale, 1, nullptr, h->n_cu,
+        pacx_launch_mdct_v2(h->T, v, frame_flags, n_cf, 0, lines, max_scale, 1, nullptr, h->n_cu, nullptr, nullptr,
                             (hipStream_t)stream);
         return post_launch(h, "pacx_mdct_batch");     /* v2 handles all four long windows */
     }
@@ -737,7 +740,7 @@ extern "C" int pacx_smr_batch(pacx_handle *h, const pacx_pcm *in, const double *
     pacx_launch_side(h->T, v, in->dtype, fast, nullptr, n_cf, sb, 0, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
                      nullptr, nullptr, st);
     pacx_launch_mask(h->T, nullptr, in->n_channels, n_cf, sb, 0, h->ws_peaks, h->ws_nkept, lines, smr,
-                     threshold, h->n_cu, nullptr, nullptr, nullptr, st);
+                     threshold, h->n_cu, nullptr, nullptr, nullptr, nullptr, st);
     if (n_peaks) {
         if (sb)
             HIP_TRY(h, hipMemcpyAsync(n_peaks, h->ws_npeaks, (size_t)n_cf * PACX_SUB * sizeof(int32_t),
@@ -760,7 +763,7 @@ extern "C" int pacx_bitalloc_batch(pacx_handle *h, int64_t n_cf, int n_channels,
     if (n_cf < 0 || n_channels < 1 || !smr || !bit_alloc)
         return fail(h, PACX_E_ARG, "pacx_bitalloc_batch: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    pacx_launch_bitalloc(h->T, frame_flags, n_channels, n_cf, short_blocks ? 1 : 0, 0, smr, bit_alloc, status,
+    pacx_launch_bitalloc(h->T, frame_flags, n_channels, n_cf, short_blocks ? 1 : 0, 0, 0, smr, bit_alloc, status,
                          (hipStream_t)stream);
     return post_launch(h, "pacx_bitalloc_batch");
 }
@@ -825,6 +828,11 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
         HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
     }
+    /* mixed streams: compacted lists of the long- and of the short-coded frames, first --
+       every persistent kernel below walks its own list */
+    if (mixed)
+        pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,
+                                h->ws_lists + 2 * n_cf, st);
     /* fork: the side chain only reads the PCM, so it runs on its own stream next to the MDCT */
     HIP_TRY(h, hipEventRecord(h->ev_fork, st));
     HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
@@ -834,7 +842,7 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
     if (fast) {
         /* long frames: persistent roofline kernel; short (CUR) frames: k_mdct_short */
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
-                            h->n_cu, st);
+                            h->n_cu, mixed ? h->ws_lists : nullptr, mixed ? h->ws_lists + 2 * n_cf : nullptr, st);
         if (mixed)
             pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale,
                              PACX_SUB, status, st);
@@ -843,15 +851,22 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
                          PACX_SUB, status, st);
     }
     HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));       /* join */
-    if (mixed)
-        pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,
-                                h->ws_lists + 2 * n_cf, st);
+    /* long frames: masked threshold, SMRs, BitAlloc, scale factors / mantissas and the payload
+       in ONE kernel (the wave that has a frame's SMRs goes on with it); PACX_FUSE_TAIL=0 keeps
+       the tail in k_tail_long behind a kernel boundary (A/B measurements, equivalence test) */
+    const char *fuse_env = getenv("PACX_FUSE_TAIL");          /* read per call: tests flip it */
+    const int fuse = (fuse_env && atoi(fuse_env) == 0) ? 0 : 1;
+    MaskTail mt;
+    mt.overall = overall_scale; mt.bit_alloc = bit_alloc; mt.scale_factor = scale_factor; mt.mantissa = mantissa;
+    mt.status = status; mt.payload = payload; mt.n_bytes = n_bytes; mt.payload_stride = PACX_PAYLOAD_STRIDE;
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
-                     nullptr, h->n_cu, h->ws_lists, h->ws_lists + n_cf, h->ws_lists + 2 * n_cf, st);
-    /* BitAlloc + scale factors/mantissas (+ payload): one fused kernel for long frames */
-    pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
-                     mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_lists + n_cf,
-                     h->ws_lists + 2 * n_cf + 1, st);
+                     nullptr, h->n_cu, h->ws_lists, h->ws_lists + n_cf, h->ws_lists + 2 * n_cf,
+                     fuse ? &mt : nullptr, st);
+    /* what is left: the long frames when not fused, the short-coded frames of a mixed batch */
+    if (!fuse || mixed)
+        pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
+                         mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_lists + n_cf,
+                         h->ws_lists + 2 * n_cf + 1, fuse, st);
     return post_launch(h, what);
 }
 
@@ -919,9 +934,12 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
         HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
     }
     HIP_TRY(h, hipMemsetAsync(n_bytes, 0, (size_t)n_cf * sizeof(int32_t), st));
+    if (mixed)
+        pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,
+                                h->ws_lists + 2 * n_cf, st);
     if (fast) {
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
-                            h->n_cu, st);
+                            h->n_cu, mixed ? h->ws_lists : nullptr, mixed ? h->ws_lists + 2 * n_cf : nullptr, st);
         if (mixed)
             pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale,
                              PACX_SUB, status, st);
@@ -932,12 +950,14 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
     /* the side chain also folds max|FFT| into the overall scale of SBR long blocks */
     pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
                      T.use_sbr ? h->ws_sbr_mean : nullptr, T.use_sbr ? overall_scale : nullptr, st);
-    if (mixed)
-        pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,
-                                h->ws_lists + 2 * n_cf, st);
+    /* BitAlloc of the long frames runs inside the mask kernel (gain-shape handles stop there) */
+    MaskTail mt;
+    memset(&mt, 0, sizeof(mt));
+    mt.bit_alloc = bit_alloc;
+    mt.status = status;
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
-                     nullptr, h->n_cu, h->ws_lists, h->ws_lists + n_cf, h->ws_lists + 2 * n_cf, st);
-    pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_smr, bit_alloc, status, st);
+                     nullptr, h->n_cu, h->ws_lists, h->ws_lists + n_cf, h->ws_lists + 2 * n_cf, &mt, st);
+    pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, 1, h->ws_smr, bit_alloc, status, st);
     pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
                    h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
                    h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, st);

@@ -66,4 +66,16 @@ struct __attribute__((aligned(8))) PacxPeak {
     double slope;   /* -27 + 0.367*max(spl-40,0): upper-side slope, dB/Bark   */
 };
 
+/* outputs of the tail fused into the long mask kernel (k_psy.hip k_mask<1024, true>) */
+struct MaskTail {
+    const int32_t *overall;     /* [cf][8], from the MDCT kernel              */
+    int32_t *bit_alloc;         /* [cf][band_stride]                          */
+    int32_t *scale_factor;      /* [cf][band_stride]                          */
+    int32_t *mantissa;          /* [cf][1024] line-indexed, optional          */
+    uint32_t *status;           /* [cf]                                       */
+    uint8_t *payload;           /* [cf][payload_stride], optional             */
+    int32_t *n_bytes;           /* [cf]                                       */
+    int payload_stride;
+};
+
 #endif

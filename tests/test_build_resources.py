@@ -33,8 +33,9 @@ HOT = [
     (r"^void k_side_long<0, true, true>\(", 168, 3),     # int16 fast path, compact LDS
     (r"^void k_side_long<0, true, false>\(", 168, 3),    # ... SBR handles
     (r"^void k_side_short<0, true>\(", 168, 3),
-    (r"^void k_mask<1024>\(", 168, 3),
-    (r"^void k_mask<128>\(", 96, 5),
+    (r"^void k_mask<1024, true>\(", 168, 3),            # mask + BitAlloc + quantise + pack, long frames
+    (r"^void k_mask<1024, false>\(", 168, 3),
+    (r"^void k_mask<128, false>\(", 96, 5),
     (r"^k_tail_long\(", 128, 4),
     (r"^k_tail_short\(", 64, 8),
     (r"^k_gather_small\(", None, None),

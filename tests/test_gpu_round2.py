@@ -232,3 +232,46 @@ def test_large_batch_sampled_against_oracle(A, torch):
         assert host["payload"][i, :n].tobytes() == want, i
         rec = body[offs[i]:offs[i + 1]].tobytes()
         assert rec == len(want).to_bytes(4, "little") + want, i
+
+
+# ------------------------------------------------ fused mask + tail kernel
+@pytest.mark.parametrize("mixed", [False, True])
+def test_fused_tail_equals_separate_kernels(A, torch, mixed):
+    """k_mask<1024, true> (SMRs, BitAlloc, scale factors, mantissas and payload of a long frame in
+    one wave) against the same stages as separate kernels behind a boundary (PACX_FUSE_TAIL=0:
+    k_mask<1024, false> + k_tail_long): every output bit for bit, on an all-long batch and on a
+    block-switched one (long frames through the fused kernel, short ones through k_tail_short)."""
+    import os
+    if mixed:
+        ex = load_excerpt("castanet")
+        sr, pcm = int(ex["sr"]), ex["pcm"][:48 * 1024]
+    else:
+        sr, pcm = 48000, A.synth.stream(300, 2)
+    enc = A.context.encoder(sr, 128 / (sr / 1000))
+    planar = A.pacfile.device_stream(enc, pcm)
+    view = A.engine.PcmView.stream(planar)
+    flags = enc.transient_flags(planar, len(pcm) // 1024)[1] if mixed else None
+
+    def run():
+        out = enc.encode_pack(view, flags, want_mantissa=True)
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in out.items() if v is not None}
+    old = os.environ.get("PACX_FUSE_TAIL")
+    try:
+        os.environ["PACX_FUSE_TAIL"] = "0"
+        ref = run()
+        os.environ["PACX_FUSE_TAIL"] = "1"
+        got = run()
+    finally:
+        if old is None:
+            os.environ.pop("PACX_FUSE_TAIL", None)
+        else:
+            os.environ["PACX_FUSE_TAIL"] = old
+    for k in ("overall", "scale_factor", "bit_alloc", "mantissa", "status", "n_bytes"):
+        assert torch.equal(got[k], ref[k]), k
+    nb = ref["n_bytes"].cpu().numpy()
+    pg, pr = got["payload"].cpu().numpy(), ref["payload"].cpu().numpy()
+    for i in range(len(nb)):
+        assert pg[i, :nb[i]].tobytes() == pr[i, :nb[i]].tobytes(), i
+    if mixed:
+        assert (ref["status"].cpu().numpy() & 1).any() and not (ref["status"].cpu().numpy() & 1).all()
