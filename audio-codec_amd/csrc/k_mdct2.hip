@@ -216,11 +216,13 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 2) void k_mdct_long_v2(
         /* overall scale = minimum of the lanes' own scales (ScaleFactor is non-increasing),
            by bisection with one ballot per bit: see k_mdct3.hip */
         int lo = 0;
+        bool guard = false;
         if (scale_out) {
             const int s = pacx_scale_factor(mx, T.n_scale_bits, 5);
             for (int bit = T.n_scale_bits - 1; bit >= 0; --bit)
                 if (!__builtin_amdgcn_ballot_w64(s < lo + (1 << bit)))
                     lo += 1 << bit;
+            guard = status_init && s == lo && pacx_scale_guard(mx, T.n_scale_bits, 5, 2.0 * PACX_GUARD_LINE_ERR * mx);   /* PACX_ST_GUARD, as k_mdct3.hip */
         }
         double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);
 #pragma unroll
@@ -228,6 +230,8 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 2) void k_mdct_long_v2(
             out[lane + 64 * k3] = make_double2(a[k3], odd[k3]);
         if (scale_out && lane == 0)
             scale_out[(long long)cf * scale_stride] = lo;
+        if (__builtin_amdgcn_ballot_w64(guard) && lane == 0)
+            status_init[cf] = 16u;
     }
 }
 

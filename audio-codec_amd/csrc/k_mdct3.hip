@@ -358,11 +358,16 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
            found by bisection with one ballot per bit while the lane reversal above is in
            flight (a 64-bit max over the wave would be six dependent LDS round trips) */
         int lo = 0;
+        bool guard = false;
         if (scale_out) {
             const int s = pacx_scale_factor(mx, T.n_scale_bits, 5);
             for (int bit = T.n_scale_bits - 1; bit >= 0; --bit)
                 if (!__builtin_amdgcn_ballot_w64(s < lo + (1 << bit)))
                     lo += 1 << bit;
+            /* PACX_ST_GUARD: the lanes that decide the minimum hold a maximum within a factor
+               two of the block's; theirs sitting at a boundary of ScaleFactor flags the frame
+               (line error bound relative to the block maximum, pacx_exact.h) */
+            guard = status_init && s == lo && pacx_scale_guard(mx, T.n_scale_bits, 5, 2.0 * PACX_GUARD_LINE_ERR * mx);
         }
         double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);
         static_assert(EPI_STORES * 64 * 2 == PACX_M_LONG, "one epilogue = EPI_STORES 16-byte stores per lane");
@@ -371,6 +376,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
             out[lane + 64 * k3] = make_double2(a[k3], odd[k3]);
         if (scale_out && lane == 0)
             scale_out[(long long)cf * scale_stride] = lo;
+        if (__builtin_amdgcn_ballot_w64(guard) && lane == 0)
+            status_init[cf] = 16u;                 /* after this lane's own zero-store of the same word */
     };
 #ifdef PACX_MDCT_DEBUG
     const bool dbg_on = blockIdx.x == 7;

@@ -900,7 +900,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 if (tl == nb && nb < PACX_MAX_BANDS)
                     ba_s[nb] = 0;                         /* dummy band of the lines no band covers */
                 if (cap && tail.status && tl == 0)
-                    atomicOr(&tail.status[cf], 4u);
+                    atomicOr(&tail.status[cf], ((cap & 1) ? 4u : 0u) | ((cap & 2) ? 16u : 0u));   /* ALLOC_CAP, GUARD */
                 PSY_T(4);
                 if (!T.use_vq) {
                     /* 2. the payload's layout follows from the allocation alone: band header
@@ -948,6 +948,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                     PSY_T(5);
                     /* 4. mantissas, written into the bit buffer (and to HBM when asked for) as they
                        are made: four at a time, never all sixteen live */
+                    bool near = false;                    /* PACX_ST_GUARD, see pacx_exact.h */
 #pragma unroll
                     for (int j4 = 0; j4 < 16; j4 += 4) {
                         int mq[4];
@@ -957,12 +958,15 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                             const int b = band[j];
                             const int a = ba_s[b];
                             mq[u] = a ? pacx_mantissa(x[j], sf_s[b], T.n_scale_bits, a) : 0;
+                            near = near || pacx_quant_guard(fabs(x[j]), (1 << T.n_scale_bits) - 1 + a, PACX_GUARD_LINE_ERR);
                             if (tail.payload && a)
                                 put_bits(words, offs[b] + (k0 + j - lower_s[b]) * a, (unsigned)mq[u], a);
                         }
                         if (tail.mantissa)
                             *(int4 *)(tail.mantissa + loff + k0 + j4) = make_int4(mq[0], mq[1], mq[2], mq[3]);
                     }
+                    if (tail.status && __builtin_amdgcn_ballot_w64(near) && tl == 0)
+                        atomicOr(&tail.status[cf], 16u);
                     if (tail.payload) {
                         wave_lds_fence();
                         const int nbytes = ((end - 3) + 4 + 7) >> 3;

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
     if (has)
         bit_alloc[off + l] = bits;
     if (alive && cap && status && l == 0)
-        atomicOr(&status[cf], 4u);
+        atomicOr(&status[cf], ((cap & 1) ? 4u : 0u) | ((cap & 2) ? 16u : 0u));   /* ALLOC_CAP, GUARD */
 }
 
 template <int M>
@@ -96,7 +96,8 @@ __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__
         double xl[16];
         uint8_t bandl[16];
         int32_t mantl[16];
-        quantize_long_core(T, lines + loff, up, bmax, ba_s, sf_s, lane, xl, bandl, mantl);
+        bool near_unused;
+        quantize_long_core(T, lines + loff, up, bmax, ba_s, sf_s, lane, xl, bandl, mantl, near_unused);
         if (lane < nb)
             scale_factor[boff + lane] = sf_s[lane];
 #pragma unroll
@@ -142,54 +143,6 @@ __global__ __launch_bounds__(64) void k_quantize(PacxTables T, const uint8_t *__
             m = wave_max(m);
             if (lane == b)
                 bmax[b] = (unsigned long long)__double_as_longlong(m);
-        }
-    } else {
-        /* Each lane owns runs of consecutive lines of one band.  The band maximum of
-           |x| is taken on the bit pattern (non-negative doubles order like unsigned
-           integers) with 32-bit LDS atomics in two rounds -- high words, then low
-           words among the lanes that hold the winning high word.  (64-bit ds_max_u64
-           gave wrong maxima on gfx950 / ROCm 7.2 once in ~1500 bands when several
-           lanes hit one address; 32-bit LDS atomics are used everywhere else too.) */
-        unsigned *hi_w = (unsigned *)bmax;                 /* [nb] high words, then [nb] low words */
-        unsigned *lo_w = hi_w + PACX_MAX_BANDS;
-        {
-            int cur = band[0];
-            double m = 0.0;
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                if (band[j] != cur) {
-                    atomicMax(&hi_w[cur], (unsigned)__double2hiint(m));
-                    cur = band[j];
-                    m = 0.0;
-                }
-                m = fmax(m, fabs(x[j]));
-            }
-            atomicMax(&hi_w[cur], (unsigned)__double2hiint(m));
-        }
-        __syncthreads();
-        {
-            int cur = band[0];
-            double m = 0.0;
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                if (band[j] != cur) {
-                    if ((unsigned)__double2hiint(m) == hi_w[cur])
-                        atomicMax(&lo_w[cur], (unsigned)__double2loint(m));
-                    cur = band[j];
-                    m = 0.0;
-                }
-                m = fmax(m, fabs(x[j]));
-            }
-            if ((unsigned)__double2hiint(m) == hi_w[cur])
-                atomicMax(&lo_w[cur], (unsigned)__double2loint(m));
-        }
-        __syncthreads();
-        if (lane < nb) {
-            const unsigned hw = hi_w[lane], lw = lo_w[lane];
-            __syncthreads();
-            bmax[lane] = ((unsigned long long)hw << 32) | lw;
-        } else {
-            __syncthreads();
         }
     }
     __syncthreads();
@@ -371,7 +324,7 @@ extern "C" int pacx_debug_read_tail(long long *out, int n)
 #define TAIL_T(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
+__global__ __launch_bounds__(64, 4) void k_tail_long(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
                                                  long long n_cf, int mixed, const double *__restrict__ smr,
                                                  const double *__restrict__ lines,
                                                  const int32_t *__restrict__ overall,
@@ -424,7 +377,7 @@ __global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *_
         if (alive && l == nb && nb < PACX_MAX_BANDS)
             ba_2[half][nb] = 0;                           /* dummy band of the lines no band covers */
         if (alive && cap && status && l == 0)
-            atomicOr(&status[cfh], 4u);
+            atomicOr(&status[cfh], ((cap & 1) ? 4u : 0u) | ((cap & 2) ? 16u : 0u));
     }
     TAIL_T(0);
     for (int c = 0; c < per_block; ++c) {
@@ -446,9 +399,12 @@ __global__ __launch_bounds__(64) void k_tail_long(PacxTables T, const uint8_t *_
         double x[16];
         uint8_t band[16];
         int32_t mant[16];
-        quantize_long_core(T, lines + cf * PACX_M_LONG, (double)(1 << ov), bmax, ba_s, sf_s, lane, x, band, mant);
+        bool near;
+        quantize_long_core(T, lines + cf * PACX_M_LONG, (double)(1 << ov), bmax, ba_s, sf_s, lane, x, band, mant, near);
         if (lane < nb)
             scale_factor[boff + lane] = sf_s[lane];
+        if (status && __builtin_amdgcn_ballot_w64(near) && lane == 0)
+            atomicOr(&status[cf], 16u);                   /* PACX_ST_GUARD */
         const int k0 = 16 * lane;
         if (mantissa) {
 #pragma unroll
@@ -557,7 +513,7 @@ __global__ __launch_bounds__(256) void k_tail_short(PacxTables T, const uint8_t 
             sf_s[sb][nb] = 0;
         }
         if (cap && status && l == 0)
-            atomicOr(&status[cf], 4u);
+            atomicOr(&status[cf], ((cap & 1) ? 4u : 0u) | ((cap & 2) ? 16u : 0u));
     }
     for (int i = tid; i < PACX_PACK_WORDS; i += 256)
         words[i] = 0u;
@@ -602,6 +558,13 @@ __global__ __launch_bounds__(256) void k_tail_short(PacxTables T, const uint8_t 
         const int a0 = ba_s[sb][band0], a1 = ba_s[sb][band1];
         mant[q][0] = a0 ? pacx_mantissa(x0, sf_s[sb][band0], T.n_scale_bits, a0) : 0;
         mant[q][1] = a1 ? pacx_mantissa(x1, sf_s[sb][band1], T.n_scale_bits, a1) : 0;
+        if (status) {                                     /* PACX_ST_GUARD, see pacx_exact.h */
+            const int r0 = (1 << T.n_scale_bits) - 1;
+            const bool near = (band0 < nb && pacx_quant_guard(fabs(x0), r0 + a0, PACX_GUARD_LINE_ERR)) ||
+                              (band1 < nb && pacx_quant_guard(fabs(x1), r0 + a1, PACX_GUARD_LINE_ERR));
+            if (__builtin_amdgcn_ballot_w64(near) && lane == 0)
+                atomicOr(&status[cf], 16u);
+        }
         if (lane < nb)
             scale_factor[cf * T.band_stride + sb * nb + lane] = sf_s[sb][lane];
         if (mantissa)

@@ -53,6 +53,40 @@ PACX_HD int64_t pacx_quant_mag(double ax, int r_bits)
     return (int64_t)floor(t * 0.5);
 }
 
+/* PACX_ST_GUARD -- how close a quantiser input sits to a decision boundary.
+ * The code floor(t/2), t = (2^R - 1) ax + 1 (coder/quantize.py:73), changes where t crosses
+ * an even integer (and at ax = 1, the clip).  This build's MDCT lines differ from the
+ * reference's by the rounding noise of two different FFT factorisations: measured ~2e-13 of the
+ * block maximum, and the lines are scaled so that this maximum is below 1.  A line is "near a
+ * boundary" when t lies within (2^R - 1) * PACX_GUARD_LINE_ERR of one: its code could be the
+ * neighbouring one in the reference's arithmetic.  (Not an error: the codes written are the
+ * exact codes of THIS arithmetic; the flag marks frames a bit-exactness harness may want to
+ * recompute on the CPU.) */
+#define PACX_GUARD_LINE_ERR 5e-13       /* absolute, on lines scaled by 2^overallScale */
+#define PACX_GUARD_ALLOC_ERR 1e-9       /* on Ropt - level (SMRs agree with the reference to 1e-9 dB) */
+
+PACX_HD int pacx_quant_guard(double ax, int r_bits, double err)
+{
+    const double s = (double)(((int64_t)1 << r_bits) - 1);
+    if (ax >= 1.0 - err)
+        return ax <= 1.0 + err;                   /* at the clip (beyond it the code is constant) */
+    const double half = (s * ax + 1.0) * 0.5;
+    return fabs(half - rint(half)) * 2.0 <= s * err;
+}
+
+/* the same for ScaleFactor (coder/quantize.py:99-125): the leading-zero count of the magnitude
+   code changes where the code crosses a power of two */
+PACX_HD int pacx_scale_guard(double ax, int n_scale_bits, int n_mant_bits, double err)
+{
+    const int r_bits = (1 << n_scale_bits) - 1 + n_mant_bits;
+    if (!pacx_quant_guard(ax, r_bits, err))
+        return 0;
+    const double s = (double)(((int64_t)1 << r_bits) - 1);
+    const double half = (s * ax + 1.0) * 0.5;     /* near an integer n: does n have one bit set? */
+    const int64_t n = (int64_t)rint(half);
+    return ax >= 1.0 - err || (n > 0 && (n & (n - 1)) == 0);
+}
+
 PACX_HD int pacx_clz64(uint64_t v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

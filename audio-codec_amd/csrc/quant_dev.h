@@ -176,6 +176,22 @@ __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, in
             }
         }
     }
+    /* PACX_ST_GUARD: a band whose final Ropt - level sits within PACX_GUARD_ALLOC_ERR of a
+       rounding boundary k + 1/2 (np.round at coder/bitalloc.py:103), or of the 2-bit / 16-bit
+       limits of :104-107.  `want`, `frac` and the ladder level belong to the last pass. */
+    {
+        double level = 0.0;
+        if (n_flip > 0 && n_flip <= nd) {
+            const bool sel = posf && lt <= n_flip - 1 && n_flip - 1 < le;
+            const unsigned smask = (unsigned)(__builtin_amdgcn_ballot_w64(sel) >> (32 * half));
+            level = __shfl(frac, smask ? __builtin_ctz(smask) : 0, 32);
+        }
+        const double r = want - level;
+        const double d = fabs((r - floor(r)) - 0.5);
+        const bool near = alive && valid && d <= PACX_GUARD_ALLOC_ERR;
+        if ((unsigned)(__builtin_amdgcn_ballot_w64(near) >> (32 * half)))
+            cap |= 2;
+    }
     bits_out = bits;
     cap_out = cap;
 }
@@ -212,56 +228,30 @@ __device__ __forceinline__ void long_scale_factors(const PacxTables &T, const do
             band[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
     }
     wave_lds_fence();
-    /* Each lane owns runs of consecutive lines of one band.  The band maximum of
-       |x| is taken on the bit pattern (non-negative doubles order like unsigned
-       integers) with 32-bit LDS atomics in two rounds -- high words, then low
-       words among the lanes that hold the winning high word.  (64-bit ds_max_u64
-       gave wrong maxima on gfx950 / ROCm 7.2 once in ~1500 bands when several
-       lanes hit one address; 32-bit LDS atomics are used everywhere else too.) */
-    unsigned *hi_w = (unsigned *)bmax;                 /* [nb] high words, then [nb] low words */
-    unsigned *lo_w = hi_w + PACX_MAX_BANDS;
+    /* Each lane owns runs of consecutive lines of one band.  The band maximum of |x| is
+       taken on the bit pattern (non-negative doubles order like unsigned integers) with one
+       64-bit LDS atomic max (ds_max_u64) per run.  (Round 1 used two rounds of 32-bit atomics
+       here, blaming lost updates on ds_max_u64; tools/ds_max_u64_probe.hip runs this very access
+       pattern -- long and short band layouts, ties included -- 23 million band maxima without
+       one wrong result on gfx950 / ROCm 7.2, and the whole-file byte-exactness tests pass on the
+       64-bit form: the round-1 failure was not the hardware's.) */
     {
         int cur = band[0];
         double m = 0.0;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             if (band[j] != cur) {
-                atomicMax(&hi_w[cur], (unsigned)__double2hiint(m));
+                atomicMax(&bmax[cur], (unsigned long long)__double_as_longlong(m));
                 cur = band[j];
                 m = 0.0;
             }
             m = fmax(m, fabs(x[j]));
         }
-        atomicMax(&hi_w[cur], (unsigned)__double2hiint(m));
+        atomicMax(&bmax[cur], (unsigned long long)__double_as_longlong(m));
     }
     wave_lds_fence();
-    {
-        int cur = band[0];
-        double m = 0.0;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            if (band[j] != cur) {
-                if ((unsigned)__double2hiint(m) == hi_w[cur])
-                    atomicMax(&lo_w[cur], (unsigned)__double2loint(m));
-                cur = band[j];
-                m = 0.0;
-            }
-            m = fmax(m, fabs(x[j]));
-        }
-        if ((unsigned)__double2hiint(m) == hi_w[cur])
-            atomicMax(&lo_w[cur], (unsigned)__double2loint(m));
-    }
-    wave_lds_fence();
-    unsigned hw = 0, lw = 0;
-    if (lane < nb) {
-        hw = hi_w[lane];
-        lw = lo_w[lane];
-    }
-    wave_lds_fence();
-    if (lane < nb) {
-        const double mx = __longlong_as_double((long long)(((unsigned long long)hw << 32) | lw));
-        sf_s[lane] = pacx_scale_factor(mx, T.n_scale_bits, ba_s[lane]);
-    }
+    if (lane < nb)
+        sf_s[lane] = pacx_scale_factor(__longlong_as_double((long long)bmax[lane]), T.n_scale_bits, ba_s[lane]);
     wave_lds_fence();
 }
 
@@ -269,14 +259,16 @@ __device__ __forceinline__ void long_scale_factors(const PacxTables &T, const do
 __device__ __forceinline__ void quantize_long_core(const PacxTables &T, const double *__restrict__ lin,
                                                    double up, unsigned long long *bmax, const int *ba_s,
                                                    int *sf_s, int lane, double (&x)[16], uint8_t (&band)[16],
-                                                   int32_t (&mant)[16])
+                                                   int32_t (&mant)[16], bool &near)
 {
     long_scale_factors(T, lin, up, bmax, ba_s, sf_s, lane, x, band);
+    near = false;                                  /* PACX_ST_GUARD of this lane's lines (pacx_exact.h) */
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int b = band[j];
         const int ba = ba_s[b];
         mant[j] = ba ? pacx_mantissa(x[j], sf_s[b], T.n_scale_bits, ba) : 0;
+        near = near || pacx_quant_guard(fabs(x[j]), (1 << T.n_scale_bits) - 1 + ba, PACX_GUARD_LINE_ERR);
     }
 }
 

@@ -23,6 +23,8 @@ double hc_spl_scalar(double v) { return pacx_spl_scalar(v); }
 double hc_bark(double f) { return pacx_bark(f); }
 double hc_thresh_quiet(double f) { return pacx_thresh_quiet(f); }
 int hc_window_kind(unsigned f) { return pacx_window_kind(f); }
+int hc_quant_guard(double ax, int r, double err) { return pacx_quant_guard(ax, r, err); }
+int hc_scale_guard(double ax, int nsb, int nmb, double err) { return pacx_scale_guard(ax, nsb, nmb, err); }
 
 /* pyramid-VQ tables (pacx_vq_tables.h) */
 static PacxVqHostTables g_vq;

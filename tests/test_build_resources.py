@@ -37,7 +37,7 @@ HOT = [
     (r"^void k_mask<1024, false>\(", 168, 3),
     (r"^void k_mask<128, false>\(", 96, 5),
     (r"^k_tail_long\(", 128, 4),
-    (r"^k_tail_short\(", 64, 8),
+    (r"^k_tail_short\(", 72, 7),
     (r"^k_gather_small\(", None, None),
     pytest.param(r"^k_vq\(", 168, 3, marks=pytest.mark.xfail(strict=True, reason="20 spilled VGPRs at 3 waves/SIMD (needs 200)")),
     (r"^k_vq_join\(", None, None),

@@ -275,3 +275,36 @@ def test_fused_tail_equals_separate_kernels(A, torch, mixed):
         assert pg[i, :nb[i]].tobytes() == pr[i, :nb[i]].tobytes(), i
     if mixed:
         assert (ref["status"].cpu().numpy() & 1).any() and not (ref["status"].cpu().numpy() & 1).all()
+
+
+# ----------------------------------------------------------- PACX_ST_GUARD
+def test_guard_flag_on_a_corpus_sample(A, torch):
+    """PACX_ST_GUARD marks channel-frames with a rounding decision near its boundary (a mantissa
+    or scale-factor quantiser input next to an even integer, coder/quantize.py:73; a BitAlloc
+    value next to k + 1/2, coder/bitalloc.py:103).  On a sample of BASELINE configs[4]'s corpus
+    (tiles at several levels): few frames are flagged, the oracle agrees bit for bit on un-flagged
+    frames spread over the sample -- and, so far, on the flagged ones too (the flag is a margin,
+    not an error)."""
+    S = A.synth
+    base = S.stream_float(512, 2)
+    pcm = np.concatenate([S.to_int16(base, S.tile_scale(t)) for t in (0, 5, 10, 15)])      # 2048 hops
+    enc = A.context.encoder(48000, 128 / 48.0)
+    planar = torch.as_tensor(S.planar_with_halo(pcm), device=enc.device)
+    out = enc.encode_pack(A.engine.PcmView.stream(planar), want_mantissa=True)
+    host = {k: v.cpu().numpy() for k, v in out.items() if v is not None and k != "flags"}
+    st = host["status"].astype(np.uint32)
+    flagged = np.nonzero(st & A._lib.ST_GUARD)[0]
+    n_cf = len(st)
+    assert n_cf == 4096
+    assert len(flagged) < 0.05 * n_cf, f"{len(flagged)} of {n_cf} channel-frames flagged"
+    assert not (st & ~np.uint32(A._lib.ST_GUARD | A._lib.ST_ALLOC_CAP)).any()
+    p = po.make_params(48000, 2, 128)
+    halo = np.concatenate((np.zeros((1024, 2), np.int16), pcm))
+    clean = np.setdiff1d(np.linspace(0, n_cf - 1, 40).astype(int), flagged)
+    for i in list(clean) + list(flagged[:12]):
+        f, ch = divmod(int(i), 2)
+        sf, ba, mant, ov = po.encode_channel(po.pcm16_to_fraction(halo[f * 1024:f * 1024 + 2048, ch]), p)
+        r = A.codec.unpack_long(enc, host, i)
+        assert r[3] == ov and r[1].tolist() == ba.tolist(), i
+        assert r[0].tolist() == sf.tolist() and r[2].tolist() == mant.tolist(), i
+    print(f"PACX_ST_GUARD: {len(flagged)} of {n_cf} channel-frames flagged")

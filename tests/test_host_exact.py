@@ -37,6 +37,8 @@ def hc(tmp_path_factory):
         getattr(lib, f).restype = ctypes.c_double
         getattr(lib, f).argtypes = [ctypes.c_double]
     lib.hc_window_kind.argtypes = [ctypes.c_uint]
+    lib.hc_quant_guard.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_double]
+    lib.hc_scale_guard.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double]
     return lib
 
 
@@ -241,3 +243,34 @@ def test_vq_tables_match_oracle(hc):
         for k in range(min(n, 300)):
             run += pv.codebook_size(l, k)
             assert hc.hc_vq_p(l, k) == run
+
+
+def test_guard_band_of_the_quantiser(hc):
+    """PACX_ST_GUARD helpers: a magnitude is flagged exactly when a perturbation of up to `err`
+    can change its code (coder/quantize.py:73: floor(((2^R - 1) ax + 1) / 2)), and the
+    ScaleFactor guard only at the boundaries where the leading-zero count changes."""
+    rng = np.random.default_rng(5)
+    err = 5e-13
+    for r_bits in (15, 17, 20, 24, 31):
+        s = float((1 << r_bits) - 1)
+        ax = rng.uniform(0, 1, 4000)
+        # some values parked right at boundaries: t = even integer +- tiny
+        k = rng.integers(1, 1 << (r_bits - 1), 400).astype(np.float64)
+        ax[:400] = (2 * k - 1) / s * (1 + rng.uniform(-1, 1, 400) * 1e-15)
+        for a in ax:
+            a = float(min(max(a, 0.0), 0.999999))
+            lo, hi = max(a - err, 0.0), a + err
+            changes = hc.hc_quant_mag(lo, r_bits) != hc.hc_quant_mag(hi, r_bits)
+            flagged = hc.hc_quant_guard(a, r_bits, err)
+            if changes:
+                assert flagged, (a, r_bits)          # never misses a code that can move
+            if not flagged:
+                assert hc.hc_quant_mag(lo, r_bits) == hc.hc_quant_mag(a, r_bits) == hc.hc_quant_mag(hi, r_bits)
+    assert hc.hc_quant_guard(1.0, 20, err) and hc.hc_quant_guard(1.0 - 1e-13, 20, err)
+    assert not hc.hc_quant_guard(1.5, 20, err) and not hc.hc_quant_guard(0.3, 10, err)
+    # ScaleFactor: 4 scale bits, 5 mantissa bits -> R = 20; boundaries where the code is a power of two
+    for j in range(4, 18):                                       # below 2^4 the count is capped at 15
+        edge = (2.0 * (1 << j) - 1) / float((1 << 20) - 1)       # t = 2 * 2^j exactly
+        assert hc.hc_scale_factor(edge * (1 - 1e-12), 4, 5) != hc.hc_scale_factor(edge * (1 + 1e-12), 4, 5)
+        assert hc.hc_scale_guard(edge, 4, 5, err)
+        assert not hc.hc_scale_guard(edge * 1.37, 4, 5, err)
