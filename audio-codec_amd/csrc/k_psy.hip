@@ -1014,13 +1014,18 @@ static void launch_side(const PacxTables &T, const PacxPcmView &in, const uint8_
                         hipStream_t st)
 {
     const dim3 grid((unsigned)n_cf), block(64);
-    if ((!short_blocks || mixed) && sbr_mean)
+    /* mixed batches may be launched in two parts on two streams: PACX_PART_LONG / PACX_PART_SHORT
+       in the upper bits of `mixed` (pacx_dev.h) */
+    const int part = mixed >> 4;
+    mixed &= 15;
+    const bool do_long = (!short_blocks || mixed) && part != 2, do_short = (short_blocks || mixed) && part != 1;
+    if (do_long && sbr_mean)
         hipLaunchKernelGGL((k_side_long<DT, FAST, false>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks,
                            n_peaks, n_kept, sbr_mean, sbr_overall);
-    else if (!short_blocks || mixed)
+    else if (do_long)
         hipLaunchKernelGGL((k_side_long<DT, FAST, true>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks,
                            n_peaks, n_kept, sbr_mean, sbr_overall);
-    if (short_blocks || mixed)
+    if (do_short)
         hipLaunchKernelGGL((k_side_short<DT, FAST>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks, n_peaks, n_kept);
 }
 
@@ -1050,9 +1055,11 @@ void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long 
 {
     if (n_cf <= 0)
         return;
+    const int part = mixed >> 4;               /* PACX_PART_LONG / PACX_PART_SHORT, see launch_side */
+    mixed &= 15;
     /* persistent grids: MASK_WAVES x 8 KB of running maxima + the LDS tables per workgroup,
        MASK_WG_PER_CU workgroups per CU for the long kernel */
-    if (!short_blocks || mixed) {
+    if ((!short_blocks || mixed) && part != 2) {
         long long blocks = (n_cf + MASK_WAVES - 1) / MASK_WAVES;
         if (blocks > (long long)MASK_WG_PER_CU * n_cu)
             blocks = (long long)MASK_WG_PER_CU * n_cu;
@@ -1065,7 +1072,7 @@ void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long 
                                flags, n_ch, n_cf, mixed, peaks, n_peaks, lines, smr, thr_out,
                                mixed ? list_long : nullptr, counts, MaskTail{});
     }
-    if (short_blocks || mixed) {
+    if ((short_blocks || mixed) && part != 1) {
         const long long units = n_cf * PACX_SUB;
         long long blocks = (units + MASK_WAVES - 1) / MASK_WAVES;
         if (blocks > (32LL / MASK_WAVES) * n_cu)

@@ -859,10 +859,13 @@ void pacx_launch_tail(const PacxTables &T, const uint8_t *flags, int n_ch, long 
        waves).  Mixed streams: one frame per wave -- the waves of short-coded frames leave at
        once, and the long ones that remain fit the chip in one round, so the shorter chain per
        wave wins */
-    if (!skip_long)
+    /* skip_long: 0 = long and short frames, 1 = short frames only, 2 = long frames only */
+    if (skip_long != 1)
         hipLaunchKernelGGL(k_tail_long, dim3((unsigned)(mixed ? n_cf : (n_cf + 1) / 2)), dim3(64), 0, st, T, flags,
                            n_ch, n_cf, mixed, smr, lines, overall, bit_alloc, scale_factor, mantissa, status, payload,
                            payload_stride, n_bytes);
+    if (skip_long == 2)
+        return;
     if (mixed && list_short && T.nb_short <= 8) {
         /* short frames: one fused workgroup each, over the compacted list */
         hipLaunchKernelGGL(k_tail_short, dim3((unsigned)n_cf), dim3(256), 0, st, T, flags, n_ch, list_short,

@@ -66,6 +66,12 @@ struct __attribute__((aligned(8))) PacxPeak {
     double slope;   /* -27 + 0.367*max(spl-40,0): upper-side slope, dB/Bark   */
 };
 
+/* a mixed (block-switched) batch splits into two independent chains -- long-coded frames and
+   short-coded frames -- that the entry points put on different streams: the launchers take
+   the part in the upper bits of their `mixed` argument (0 = both parts) */
+#define PACX_PART_LONG  (1 << 4)
+#define PACX_PART_SHORT (2 << 4)
+
 /* outputs of the tail fused into the long mask kernel (k_psy.hip k_mask<1024, true>) */
 struct MaskTail {
     const int32_t *overall;     /* [cf][8], from the MDCT kernel              */

@@ -177,18 +177,20 @@ __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, in
         }
     }
     /* PACX_ST_GUARD: a band whose final Ropt - level sits within PACX_GUARD_ALLOC_ERR of a
-       rounding boundary k + 1/2 (np.round at coder/bitalloc.py:103), or of the 2-bit / 16-bit
-       limits of :104-107.  `want`, `frac` and the ladder level belong to the last pass. */
+       rounding boundary k + 1/2 (np.round at coder/bitalloc.py:103).  The band the ladder level
+       was taken from is at k + 1/2 by construction (want - (frac(want) - 1/2)), in the
+       reference's arithmetic as in this one: it is not what the flag is about. */
     {
         double level = 0.0;
+        bool sel = false;
         if (n_flip > 0 && n_flip <= nd) {
-            const bool sel = posf && lt <= n_flip - 1 && n_flip - 1 < le;
+            sel = posf && lt <= n_flip - 1 && n_flip - 1 < le;
             const unsigned smask = (unsigned)(__builtin_amdgcn_ballot_w64(sel) >> (32 * half));
             level = __shfl(frac, smask ? __builtin_ctz(smask) : 0, 32);
         }
         const double r = want - level;
         const double d = fabs((r - floor(r)) - 0.5);
-        const bool near = alive && valid && d <= PACX_GUARD_ALLOC_ERR;
+        const bool near = alive && valid && !sel && d <= PACX_GUARD_ALLOC_ERR;
         if ((unsigned)(__builtin_amdgcn_ballot_w64(near) >> (32 * half)))
             cap |= 2;
     }
