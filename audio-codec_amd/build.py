@@ -222,6 +222,27 @@ def build_phase_debug():
     return out
 
 
+def build_variant(name, defines):
+    """variants/libpacx_<name>.so: the library with extra -D flags on some sources, for A/B
+    measurements through PACX_LIB (never loaded by default).  defines: {source: [flags]}."""
+    build(verbose=False)
+    out_dir = os.path.join(HERE, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    objs = []
+    for s in SOURCES:
+        if s in defines:
+            obj = os.path.join(out_dir, s.replace(".hip", f"_{name}.o"))
+            flags = [f for f in FLAGS if not f.startswith("-Rpass")]
+            subprocess.check_call([_hipcc()] + flags + list(defines[s]) + ["-c", os.path.join(CSRC, s), "-o", obj],
+                                  stderr=subprocess.DEVNULL)
+            objs.append(obj)
+        else:
+            objs.append(os.path.join(OBJ, s.replace(".hip", ".o")))
+    out = os.path.join(out_dir, f"libpacx_{name}.so")
+    subprocess.check_call([_hipcc(), "-shared", "--offload-arch=gfx950", "-o", out] + objs)
+    return out
+
+
 def build_tools():
     """tools/*.hip -> variants/<name> (stand-alone HIP programs, measuring aids)."""
     out_dir = os.path.join(HERE, "variants")
@@ -238,7 +259,16 @@ def build_tools():
 
 
 if __name__ == "__main__":
-    if "--tools" in sys.argv:
+    if "--variant" in sys.argv:            # --variant name source.hip -DX=1 [source2.hip -DY ...]
+        i = sys.argv.index("--variant")
+        name, rest, defs, cur = sys.argv[i + 1], sys.argv[i + 2:], {}, None
+        for a in rest:
+            if a.endswith(".hip"):
+                cur = defs.setdefault(a, [])
+            else:
+                cur.append(a)
+        print(build_variant(name, defs))
+    elif "--tools" in sys.argv:
         print(build_tools())
     elif "--phase-debug" in sys.argv:
         print(build_phase_debug())

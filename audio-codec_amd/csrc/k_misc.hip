@@ -74,9 +74,53 @@ __global__ __launch_bounds__(64) void k_transient(PacxPcmView in, long long n_ho
         return;
     const short *base = (const short *)in.base + h * in.frame_stride;
     const int n_ch = in.n_ch < 8 ? in.n_ch : 8;
-    /* pass 1: per channel the peak magnitude and its first position */
     int upto = 0;
     int peak_c[8];
+    long long total = 0;
+    const bool fast = hop == 1024 && in.samp_stride == 1 && n_ch <= 2 && (in.frame_stride & 7) == 0 &&
+                      (in.ch_stride & 7) == 0 && ((uintptr_t)in.base & 15) == 0;
+    if (fast) {
+        /* unit-stride hops of 1024 samples: 16 samples per lane and channel in two 16-byte loads,
+           kept in registers for both passes (lane l owns samples 8 l + 512 j .. + 7, j = 0, 1) */
+        int mag[2][16];
+        for (int ch = 0; ch < n_ch; ++ch) {
+            const int4 *src = (const int4 *)(base + (long long)ch * in.ch_stride);
+            const int4 q[2] = {src[lane], src[lane + 64]};
+            int best = -1, where = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int c = (k & 1) ? (w[k >> 1] >> 16) : (int)(short)(w[k >> 1] & 0xFFFF);
+                    const int m = (c < 0 ? -c : c) & 32767;
+                    mag[ch][8 * j + k] = m;
+                    if (m > best) { best = m; where = 8 * lane + 512 * j + k; }     /* ascending inside the lane */
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {      /* wave arg-max, lowest index wins ties */
+                const int ob = __shfl_xor(best, off, 64), ow = __shfl_xor(where, off, 64);
+                if (ob > best || (ob == best && ow < where)) { best = ob; where = ow; }
+            }
+            peak_c[ch] = best;
+            upto = max(upto, where + 500);
+        }
+        if (upto > 2 * hop)
+            upto = 2 * hop;
+        const int cols = upto < hop ? upto : hop;
+        for (int ch = 0; ch < n_ch; ++ch) {
+            int part = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    part += (8 * lane + 512 * j + k < cols) ? mag[ch][8 * j + k] : 0;
+            for (int off = 32; off > 0; off >>= 1)
+                part += __shfl_xor(part, off, 64);
+            total += part;
+        }
+    } else {
+    /* pass 1: per channel the peak magnitude and its first position */
     for (int ch = 0; ch < n_ch; ++ch) {
         const short *src = base + (long long)ch * in.ch_stride;
         int best = -1, where = 0;
@@ -96,7 +140,6 @@ __global__ __launch_bounds__(64) void k_transient(PacxPcmView in, long long n_ho
         upto = 2 * hop;
     const int cols = upto < hop ? upto : hop;            /* columns that are not padding zeros */
     /* pass 2: sum of |c| over the first `cols` samples of every channel (exact) */
-    long long total = 0;
     for (int ch = 0; ch < n_ch; ++ch) {
         const short *src = base + (long long)ch * in.ch_stride;
         int part = 0;
@@ -107,6 +150,7 @@ __global__ __launch_bounds__(64) void k_transient(PacxPcmView in, long long n_ho
         for (int off = 32; off > 0; off >>= 1)
             part += __shfl_xor(part, off, 64);
         total += part;
+    }
     }
     if (lane == 0) {
         bool tr = false;
@@ -174,11 +218,67 @@ __global__ __launch_bounds__(256) void k_frame_lists(const uint8_t *__restrict__
     }
 }
 
+/* the same lists for batches of up to a few thousand frames, by ONE workgroup: no counters to
+ * zero first (a memset launch), no atomics, and the lists come out in frame order */
+#define LISTS_SMALL_MAX 16384
+__global__ __launch_bounds__(1024) void k_frame_lists_small(const uint8_t *__restrict__ flags, long long n_frames,
+                                                            int n_ch, int32_t *__restrict__ list_long,
+                                                            int32_t *__restrict__ list_short,
+                                                            int32_t *__restrict__ counts)
+{
+    __shared__ int ws[16], wl[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int run_s = 0, run_l = 0;                              /* frames placed so far (all threads agree) */
+    for (long long base = 0; base < n_frames; base += 1024) {
+        const long long f = base + tid;
+        const bool in_range = f < n_frames;
+        const bool is_short = in_range && (flags[f] & 2u);
+        const bool is_long = in_range && !is_short;
+        const unsigned long long ms = __ballot(is_short), ml = __ballot(is_long);
+        if (lane == 0) {
+            ws[wv] = __popcll(ms);
+            wl[wv] = __popcll(ml);
+        }
+        __syncthreads();
+        int before_s = 0, before_l = 0, all_s = 0, all_l = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            before_s += w < wv ? ws[w] : 0;
+            before_l += w < wv ? wl[w] : 0;
+            all_s += ws[w];
+            all_l += wl[w];
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (is_short) {
+            const int at = (run_s + before_s + __popcll(ms & below)) * n_ch;
+            for (int c = 0; c < n_ch; ++c)
+                list_short[at + c] = (int32_t)(f * n_ch + c);
+        }
+        if (is_long) {
+            const int at = (run_l + before_l + __popcll(ml & below)) * n_ch;
+            for (int c = 0; c < n_ch; ++c)
+                list_long[at + c] = (int32_t)(f * n_ch + c);
+        }
+        run_s += all_s;
+        run_l += all_l;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        counts[0] = run_l * n_ch;
+        counts[1] = run_s * n_ch;
+    }
+}
+
 void pacx_launch_frame_lists(const uint8_t *flags, long long n_frames, int n_ch, int32_t *list_long,
                              int32_t *list_short, int32_t *counts, hipStream_t st)
 {
     if (n_frames <= 0)
         return;
+    if (n_frames <= LISTS_SMALL_MAX) {
+        hipLaunchKernelGGL(k_frame_lists_small, dim3(1), dim3(1024), 0, st, flags, n_frames, n_ch, list_long,
+                           list_short, counts);
+        return;
+    }
     (void)hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st);
     hipLaunchKernelGGL(k_frame_lists, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, flags, n_frames,
                        n_ch, list_long, list_short, counts);
