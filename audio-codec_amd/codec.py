@@ -168,8 +168,7 @@ def Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams
     `mantissa` is line-indexed, as PACFile.getDecodedBlock builds it."""
     import torch
     if getattr(codingParams, "useVQ", False):
-        raise NotImplementedError("gain-shape blocks are decoded from their payload: use "
-                                  "PACFile.ReadDataBlock / pacfile.decode_stream (pacx_decode_vq_batch)")
+        return _decode_vq(bitAlloc, overallScaleFactor, pb, codingParams, lastTrans, curTrans, nextTrans, sbr=False)
     enc = context.encoder_for_params(codingParams)
     n_lines = codingParams.nMDCTLines
     if n_lines not in (1024, 128) or bool(curTrans) != (n_lines == 128):
@@ -187,3 +186,87 @@ def Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams
     codes["mantissa"][0, :n_lines] = torch.as_tensor(np.asarray(mantissa, dtype=np.int32)[:n_lines], device=dev)
     block = enc.decode(codes, 1, want_blocks=True, want_pcm=False)[0].cpu().numpy()
     return block[448:448 + 256].copy() if curTrans else block
+
+
+class _Bits:
+    """MSB-first bit string under construction (the payload handed to pacx_decode_vq_batch)."""
+
+    def __init__(self):
+        self.acc, self.n = 0, 0
+
+    def put(self, value, width):
+        if width:
+            self.acc = (self.acc << width) | (int(value) & ((1 << width) - 1))
+            self.n += width
+
+    def tobytes(self):
+        pad = -self.n % 8
+        return ((self.acc << pad)).to_bytes((self.n + pad) // 8, "big")
+
+
+def _decode_vq(bitAlloc, overallScaleFactor, pb, codingParams, lastTrans, curTrans, nextTrans, sbr):
+    """useVQ branch of codec.Decode (coder/codec.py:47-92) and codec.Decode_SBR (:95-222) for one
+    channel.  The reference walks `pb` (its PackedBits cursor, positioned behind the
+    allocations) band by band through dequantize_gain_shape; here the bits of the coded bands
+    are taken from the same cursor with its own ReadBits -- exactly as many as the reference
+    consumes: bitAlloc * nLines per coded band, an SBR-omitted band counting one line
+    (:121-134) -- put back behind a rebuilt block header, and the block is decoded on the GPU
+    (pacx_decode_vq_batch: index decoding, mid/side recombination, gains, SBR reconstruction,
+    IMDCT, window).  Any object with ReadBits(nBits) serves as `pb`."""
+    import torch
+    cp = codingParams
+    enc = context.encoder(cp.sampleRate, cp.targetBitsPerSample, cp.nScaleBits, cp.nMantSizeBits,
+                          getattr(cp, "sfBands", None), getattr(cp, "sfBandsShort", None),
+                          use_vq=True, use_sbr=bool(sbr))
+    bands = enc.sfBandsShort if curTrans else enc.sfBands
+    nb = bands.nBands
+    if len(bitAlloc) != nb:
+        raise ValueError("bitAlloc must hold one entry per scale factor band")
+    omitted = set(int(b) for b in getattr(cp, "omittedBands", [])) if sbr else set()
+    bits = _Bits()
+    bits.put(int(bool(lastTrans)), 1)
+    bits.put(int(bool(curTrans)), 1)
+    bits.put(int(bool(nextTrans)), 1)
+    n_sub = _lib.SUB if curTrans else 1
+    for sub in range(n_sub):                         # a lone short block sits in sub-block 0
+        first = sub == 0
+        bits.put(int(overallScaleFactor) if first else 0, cp.nScaleBits)
+        for b in range(nb):
+            ba = int(bitAlloc[b]) if first else 0
+            bits.put(ba - 1 if ba else 0, cp.nMantSizeBits)
+        if first:
+            for b in range(nb):
+                ba = int(bitAlloc[b])
+                left = ba * (1 if (b in omitted and not curTrans) else int(bands.nLines[b]))
+                while left > 0:                      # the reference's own cursor advances as it would there
+                    take = min(left, 24)
+                    bits.put(pb.ReadBits(take), take)
+                    left -= take
+    raw = bits.tobytes()
+    if len(raw) > enc.payload_stride:
+        raise ValueError("channel-block longer than any the coder writes")
+    slot = np.zeros((1, enc.payload_stride), dtype=np.uint8)
+    slot[0, :len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+    out = enc.decode_vq(torch.as_tensor(slot, device=enc.device),
+                        torch.tensor([len(raw)], dtype=torch.int32, device=enc.device), 1,
+                        want_blocks=True, want_pcm=False)
+    st = int(out["status"][0].item())
+    if st & _lib.ST_MALFORMED:
+        raise RuntimeError("Only read a partial block of coded PACFile data")
+    if st & _lib.ST_VQ_UNDEFINED:
+        raise RuntimeError("gain-shape block the reference's decoder fails on (PACX_ST_VQ_UNDEFINED)")
+    block = out["blocks"][0].cpu().numpy()
+    return block[448:448 + 256].copy() if curTrans else block
+
+
+def Decode_SBR(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,
+               lastTrans=False, curTrans=False, nextTrans=False):
+    """coder/codec.py:95-222 (long block of an SBR file, gain-shape coder): dequantised lines,
+    spectral band replication (Gaussian-smoothed envelope, order-1 spline transposition,
+    per-band scaling), IMDCT, window.  Scalar-mantissa SBR streams are not produced by the
+    reference's driver (coder/pacfile.py:703-705) and are not decoded here."""
+    if not getattr(codingParams, "useVQ", False):
+        raise NotImplementedError("scalar-mantissa SBR is not produced by the reference's driver")
+    if curTrans:
+        raise ValueError("Decode_SBR decodes long blocks (coder/pacfile.py:661-666)")
+    return _decode_vq(bitAlloc, overallScaleFactor, pb, codingParams, lastTrans, curTrans, nextTrans, sbr=True)

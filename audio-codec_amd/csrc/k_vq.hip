@@ -67,6 +67,16 @@ template <typename T> __device__ __forceinline__ T ldc(const T *p)
     return *(const __attribute__((address_space(4))) T *)(unsigned long long)p;
 }
 
+/* The device library's atan / log / log2(tan) are polynomial evaluations with one or two dozen
+   64-bit coefficients.  Inlined into the band loop the compiler hoists every coefficient out
+   of the loops into a VGPR pair of its own -- some sixty registers held for constants, which
+   is what had this kernel at 168 VGPRs with 20 spilled (the spill reloads sat inside the
+   Horner chains).  As real calls (once or twice per tree node, wave-uniform arguments) the
+   coefficients live only inside the callee. */
+__device__ __attribute__((noinline)) double vq_atan(double x) { return atan(x); }
+__device__ __attribute__((noinline)) double vq_log(double x) { return log(x); }
+__device__ __attribute__((noinline)) double vq_log2_tan(double theta_q) { return log2(tan(fabs(theta_q)) + PACX_EPS); }
+
 /* ---- table access --------------------------------------------------------- */
 __device__ __forceinline__ uint64_t vq_N(const VqView &V, int l, long long k)
 {
@@ -466,7 +476,7 @@ __device__ __forceinline__ bool vq_quad_try(const VqView &V, VqOut &o, const dou
         m = m / m_l2;
     if (s_l2 != 0.0)
         sd = sd / s_l2;
-    const double theta = (m_l2 == 0.0) ? 0.0 : atan(s_l2 / m_l2);
+    const double theta = (m_l2 == 0.0) ? 0.0 : vq_atan(s_l2 / m_l2);
     const int a_theta = (int)floor((double)bits / (double)hh + ldc(&V.half_log2[hh]));
     int a_rest = bits - a_theta;
     if (a_rest < 0)
@@ -495,7 +505,7 @@ __device__ __forceinline__ bool vq_quad_try(const VqView &V, VqOut &o, const dou
         if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta_q > 0.0)
             lt = V.log2_tan[((1 << (a_theta - 1)) - 1) + (int)code];
         else
-            lt = log2(tan(fabs(theta_q)) + PACX_EPS);
+            lt = vq_log2_tan(theta_q);
         const double v = ((double)a_rest - (double)(hh - 1) * lt) / 2.0;
         const double f = floor(v);
         a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
@@ -568,7 +578,7 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
                     sv[i] = sv[i] / s_l2;
             }
             vq_fence();
-            const double theta = (m_l2 == 0.0) ? 0.0 : atan(s_l2 / m_l2);
+            const double theta = (m_l2 == 0.0) ? 0.0 : vq_atan(s_l2 / m_l2);
             /* gain_shape_alloc(bits, half): floor(bits/half + 0.5 log2(half)) for the angle */
             int a_theta = (int)floor((double)bits / (double)half + ldc(&V.half_log2[half]));
             int a_rest = bits - a_theta;
@@ -610,7 +620,7 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
                 if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta_q > 0.0)
                     lt = V.log2_tan[((1 << (a_theta - 1)) - 1) + (int)theta_code];
                 else
-                    lt = log2(tan(fabs(theta_q)) + PACX_EPS);
+                    lt = vq_log2_tan(theta_q);
                 const double v = ((double)a_rest - (double)(half - 1) * lt) / 2.0;
                 const double f = floor(v);
                 a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
@@ -847,7 +857,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
         const double gain = gain_s[b];
         if (b >= first_omit) {
             /* L = 1: every bit goes to the gain (gain_shape_alloc(R, 1)) */
-            const double g = log(1.0 + 255.0 * fabs(gain / 1.0)) / V.log_mu1;
+            const double g = vq_log(1.0 + 255.0 * fabs(gain / 1.0)) / V.log_mu1;
             vq_quantize_emit(o, g, ba, lane);
         } else {
             const int lo = ldc(&lower[b]), cnt = ldc(&count[b]);
@@ -867,7 +877,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
             }
             if (bits_gain < 0)
                 bits_gain = 0;
-            const double g = log(1.0 + 255.0 * fabs(gain / (double)cnt)) / V.log_mu1;
+            const double g = vq_log(1.0 + 255.0 * fabs(gain / (double)cnt)) / V.log_mu1;
             vq_quantize_emit(o, g, bits_gain, lane);
         }
         if (o.pos != start_s[b + 1])

@@ -93,8 +93,14 @@ class PACFile(AudioFile):
 
     def Decode(self, scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,
                lastTrans=False, curTrans=False, nextTrans=False):
-        """coder/pacfile.py:645-668 (no SBR)."""
-        return codec.Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,
+        """coder/pacfile.py:645-668: Decode_SBR for a long block of an SBR file that codes an
+        omitted band, codec.Decode otherwise."""
+        cp = codingParams
+        if getattr(cp, "useSBR", False) and not curTrans and len(getattr(cp, "omittedBands", [])) and \
+                np.any(np.array(bitAlloc)[np.array(cp.omittedBands)] != 0):
+            return codec.Decode_SBR(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, cp,
+                                    lastTrans, curTrans, nextTrans)
+        return codec.Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, cp,
                             lastTrans, curTrans, nextTrans)
 
     def ReadFileHeader(self):

@@ -39,7 +39,7 @@ HOT = [
     (r"^k_tail_long\(", 128, 4),
     (r"^k_tail_short\(", 72, 7),
     (r"^k_gather_small\(", None, None),
-    pytest.param(r"^k_vq\(", 168, 3, marks=pytest.mark.xfail(strict=True, reason="20 spilled VGPRs at 3 waves/SIMD (needs 200)")),
+    (r"^k_vq\(", 128, 3),
     (r"^k_vq_join\(", None, None),
     (r"^k_vq_dec\(", 168, 3),
     (r"^k_unpack\(", None, None),
@@ -71,7 +71,7 @@ def test_every_kernel_is_reported(res):
 
 def test_only_listed_kernels_use_scratch(res):
     """anything else with scratch is a function-level mirror off the hot path, named here"""
-    allowed = {"k_bitalloc_generic", "k_vq("}        # serial reference-shaped BitAlloc (bitalloc.BitAlloc mirror), one lane per call
+    allowed = {"k_bitalloc_generic"}        # serial reference-shaped BitAlloc (bitalloc.BitAlloc mirror), one lane per call
     for name, r in res.items():
         if r["scratch"] or r["vgpr_spill"]:
             assert any(a in name for a in allowed), f"{name}: scratch {r['scratch']}, spilled {r['vgpr_spill']}"

@@ -336,3 +336,60 @@ def test_rich_synthetic_stream_vs_oracle(A, kbps):
     got = A.pacfile.encode_stream(pcm, 48000, kbps, block_switching=True, use_vq=True, use_sbr=kbps < 128)
     assert got == want, describe_diff(got, want)
     assert np.array_equal(A.pacfile.decode_stream(got), pv.decode_stream_vq(want))
+
+
+# ------------------------------------------- codec.Decode / Decode_SBR on gain-shape blocks
+@pytest.mark.parametrize("kbps", [128, 96])
+def test_codec_decode_on_gain_shape_blocks(A, kbps):
+    """codec.Decode with useVQ (coder/codec.py:47-92) and codec.Decode_SBR (:95-222) called the
+    way PACFile.getDecodedBlock calls them (coder/pacfile.py:177-229): flags, overall scale and
+    allocations already read, `pb` a bit cursor standing at the first coded band.  Blocks of the
+    reference's own castanet stream (long, short and -- at 96 kb/s -- SBR blocks) against the
+    oracle's decode_block_vq; the cursor must end where the reference's would."""
+    from oracle import pac_oracle as po
+    from oracle import pac_oracle_vq as pv
+    ex = np.load(os.path.join(GOLDEN, "excerpt_vq_castanet.npz"))
+    pac = bytes(ex[f"pac_vq{kbps}"])
+    head, blocks = split_blocks(pac)
+    cp, _ = A.pacfile.parse_header(head)
+    cp.omittedBands = A.pacfile.omitted_bands(cp.sfBands) if cp.useSBR else []
+    p = pv.make_params_vq(cp.sampleRate, cp.nChannels, kbps)
+
+    class Cursor:                      # the reference's PackedBits, as far as Decode uses it
+        def __init__(self, data):
+            self.br = po.BitReader(data)
+
+        def ReadBits(self, n):
+            return self.br.get(n)
+
+    seen = {"long": 0, "short": 0, "sbr": 0}
+    for blk in blocks[:40]:
+        cur, ref = Cursor(blk), po.BitReader(blk)
+        fl = [cur.ReadBits(1) for _ in range(3)]
+        assert fl == [ref.get(1) for _ in range(3)]
+        last_t, cur_t, next_t = fl
+        n_sub = 8 if cur_t else 1
+        bands = cp.sfBandsShort if cur_t else cp.sfBands
+        cp.nMDCTLines = 128 if cur_t else 1024
+        p.nMDCTLines = p.nSamplesPerBlock = cp.nMDCTLines
+        try:
+            for _ in range(n_sub):
+                want = pv.decode_block_vq(ref, p, last_t, cur_t, next_t)
+                overall = cur.ReadBits(cp.nScaleBits)
+                alloc = []
+                for b in range(bands.nBands):
+                    a = cur.ReadBits(cp.nMantSizeBits)
+                    alloc.append(a + 1 if a else 0)
+                pf = A.pacfile.PACFile.__new__(A.pacfile.PACFile)
+                got = pf.Decode(None, alloc, None, overall, cur, cp, last_t, cur_t, next_t)
+                sbr = bool(cp.useSBR and not cur_t and np.any(np.array(alloc)[np.array(cp.omittedBands, dtype=int)] != 0))
+                seen["sbr" if sbr else ("short" if cur_t else "long")] += 1
+                assert got.shape == want.shape
+                assert np.max(np.abs(got - want)) <= 1e-12 * max(np.max(np.abs(want)), 1e-300)
+                assert cur.br.pos == ref.pos           # the cursor ends where the reference's would
+        finally:
+            cp.nMDCTLines = 1024
+            p.nMDCTLines = p.nSamplesPerBlock = 1024
+    assert seen["long"] + seen["sbr"] > 0 and seen["short"] > 0
+    if kbps < 128:
+        assert seen["sbr"] > 0
