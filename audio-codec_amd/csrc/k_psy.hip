@@ -67,6 +67,11 @@ extern "C" int pacx_debug_read_psy(long long *out, int n)
 #define SIDE_T(k) do { } while (0)
 #endif
 
+/* SPL(Intensity(.)) of the winning masker level as a real call: inlined, the device library's
+   exp2 brings a dozen 64-bit polynomial coefficients that the compiler hoists out of the
+   frame loop into registers of their own */
+__device__ __attribute__((noinline)) double mask_round_trip(double x) { return pacx_spl_of_intensity_of(x); }
+
 /* one tonal masker from bins f-1, f (coder/psychoac.py:321-328, :61-68) */
 __device__ __forceinline__ PacxPeak make_peak(double left, double centre, int f, double fstep)
 {
@@ -646,7 +651,9 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
        fetched by all lanes with two broadcast LDS reads -- the LDS pipe idles in this
        kernel, the VALU is its bound, and six v_readlane + two v_mov per survivor were
        40 % of the evaluation loop's VALU instructions */
-    __shared__ __attribute__((aligned(16))) double mks[MASK_WAVES][64][4];
+    /* (z, spl) pairs and slopes apart: 24 bytes per masker, every read aligned */
+    __shared__ __attribute__((aligned(16))) double2 mk_zs_all[MASK_WAVES][64];
+    __shared__ __attribute__((aligned(16))) double mk_u_all[MASK_WAVES][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *__restrict__ bark_g = SHORT ? T.bark_short : T.bark_long;
     const double *__restrict__ quiet_g = SHORT ? T.thresh_short : T.thresh_long;
@@ -673,7 +680,8 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     __syncthreads();
 
     double *buf = bufs[wv];
-    double (*mk)[4] = mks[wv];
+    double2 *mk_zs = mk_zs_all[wv];
+    double *mk_u = mk_u_all[wv];
     const int nb = SHORT ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
@@ -743,9 +751,8 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
             const double b_lvl = wave_max_upper(lvl);
             const double b_slope = wave_max_upper(q.slope);
             wave_lds_fence();                      /* the previous batch's reads are done */
-            mk[lane][0] = q.z;
-            mk[lane][1] = q.spl;
-            mk[lane][2] = q.slope;
+            mk_zs[lane] = make_double2(q.z, q.spl);
+            mk_u[lane] = q.slope;
             wave_lds_fence();
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
@@ -794,8 +801,8 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                     double pus[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        zs[u] = *(const double2 *)mk[bs[u]];             /* broadcast reads */
-                        pus[u] = mk[bs[u]][2];
+                        zs[u] = mk_zs[bs[u]];                            /* broadcast reads */
+                        pus[u] = mk_u[bs[u]];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -831,7 +838,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
             }
             const double bst = buf[k];
             if (bst > -INFINITY)
-                thr = fmax(thr, pacx_spl_of_intensity_of(bst));
+                thr = fmax(thr, mask_round_trip(bst));
             if (thr_out)
                 thr_out[loff + k] = thr;
             /* pacx_spl_array((v * v) * 4.0), coder/psychoac.py:10-25, with the lean log10 of

@@ -89,6 +89,12 @@ __device__ __forceinline__ double vqd_wave_sum(double v)
     return v;
 }
 
+/* device-library polynomials as real calls: inlined, their coefficients are hoisted out of the
+   band loops into registers of their own (see k_vq.hip) */
+__device__ __attribute__((noinline)) double vqd_cos(double x) { return cos(x); }
+__device__ __attribute__((noinline)) double vqd_sin(double x) { return sin(x); }
+__device__ __attribute__((noinline)) double vqd_pow256(double y) { return pow(256.0, y); }
+
 /* up to 64 bits from the MSB-first word array */
 __device__ __forceinline__ unsigned long long vqd_get(const unsigned *words, int pos, int width)
 {
@@ -393,7 +399,7 @@ __device__ __forceinline__ void vqd_shape(const VqDecView &V, const unsigned *wo
         /* phase 2: left/right from mid/side (:455-466) */
         {
             const VqdFrame F = fr[depth];
-            const double ct = cos(F.theta), st = sin(F.theta);
+            const double ct = vqd_cos(F.theta), st = vqd_sin(F.theta);
             const double root2 = sqrt(2.0);
             const int cut = F.n / 2;
             const double *mid = scr + F.reg, *side = scr + F.reg + F.half;
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
                 deq = -deq;
         }
         const double sgn = (deq > 0.0) ? 1.0 : ((deq < 0.0) ? -1.0 : 0.0);
-        const double gain = (sgn / 255.0 * (pow(256.0, fabs(deq)) - 1.0)) * (double)n;
+        const double gain = (sgn / 255.0 * (vqd_pow256(fabs(deq)) - 1.0)) * (double)n;
         double *dst = lines_s + (shrt ? s * PACX_M_SHORT : 0) + at;
         for (int i = lane; i < n; i += 64)
             dst[i] = gain * scr[i];
