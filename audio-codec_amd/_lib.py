@@ -53,6 +53,7 @@ class PacxConfig(ctypes.Structure):
         ("line_freq_long", c_double_p),
         ("kbd_long", c_double_p),
         ("kbd_short", c_double_p),
+        ("guard", ctypes.c_int32),
     ]
 
 

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void k_mdct_short(PacxTables T, PacxPcmView in,
         if (r == 0)
             scale_out[cf * PACX_SUB + g] = pacx_scale_factor(mx, T.n_scale_bits, 5);
         /* PACX_ST_GUARD: a sub-block maximum at a boundary of ScaleFactor (pacx_exact.h) */
-        const bool guard = status && pacx_scale_guard(mx, T.n_scale_bits, 5, PACX_GUARD_LINE_ERR * mx);
+        const bool guard = T.guard && status && pacx_scale_guard(mx, T.n_scale_bits, 5, PACX_GUARD_LINE_ERR * mx);
         if (__builtin_amdgcn_ballot_w64(guard) && lane == 0)
             atomicOr(&status[cf], 16u);
     }

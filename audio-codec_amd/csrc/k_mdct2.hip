@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * MDCT2_WAVES, 2) void k_mdct_long_v2(
             for (int bit = T.n_scale_bits - 1; bit >= 0; --bit)
                 if (!__builtin_amdgcn_ballot_w64(s < lo + (1 << bit)))
                     lo += 1 << bit;
-            guard = status_init && s == lo && pacx_scale_guard(mx, T.n_scale_bits, 5, 2.0 * PACX_GUARD_LINE_ERR * mx);   /* PACX_ST_GUARD, as k_mdct3.hip */
+            guard = T.guard && status_init && s == lo && pacx_scale_guard(mx, T.n_scale_bits, 5, 2.0 * PACX_GUARD_LINE_ERR * mx);   /* PACX_ST_GUARD, as k_mdct3.hip */
         }
         double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);
 #pragma unroll

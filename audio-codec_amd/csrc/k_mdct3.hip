@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
             /* PACX_ST_GUARD: the lanes that decide the minimum hold a maximum within a factor
                two of the block's; theirs sitting at a boundary of ScaleFactor flags the frame
                (line error bound relative to the block maximum, pacx_exact.h) */
-            guard = status_init && s == lo && pacx_scale_guard(mx, T.n_scale_bits, 5, 2.0 * PACX_GUARD_LINE_ERR * mx);
+            guard = T.guard && status_init && s == lo && pacx_scale_guard(mx, T.n_scale_bits, 5, 2.0 * PACX_GUARD_LINE_ERR * mx);
         }
         double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);
         static_assert(EPI_STORES * 64 * 2 == PACX_M_LONG, "one epilogue = EPI_STORES 16-byte stores per lane");

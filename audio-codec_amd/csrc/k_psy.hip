@@ -67,10 +67,15 @@ extern "C" int pacx_debug_read_psy(long long *out, int n)
 #define SIDE_T(k) do { } while (0)
 #endif
 
-/* SPL(Intensity(.)) of the winning masker level as a real call: inlined, the device library's
-   exp2 brings a dozen 64-bit polynomial coefficients that the compiler hoists out of the
-   frame loop into registers of their own */
+/* SPL(Intensity(.)) of the winning masker level (inlined: the device library's exp2 brings a
+   dozen 64-bit polynomial coefficients that the compiler hoists out of the frame loop into
+   registers of their own, but here that costs no occupancy and a call per line costs time) */
+#ifdef MASK_NOINLINE_RT          /* A/B switch: as a real call the kernels need 17-19 fewer registers
+                                    (no occupancy step is crossed) and the step runs 2.8 % slower */
 __device__ __attribute__((noinline)) double mask_round_trip(double x) { return pacx_spl_of_intensity_of(x); }
+#else
+__device__ __forceinline__ double mask_round_trip(double x) { return pacx_spl_of_intensity_of(x); }
+#endif
 
 /* one tonal masker from bins f-1, f (coder/psychoac.py:321-328, :61-68) */
 __device__ __forceinline__ PacxPeak make_peak(double left, double centre, int f, double fstep)
@@ -899,7 +904,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 const bool has = half == 0 && l < nb;
                 const int nl = has ? n_lines[l] : 0;
                 int bits = 0, cap = 0;
-                bitalloc_half(half == 0, has, has ? s_l : 0.0, nl, budget, max_mant, cp + 32 * half, half, l, bits, cap);
+                bitalloc_half(half == 0, has, has ? s_l : 0.0, nl, budget, max_mant, cp + 32 * half, half, l, bits, cap, T.guard != 0);
                 if (has) {
                     tail.bit_alloc[boff + l] = bits;
                     ba_s[l] = bits;
@@ -965,7 +970,8 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                             const int b = band[j];
                             const int a = ba_s[b];
                             mq[u] = a ? pacx_mantissa(x[j], sf_s[b], T.n_scale_bits, a) : 0;
-                            near = near || pacx_quant_guard(fabs(x[j]), (1 << T.n_scale_bits) - 1 + a, PACX_GUARD_LINE_ERR);
+                            if (T.guard)
+                                near = near || pacx_quant_guard(fabs(x[j]), (1 << T.n_scale_bits) - 1 + a, PACX_GUARD_LINE_ERR);
                             if (tail.payload && a)
                                 put_bits(words, offs[b] + (k0 + j - lower_s[b]) * a, (unsigned)mq[u], a);
                         }

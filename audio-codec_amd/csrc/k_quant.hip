@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
     const double s = has ? smr[off + l] : 0.0;
     const int nl = has ? n_lines[l] : 0;
     int bits = 0, cap = 0;
-    bitalloc_half(alive, has, s, nl, budget, max_mant, cp[half], half, l, bits, cap);
+    bitalloc_half(alive, has, s, nl, budget, max_mant, cp[half], half, l, bits, cap, T.guard != 0);
     if (has)
         bit_alloc[off + l] = bits;
     if (alive && cap && status && l == 0)
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64, 4) void k_tail_long(PacxTables T, const uint8_t
         const double sv = has ? smr[boff + l] : 0.0;
         const int nl = has ? n_lines[l] : 0;
         int bits = 0, cap = 0;
-        bitalloc_half(alive, has, sv, nl, budget, max_mant, cp[half], half, l, bits, cap);
+        bitalloc_half(alive, has, sv, nl, budget, max_mant, cp[half], half, l, bits, cap, T.guard != 0);
         if (has) {
             bit_alloc[boff + l] = bits;
             ba_2[half][l] = bits;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_tail_short(PacxTables T, const uint8_t 
         const double sv = has ? smr[off + l] : 0.0;
         const int nl = has ? T.band_lines_short[l] : 0;
         int bits = 0, cap = 0;
-        bitalloc_half(true, has, sv, nl, budget, max_mant, cp[wv][half], half, l, bits, cap);
+        bitalloc_half(true, has, sv, nl, budget, max_mant, cp[wv][half], half, l, bits, cap, T.guard != 0);
         if (has) {
             bit_alloc[off + l] = bits;
             ba_s[sb][l] = bits;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void k_tail_short(PacxTables T, const uint8_t 
         const int a0 = ba_s[sb][band0], a1 = ba_s[sb][band1];
         mant[q][0] = a0 ? pacx_mantissa(x0, sf_s[sb][band0], T.n_scale_bits, a0) : 0;
         mant[q][1] = a1 ? pacx_mantissa(x1, sf_s[sb][band1], T.n_scale_bits, a1) : 0;
-        if (status) {                                     /* PACX_ST_GUARD, see pacx_exact.h */
+        if (status && T.guard) {                          /* PACX_ST_GUARD, see pacx_exact.h */
             const int r0 = (1 << T.n_scale_bits) - 1;
             const bool near = (band0 < nb && pacx_quant_guard(fabs(x0), r0 + a0, PACX_GUARD_LINE_ERR)) ||
                               (band1 < nb && pacx_quant_guard(fabs(x1), r0 + a1, PACX_GUARD_LINE_ERR));

@@ -501,6 +501,7 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     T.target_bps = cfg->target_bits_per_sample;
 
     /* coding variant */
+    T.guard = cfg->guard ? 1 : 0;
     T.use_vq = cfg->use_vq ? 1 : 0;
     T.use_sbr = cfg->use_sbr ? 1 : 0;
     T.first_omitted = T.nb_long;

@@ -51,6 +51,7 @@ struct PacxTables {
     int use_vq, use_sbr;
     int first_omitted;                /* first band of sbr.omitted_bands (they are the tail) */
     const int32_t *band_lines_long_alloc;   /* nLines with omitted bands counted as 1 */
+    int guard;                        /* compute PACX_ST_GUARD (pacx_config.guard) */
 };
 
 struct PacxPcmView {

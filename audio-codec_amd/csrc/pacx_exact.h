@@ -67,6 +67,7 @@ PACX_HD int64_t pacx_quant_mag(double ax, int r_bits)
 
 PACX_HD int pacx_quant_guard(double ax, int r_bits, double err)
 {
+
     const double s = (double)(((int64_t)1 << r_bits) - 1);
     if (ax >= 1.0 - err)
         return ax <= 1.0 + err;                   /* at the clip (beyond it the code is constant) */

@@ -37,7 +37,7 @@ __device__ __forceinline__ int half_sum_i(int v)
  * alive = false). */
 __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, int nl, double budget,
                                               int max_mant, double *c, int half, int l, int &bits_out,
-                                              int &cap_out)
+                                              int &cap_out, bool want_guard = false)
 {
     const unsigned lt_mask = (1u << l) - 1u;
 
@@ -180,7 +180,7 @@ __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, in
        rounding boundary k + 1/2 (np.round at coder/bitalloc.py:103).  The band the ladder level
        was taken from is at k + 1/2 by construction (want - (frac(want) - 1/2)), in the
        reference's arithmetic as in this one: it is not what the flag is about. */
-    {
+    if (want_guard) {
         double level = 0.0;
         bool sel = false;
         if (n_flip > 0 && n_flip <= nd) {
@@ -265,12 +265,21 @@ __device__ __forceinline__ void quantize_long_core(const PacxTables &T, const do
 {
     long_scale_factors(T, lin, up, bmax, ba_s, sf_s, lane, x, band);
     near = false;                                  /* PACX_ST_GUARD of this lane's lines (pacx_exact.h) */
+    if (T.guard) {                                 /* wave-uniform: handles that asked for the flag */
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int b = band[j];
-        const int ba = ba_s[b];
-        mant[j] = ba ? pacx_mantissa(x[j], sf_s[b], T.n_scale_bits, ba) : 0;
-        near = near || pacx_quant_guard(fabs(x[j]), (1 << T.n_scale_bits) - 1 + ba, PACX_GUARD_LINE_ERR);
+        for (int j = 0; j < 16; ++j) {
+            const int b = band[j];
+            const int ba = ba_s[b];
+            mant[j] = ba ? pacx_mantissa(x[j], sf_s[b], T.n_scale_bits, ba) : 0;
+            near = near || pacx_quant_guard(fabs(x[j]), (1 << T.n_scale_bits) - 1 + ba, PACX_GUARD_LINE_ERR);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = band[j];
+            const int ba = ba_s[b];
+            mant[j] = ba ? pacx_mantissa(x[j], sf_s[b], T.n_scale_bits, ba) : 0;
+        }
     }
 }
 

@@ -88,7 +88,8 @@ extern "C" {
                                      gives NaN pulses, a gain index wider than
                                      128 bits): the band's bits are zeros     */
 
-#define PACX_ST_GUARD        16u   /* a rounding decision of this cf sat within a few
+#define PACX_ST_GUARD        16u   /* (handles created with pacx_config.guard = 1)
+                                     a rounding decision of this cf sat within a few
                                      ulps of its boundary: a mantissa / scale-factor
                                      quantiser input (2^R-1)|x|+1 next to an even
                                      integer (coder/quantize.py:73), or a BitAlloc
@@ -166,6 +167,9 @@ typedef struct pacx_config {
     /* KBDWindow(alpha = 4) tables (coder/window.py:53-57), optional: */
     const double *kbd_long;         /* [2*n_lines_long]                              */
     const double *kbd_short;        /* [2*n_lines_short]                             */
+    /* 1: compute PACX_ST_GUARD (rounding decisions near their boundaries) in the whole-path
+       entry points; costs about 3 % of the scalar encode throughput, off by default */
+    int32_t guard;
 } pacx_config;
 
 /* one written field of a gain-shape coded band (see pacx_encode_vq_batch) */

@@ -288,10 +288,15 @@ def test_guard_flag_on_a_corpus_sample(A, torch):
     S = A.synth
     base = S.stream_float(512, 2)
     pcm = np.concatenate([S.to_int16(base, S.tile_scale(t)) for t in (0, 5, 10, 15)])      # 2048 hops
-    enc = A.context.encoder(48000, 128 / 48.0)
+    enc = A.engine.Encoder(48000, 128 / 48.0, guard=True)              # pacx_config.guard = 1
+    plain = A.context.encoder(48000, 128 / 48.0)                       # default handle: no flag, same codes
     planar = torch.as_tensor(S.planar_with_halo(pcm), device=enc.device)
     out = enc.encode_pack(A.engine.PcmView.stream(planar), want_mantissa=True)
     host = {k: v.cpu().numpy() for k, v in out.items() if v is not None and k != "flags"}
+    ref = plain.encode_pack(A.engine.PcmView.stream(planar), want_mantissa=True)
+    assert not (ref["status"].cpu().numpy() & A._lib.ST_GUARD).any()
+    for k in ("overall", "scale_factor", "bit_alloc", "mantissa", "n_bytes"):
+        assert torch.equal(out[k], ref[k]), k
     st = host["status"].astype(np.uint32)
     flagged = np.nonzero(st & A._lib.ST_GUARD)[0]
     n_cf = len(st)
@@ -308,3 +313,43 @@ def test_guard_flag_on_a_corpus_sample(A, torch):
         assert r[3] == ov and r[1].tolist() == ba.tolist(), i
         assert r[0].tolist() == sf.tolist() and r[2].tolist() == mant.tolist(), i
     print(f"PACX_ST_GUARD: {len(flagged)} of {n_cf} channel-frames flagged")
+    enc.close()
+
+
+# ------------------------------------------- BASELINE configs[4]: one rank's shard
+def test_corpus_shard_equals_its_sub_shards(A, torch):
+    """One eighth of the 1 048 576-frame corpus (what one of eight ranks encodes: 131 072 stereo
+    frames = 262 144 channel-frames in ONE call) against the same hops encoded as eight
+    16 384-frame sub-shards with their one-hop halos: the .pac bodies must concatenate to the
+    same bytes.  This is the property the multi-GPU sharding rests on, at full shard size (the
+    large-batch paths: chunked body scan, many iterations per persistent wave)."""
+    S = A.synth
+    lo, hi = 131072 * 3, 131072 * 4                      # rank 3 of 8: tiles 96..127, every level
+    base = S.stream_float(S.TILE_HOPS, 2)
+    enc = A.engine.Encoder(48000, 128 / 48.0, guard=True)
+
+    def body_of(a, b):
+        planar = torch.as_tensor(S.corpus_shard(a, b, base=base), device=enc.device)
+        view = A.engine.PcmView.stream(planar)
+        out = enc.alloc_outputs(view.n_cf, with_payload=True)
+        out["mantissa"] = None
+        enc.encode_pack(view, None, out)
+        body, total = enc.gather_body(out["payload"], out["n_bytes"],
+                                      capacity=A.dist.slot_bytes(view.n_cf, 128 / 48.0))
+        n = int(total.item())
+        st = out["status"].cpu().numpy()
+        return body[:n].clone(), st
+    whole, st_whole = body_of(lo, hi)
+    parts, sts = [], []
+    step = (hi - lo) // 8
+    for k in range(8):
+        b, s = body_of(lo + k * step, lo + (k + 1) * step)
+        parts.append(b)
+        sts.append(s)
+    cat = torch.cat(parts)
+    assert cat.numel() == whole.numel()
+    assert torch.equal(cat, whole)
+    assert np.array_equal(np.concatenate(sts), st_whole)
+    flagged = int(np.count_nonzero(st_whole & A._lib.ST_GUARD))
+    print(f"corpus shard: {whole.numel()} body bytes for {2 * (hi - lo)} channel-frames, {flagged} flagged PACX_ST_GUARD")
+    enc.close()
