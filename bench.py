@@ -118,6 +118,17 @@ def cpu_baseline(vq_kbps=None, frames_per_core=None):
     return out
 
 
+def cpu_baseline_bs(pcm, sample_rate, n_hops_cpu=192):
+    """block-switched workload: the oracle's whole file loop on the first hops of the same stream"""
+    from oracle import pac_oracle as po
+    t0 = time.perf_counter()
+    po.encode_stream(pcm[:n_hops_cpu * 1024], sample_rate, KBPS, block_switching=True)
+    dtc = time.perf_counter() - t0
+    return {"value": (n_hops_cpu + 2) * N_CH / dtc, "unit": "channel-frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_hops_cpu} hops of the same tiled stream through oracle/pac_oracle.py "
+                      f"encode_stream (block switching on), {dtc:.1f} s"}
+
+
 # ------------------------------------------------------------------ verification
 def verify_against_oracle(pcm, sample_rate, kbps, vq_kbps, flags, payload_rows, n_bytes, picks, halo=None):
     """The hops `picks` of the batch (2 channel-frames each) through the oracle; their .pac
@@ -467,15 +478,7 @@ def main():
             res["config"]["ms_per_step_without_gather"] = d2 / args.steps * 1e3
         if not args.no_cpu_baseline and world == 1:
             if block_switched:
-                from oracle import pac_oracle as po
-                n_hops_cpu = 192
-                t0 = time.perf_counter()
-                po.encode_stream(pcm[:n_hops_cpu * 1024], sample_rate, KBPS, block_switching=True)
-                dtc = time.perf_counter() - t0
-                res["cpu_baseline"] = {"value": (n_hops_cpu + 2) * N_CH / dtc, "unit": "channel-frames/s",
-                                       "cores": 1, "kind": "port",
-                                       "sample": f"first {n_hops_cpu} hops of the same tiled stream through "
-                                                 f"oracle/pac_oracle.py encode_stream (block switching on), {dtc:.1f} s"}
+                res["cpu_baseline"] = cpu_baseline_bs(pcm, sample_rate)
             else:
                 res["cpu_baseline"] = cpu_baseline(vq_kbps)
         print(json.dumps(res), flush=True)
