@@ -259,10 +259,24 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
        Z[512-k]: both are made of E[m], O[m], m = 512 - k, which lane 64-lane holds
        in register 7-k3 (lane 0: its own register 8-k3; k = 0 pairs with itself). */
     const int mirror = (64 - lane) & 63;
+    /* the two table entries of an iteration are fetched two iterations ahead: issued where
+       they are used, each pair cost a full round trip to L2 -- eight in a row were half of
+       this kernel's time (in-kernel stamps, profiles/r02_phases_side_mask_tail.txt) */
+    constexpr int AHEAD = 2;
+    cplx w1q[8], w2q[8];
+#pragma unroll
+    for (int k3 = 0; k3 < AHEAD; ++k3) {
+        w1q[k3] = T.w1024[lane + 64 * k3];
+        w2q[k3] = T.w2048[lane + 64 * k3];
+    }
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) {
         const int k = lane + 64 * k3;
-        const cplx w1k = T.w1024[k], w2k = T.w2048[k];
+        if (k3 + AHEAD < 8) {
+            w1q[k3 + AHEAD] = T.w1024[k + 64 * AHEAD];
+            w2q[k3 + AHEAD] = T.w2048[k + 64 * AHEAD];
+        }
+        const cplx w1k = w1q[k3], w2k = w2q[k3];
         const cplx t = c_mul(w1k, od[k3]);
         const cplx zk = c_add(ev[k3], t), zk5 = c_sub(ev[k3], t);
         /* partner E[m], O[m] */
@@ -311,49 +325,60 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
     }
     wave_lds_fence();
     SIDE_T(4);
-    /* pass 2: one masker per lane, 64 at a time (log10 + two atan each); Bark and
-       SPL go to LDS for the pruning scans */
-    /* COMPACT: masker p goes to the intensity slots 2p, 2p+1 (it comes from bins i_p - 1, i_p
-       with i_p >= 2p + 1, and a round of 64 reads its bins before it writes: no slot is read
-       after it has been overwritten); otherwise two lists after the 1 KB index list */
-    constexpr int ZS = COMPACT ? 2 : 1;                    /* stride of the Bark / SPL lists */
-    double *zs = COMPACT ? inten : (double *)Z + 128;
-    double *ss = COMPACT ? inten + 1 : zs + PACX_MAX_PEAKS;
-    for (int p = lane; p < count; p += 64) {
-        const int i = idx[p];
-        const PacxPeak q = make_peak(inten[i - 1], inten[i], i, T.fstep_long);
-        zs[ZS * p] = q.z;
-        ss[ZS * p] = q.spl;
-    }
-    wave_lds_fence();
-    SIDE_T(5);
-    /* pass 3: drop maskers that cannot matter.  A masker p with S_p <= 40 dB has
-       the 27 dB/Bark tent S_p - 16 - 27 max(|z - z_p| - 0.5, 0); any other masker q
-       has a tent at least that steep-sided or shallower, so q >= p EVERYWHERE as
-       soon as S_q - S_p >= 27 |z_q - z_p|.  With maskers sorted in Bark that is
-       one exclusive prefix maximum of S + 27 z and one exclusive suffix maximum
-       of S - 27 z; a 1e-9 dB margin keeps the test clear of rounding.  The
-       maximum over the kept maskers equals the maximum over all of them (on
-       real and synthetic material 60-75 % of the maskers go). */
+    /* pass 2: drop maskers that cannot matter, BEFORE their exact Bark value and SPL are
+       computed (log10 + two atan each -- a quarter of this kernel when done for every peak).
+       A masker p with S_p <= 40 dB has the 27 dB/Bark tent S_p - 16 - 27 max(|z - z_p| - 0.5, 0);
+       any other masker q has a tent at least that steep-sided or shallower, so q >= p
+       EVERYWHERE as soon as S_q - S_p >= 27 |z_q - z_p| (transitive, so dropping dominated
+       maskers never removes the last dominator).  The screen works on bounds:
+         S  within +-1e-3 dB from a float log2 of the two-bin energy;
+         z  between the Bark values of the masker's two bins (its frequency is their
+            intensity-weighted mean), from the bin table with a 1e-9 margin;
+       a masker is dropped only if the bounds prove it dominated, so the maximum over the kept
+       maskers equals the maximum over all of them (60-70 % of the maskers go).  With maskers
+       sorted in Bark that is one exclusive prefix maximum of (S + 27 z) lower bounds and one
+       exclusive suffix maximum of (S - 27 z) lower bounds.  Each lane screens 8 consecutive
+       peaks straight from the intensities. */
+    int n_kept;
     {
-        double zz[8], sv[8], pre[8], suf[8];
+        const double *__restrict__ bb = T.bark_bin_long;
+        double zlo[8], zhi[8], pre[8], suf[8];
+        float shi[8], slo[8];
+        unsigned short bin[8];
         double run_up = -INFINITY, run_dn = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8; ++i) {                       /* bin numbers first (LDS) ... */
             const int p = 8 * lane + i;
-            const bool ok = p < count;
-            zz[i] = ok ? zs[ZS * p] : 0.0;
-            sv[i] = ok ? ss[ZS * p] : -INFINITY;
+            bin[i] = (unsigned short)(p < count ? idx[p] : 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                       /* ... then all sixteen table loads in flight together */
+            zlo[i] = bb[bin[i] - 1];
+            zhi[i] = bb[bin[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = 8 * lane + i < count;
+            const int ib = bin[i];
+            const double e = inten[ib - 1] + inten[ib];
+            /* pacx_spl_scalar: exact zero -> -30, else max(96 + 10 log10(e + eps), -30) */
+            float est = 96.0f + 3.0103f * __log2f((float)(e + PACX_EPS));
+            if (e == 0.0)
+                est = -30.0f;
+            shi[i] = ok ? fmaxf(est + 1e-3f, -30.0f) : -INFINITY;
+            slo[i] = ok ? fmaxf(est - 1e-3f, -30.0f) : -INFINITY;
+            zlo[i] -= 1e-9;
+            zhi[i] += 1e-9;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                       /* exclusive, inside the lane */
             pre[i] = run_up;
-            run_up = fmax(run_up, sv[i] + 27.0 * zz[i]);
+            run_up = fmax(run_up, (double)slo[i] + 27.0 * zlo[i]);
         }
 #pragma unroll
         for (int i = 7; i >= 0; --i) {
             suf[i] = run_dn;
-            run_dn = fmax(run_dn, sv[i] - 27.0 * zz[i]);
+            run_dn = fmax(run_dn, (double)slo[i] - 27.0 * zhi[i]);
         }
         double inc_up = run_up, inc_dn = run_dn;            /* inclusive scans across lanes */
 #pragma unroll
@@ -374,9 +399,9 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int p = 8 * lane + i;
-            const double below = fmax(pre[i], ex_up) - 27.0 * zz[i];   /* best tent of a lower masker, at z_p  */
-            const double above = fmax(suf[i], ex_dn) + 27.0 * zz[i];   /* best tent of a higher masker, at z_p */
-            const bool dominated = (sv[i] <= 40.0) && (below >= sv[i] + 1e-9 || above >= sv[i] + 1e-9);
+            const double below = fmax(pre[i], ex_up) - 27.0 * zhi[i];   /* a lower masker's tent at z_p, at least */
+            const double above = fmax(suf[i], ex_dn) + 27.0 * zlo[i];   /* a higher masker's tent at z_p, at least */
+            const bool dominated = (shi[i] <= 40.0f) && (below >= (double)shi[i] + 1e-9 || above >= (double)shi[i] + 1e-9);
             if (p < count && !dominated) {
                 keep_mask |= 1 << i;
                 ++n_mine;
@@ -390,17 +415,22 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
                 incl += t;
         }
         int pos = incl - n_mine;
-        const int n_kept = __shfl(incl, 63, 64);
-        PacxPeak *__restrict__ out = peaks + cf * PACX_MAX_PEAKS;
+        n_kept = __shfl(incl, 63, 64);
+        wave_lds_fence();                                   /* every lane has read its eight idx entries */
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (keep_mask & (1 << i)) {
-                PacxPeak q;
-                q.z = zz[i];
-                q.spl = sv[i];
-                q.slope = -27.0 + 0.367 * fmax(sv[i] - 40.0, 0.0);
-                out[pos++] = q;
-            }
+        for (int i = 0; i < 8; ++i)
+            if (keep_mask & (1 << i))
+                idx[pos++] = bin[i];                        /* compacted in place: pos <= 8 lane + i */
+        wave_lds_fence();
+    }
+    SIDE_T(5);
+    /* pass 3: the kept maskers, one per lane, 64 at a time: exact Bark value, SPL and upper
+       slope (coder/psychoac.py:321-328, :61-68), straight to HBM in Bark order */
+    {
+        PacxPeak *__restrict__ out = peaks + cf * PACX_MAX_PEAKS;
+        for (int p = lane; p < n_kept; p += 64) {
+            const int i = idx[p];
+            out[p] = make_peak(inten[i - 1], inten[i], i, T.fstep_long);
         }
         if (lane == 0) {
             n_peaks[cf * PACX_SUB] = count;                 /* what estimate_peaks finds */
@@ -441,7 +471,7 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
 }
 
 template <int DT, bool FAST, bool COMPACT>
-__global__ __launch_bounds__(64) void k_side_long(PacxTables T, PacxPcmView in,
+__global__ __launch_bounds__(64, 3) void k_side_long(PacxTables T, PacxPcmView in,
                                                  const uint8_t *__restrict__ flags, long long n_cf,
                                                  int skip_cur, PacxPeak *__restrict__ peaks,
                                                  int32_t *__restrict__ n_peaks,

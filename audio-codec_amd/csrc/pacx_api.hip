@@ -483,6 +483,14 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     T.fstep_long = cfg->fft_freq_step_long != 0.0 ? cfg->fft_freq_step_long : 1.0 / (NL * (1.0 / sr));
     T.fstep_short = cfg->fft_freq_step_short != 0.0 ? cfg->fft_freq_step_short : 1.0 / (NS * (1.0 / sr));
 
+    {
+        /* Bark of the long side-chain FFT's bin frequencies: a masker made of bins i-1 and i has its
+           Bark value between entries i-1 and i (the kernel adds a margin) */
+        std::vector<double> bb(NL / 2 + 1);
+        for (int i = 0; i <= NL / 2; ++i)
+            bb[i] = pacx_bark((double)i * T.fstep_long);
+        TRY(upload(h, bb.data(), bb.size(), &T.bark_bin_long));
+    }
     T.nb_long = cfg->n_bands_long;
     T.nb_short = cfg->n_bands_short;
     int covered_long = ML, covered_short = MS;

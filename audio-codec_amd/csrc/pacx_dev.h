@@ -37,6 +37,8 @@ struct PacxTables {
     const double2 *w256;        /* exp(-2 pi j k/256),  k <= 128              */
     const double *bark_long, *thresh_long;      /* [1024]                     */
     const double *bark_short, *thresh_short;    /* [128]                      */
+    const double *bark_bin_long;     /* [1025] Bark of the long FFT bin frequencies i*fstep_long: BOUNDS for the
+                                        side chain's masker screen only (C math library, never in a result) */
     const int32_t *band_lower_long, *band_lines_long;     /* [nb_long]        */
     const int32_t *band_lower_short, *band_lines_short;   /* [nb_short]       */
     const uint8_t *line_band_long;   /* [1024] band of each line              */
