@@ -340,9 +340,45 @@ PACX_HD double pacx_spl_array(double intensity)
  * a 5-term log1p series is exact to double rounding and one exp2 replaces
  * pow + log10.  Differs from the reference's own evaluation by rounding noise
  * only (~1e-14 dB); the threshold is compared at 1e-9 dB in the tests. */
+/* 2^y to a relative 3e-13, for the round trip below (which needs t = eps 2^y to ~1e-11 only:
+ * t < 1e-3 enters the result as 4.34 log1p(t) dB).  y = n + f, |f| <= 1/2, degree-10 series
+ * of 2^f in Horner form with the coefficients as scalar-register operands, 2^n by ldexp:
+ * 16 instructions against 39 for the device library's exp2 -- inside the mask kernel's
+ * per-line loop, sixteen lines per lane and frame. */
+PACX_HD double pacx_exp2_lean(double y)
+{
+    const double n = rint(y), f = y - n;
+    const double c1 = 6.931471805599453094e-01, c2 = 2.402265069591007123e-01, c3 = 5.550410866482157995e-02,
+                 c4 = 9.618129107628477162e-03, c5 = 1.333355814642844343e-03, c6 = 1.540353039338160995e-04,
+                 c7 = 1.525273380405984028e-05, c8 = 1.321548679014430949e-06, c9 = 1.017808600923969973e-07,
+                 c10 = 7.054911620801123330e-09;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PACX_FMA_SC(r, a, b, c) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c))
+#else
+#define PACX_FMA_SC(r, a, b, c) (r) = fma((a), (b), (c))
+#endif
+    double p;
+    PACX_FMA_SC(p, f, c10, c9);
+    PACX_FMA_SC(p, f, p, c8);
+    PACX_FMA_SC(p, f, p, c7);
+    PACX_FMA_SC(p, f, p, c6);
+    PACX_FMA_SC(p, f, p, c5);
+    PACX_FMA_SC(p, f, p, c4);
+    PACX_FMA_SC(p, f, p, c3);
+    PACX_FMA_SC(p, f, p, c2);
+    PACX_FMA_SC(p, f, p, c1);
+#undef PACX_FMA_SC
+    p = fma(f, p, 1.0);
+    int e = (int)n;                                  /* |y| < 1100 here; ldexp saturates beyond */
+    return ldexp(p, e);
+}
+
 PACX_HD double pacx_spl_of_intensity_of(double x)
 {
-    const double t = PACX_EPS * exp2((96.0 - x) * 0.33219280948873623);   /* log2(10)/10 */
+    double y = (96.0 - x) * 0.33219280948873623;     /* log2(10)/10 */
+    if (y > 1000.0)
+        y = 1000.0;                                  /* t is far above 1e-3 long before: the floor */
+    const double t = PACX_EPS * pacx_exp2_lean(y);
     if (!(t < 1e-3))
         return -30.0;
     const double p = t * (1.0 + t * (-0.5 + t * (1.0 / 3.0 + t * (-0.25 + t * 0.2))));

@@ -19,6 +19,7 @@ int hc_bit_alloc(double budget, int max_mant, int nb, const int32_t *n_lines, co
 double hc_spl_array(double v) { return pacx_spl_array(v); }
 double hc_log10_pos(double x) { return pacx_log10_pos(x); }
 double hc_round_trip(double x) { return pacx_spl_of_intensity_of(x); }
+double hc_exp2_lean(double y) { return pacx_exp2_lean(y); }
 double hc_spl_scalar(double v) { return pacx_spl_scalar(v); }
 double hc_bark(double f) { return pacx_bark(f); }
 double hc_thresh_quiet(double f) { return pacx_thresh_quiet(f); }

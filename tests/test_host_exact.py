@@ -160,6 +160,19 @@ def test_masker_round_trip(hc):
     assert np.all(got >= -30.0) and np.all(got[x < -30.6] == -30.0)
 
 
+def test_lean_exp2(hc):
+    """pacx_exp2_lean (the mask kernel's per-line 2^y) against np.exp2: relative 3e-13 over the
+    range the round trip uses and well beyond"""
+    hc.hc_exp2_lean.restype = ctypes.c_double
+    hc.hc_exp2_lean.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(9)
+    y = np.concatenate((rng.uniform(-60, 300, 20000), np.linspace(-0.5, 0.5, 2001), [0.0, 1.0, -1.0, 0.5, -0.5, 1000.0]))
+    got = np.array([hc.hc_exp2_lean(float(v)) for v in y])
+    want = np.exp2(y)
+    assert np.max(np.abs(got / want - 1.0)) < 3e-13
+    assert hc.hc_exp2_lean(0.0) == 1.0 and hc.hc_exp2_lean(10.0) == 1024.0
+
+
 def test_psycho_scalars(hc, tables):
     rng = np.random.default_rng(2)
     v = 10.0 ** rng.uniform(-20, 2, 500)
