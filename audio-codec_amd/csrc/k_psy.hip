@@ -760,18 +760,6 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
 #pragma unroll
         for (int j = 0; j < PER; ++j)
             buf[lane + 64 * j] = -INFINITY;
-        /* the frame's MDCT lines (HBM / Infinity Cache: the MDCT kernel wrote them a few hundred
-           microseconds ago) are requested NOW and used after the masker loop: fetched one line
-           ahead inside the per-line loop, every one of its 16 iterations waited a memory round
-           trip -- 2 300 cycles per iteration, a quarter of this kernel (in-kernel stamps) */
-        /* (the fused-tail variant has no registers to spare for this and keeps the one-ahead fetch) */
-        constexpr bool LINES_AHEAD = !TAIL;
-        double ln[LINES_AHEAD ? PER : 1];
-        if constexpr (LINES_AHEAD) {
-#pragma unroll
-            for (int j = 0; j < PER; ++j)
-                ln[j] = lines[loff + lane + 64 * j];
-        }
         PacxPeak qn;
         qn.z = 0.0; qn.spl = -1000.0; qn.slope = 0.0;             /* padding lanes never survive */
         if (lane < np)
@@ -873,22 +861,16 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
         PSY_T(1);
         /* per line: round trip of the winner, max with quiet, SMR term; the MDCT
            line is fetched one iteration ahead */
-        double q_next = quiet_s[lane];
-        double v_next = LINES_AHEAD ? 0.0 : lines[loff + lane];
-#pragma unroll
+        double v_next = lines[loff + lane], q_next = quiet_s[lane];
+#pragma unroll 1
         for (int j = 0; j < PER; ++j) {
             const int k = lane + 64 * j;
-            double v;
-            if constexpr (LINES_AHEAD) {
-                v = ln[j];
-            } else {
-                v = v_next;
-                if (j + 1 < PER)
-                    v_next = lines[loff + k + 64];
-            }
-            double thr = q_next;                           /* threshold in quiet, one line ahead */
-            if (j + 1 < PER)
+            const double v = v_next;
+            double thr = q_next;                           /* threshold in quiet, also one ahead */
+            if (j + 1 < PER) {
+                v_next = lines[loff + k + 64];
                 q_next = quiet_s[k + 64];
+            }
             const double bst = buf[k];
             if (bst > -INFINITY)
                 thr = fmax(thr, mask_round_trip(bst));
