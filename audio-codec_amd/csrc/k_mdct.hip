@@ -111,9 +111,24 @@ __global__ __launch_bounds__(64) void k_mdct_short(PacxTables T, PacxPcmView in,
     const unsigned fl = flags ? flags[cf / in.n_ch] : 2u;
     if (only_cur && !(fl & 2u))
         return;
-    const double *__restrict__ w = prewin == 1 ? T.ones : prewin == 2 ? T.kbd_short : T.win_short;
-
-    stage_samples<DT, FAST>(raw, in, cf, PACX_SHORT_FIRST, SPAN, lane);
+    const double *__restrict__ wg = prewin == 1 ? T.ones : prewin == 2 ? T.kbd_short : T.win_short;
+    /* the block's tables go to LDS with the PCM, all in ONE round trip to L2: read from global
+       memory where they are used (32 window values, 16 + 7 twiddles per lane, each behind a wait)
+       this one-wave kernel was a chain of some fifty dependent L2 latencies -- 45 us for the
+       4 000 short-coded frames of the block-switched bench batch */
+    __shared__ __attribute__((aligned(16))) double w[PACX_N_SHORT];
+    __shared__ __attribute__((aligned(16))) cplx tws[PACX_N_SHORT / 4];
+    __shared__ __attribute__((aligned(16))) cplx w64s[8][8];          /* W64^(r k2) at [k2][r] */
+    {
+        const double2 wa = *(const double2 *)(wg + 4 * lane), wb = *(const double2 *)(wg + 4 * lane + 2);
+        const cplx tv = T.tw_short[lane];
+        const cplx wv = T.w512[(8 * (lane & 7) * (lane >> 3)) & 511];
+        stage_samples<DT, FAST>(raw, in, cf, PACX_SHORT_FIRST, SPAN, lane);
+        *(double2 *)(w + 4 * lane) = wa;
+        *(double2 *)(w + 4 * lane + 2) = wb;
+        tws[lane] = tv;
+        w64s[lane >> 3][lane & 7] = wv;
+    }
     __syncthreads();
 
     const int g = lane >> 3, r = lane & 7;
@@ -148,10 +163,10 @@ __global__ __launch_bounds__(64) void k_mdct_short(PacxTables T, PacxPcmView in,
             re = w[i0] * PcmStage<DT>::get(sub, i0) - w[i1] * PcmStage<DT>::get(sub, i1);
             im = -(w[i2] * PcmStage<DT>::get(sub, i2)) - w[i3] * PcmStage<DT>::get(sub, i3);
         }
-        v[n1] = c_mul(make_double2(re, im), T.tw_short[n]);
+        v[n1] = c_mul(make_double2(re, im), tws[n]);
     }
 
-    fft64x8(v, tile, T.w512, lane);
+    fft64x8_lds(v, tile, &w64s[0][0], lane);
 
     const double s = 2.0 / PACX_N_SHORT;     /* 2^-7 */
     double *__restrict__ out = lines + cf * PACX_M_LONG + g * PACX_M_SHORT;
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(64) void k_mdct_short(PacxTables T, PacxPcmView in,
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) {
         const int k = fft64_out_index(lane, k3);
-        const cplx y = c_mul(v[k3], T.tw_short[k]);
+        const cplx y = c_mul(v[k3], tws[k]);
         a[k3] = y.x * s;
         b[k3] = -(y.y * s);
         mx = fmax(mx, fmax(fabs(a[k3]), fabs(b[k3])));

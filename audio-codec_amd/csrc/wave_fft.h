@@ -99,6 +99,26 @@ __device__ __forceinline__ void fft64x8(cplx v[8], cplx *tile, const cplx *__res
     dft8(v);
 }
 
+/* the same with the per-lane twiddles W64^(r k2) taken from an LDS table w64[k2][r] */
+__device__ __forceinline__ void fft64x8_lds(cplx v[8], cplx *tile, const cplx *w64, int lane)
+{
+    const int g = lane >> 3, r = lane & 7;
+    dft8(v);
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2)
+        v[k2] = c_mul(v[k2], w64[8 * k2 + r]);
+    cplx *row = tile + g * WFFT_ROW;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2)
+        row[8 * k2 + (r ^ k2)] = v[k2];
+    wave_lds_fence();
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3)
+        v[n3] = row[8 * r + (n3 ^ r)];
+    wave_lds_fence();
+    dft8(v);
+}
+
 /*
  * One 512-point FFT.
  *   in : v[n1] = x[lane + 64 n1]
