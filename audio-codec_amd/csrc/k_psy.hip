@@ -529,32 +529,12 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
     if (only_cur && !(fl & 2u))
         return;
 
-    /* the block's tables go to LDS with the PCM, in one round trip to L2 (as k_mdct_short):
-       the Hann window, the FFT's per-lane twiddles and the two tables of the real-FFT split,
-       which were four global loads per iteration of the split loop, each behind a wait */
-    __shared__ __attribute__((aligned(16))) double hann_s[PACX_N_SHORT];
-    __shared__ __attribute__((aligned(16))) cplx w64s[8][8], w128s[64], w256s[132];
-    {
-        const double *__restrict__ hg = (DT == 0) ? T.hann_short_pcm : T.hann_short;
-        const double2 ha = *(const double2 *)(hg + 4 * lane), hb = *(const double2 *)(hg + 4 * lane + 2);
-        const cplx wv = T.w512[(8 * (lane & 7) * (lane >> 3)) & 511];
-        const cplx w1 = T.w128[lane], w2a = T.w256[lane], w2b = T.w256[lane + 64];
-        const cplx w2c = T.w256[128];
-        stage_samples<DT, FAST>(raw, in, cf, PACX_SHORT_FIRST, SPAN, lane);
-        *(double2 *)(hann_s + 4 * lane) = ha;
-        *(double2 *)(hann_s + 4 * lane + 2) = hb;
-        w64s[lane >> 3][lane & 7] = wv;
-        w128s[lane] = w1;
-        w256s[lane] = w2a;
-        w256s[lane + 64] = w2b;
-        if (lane == 0)
-            w256s[128] = w2c;
-    }
+    stage_samples<DT, FAST>(raw, in, cf, PACX_SHORT_FIRST, SPAN, lane);
     __syncthreads();
 
     const int g = lane >> 3, r = lane & 7;
     const E *sub = raw + g * PACX_M_SHORT;
-    const double *hw = hann_s, *hwp = hann_s;
+    const double *__restrict__ hw = T.hann_short, *__restrict__ hwp = T.hann_short_pcm;
     cplx ev[8], od[8];
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) {
@@ -563,8 +543,8 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
         od[n1] = make_double2(hann_sample<DT>(sub, i + 2, hw, hwp), hann_sample<DT>(sub, i + 3, hw, hwp));
     }
     __syncthreads();                  /* raw consumed: region B becomes inten */
-    fft64x8_lds(ev, tile, &w64s[0][0], lane);
-    fft64x8_lds(od, tile, &w64s[0][0], lane);
+    fft64x8(ev, tile, T.w512, lane);
+    fft64x8(od, tile, T.w512, lane);
     /* ev[k3] = E[k], od[k3] = O[k], k = r + 8 k3 (64-point spectra of the even / odd
        samples).  Z[k] = E[k] + W128^k O[k], Z[k+64] = E[k] - W128^k O[k]; bins k and
        k + 64 pair with Z[128-k] and Z[64-k], both made of E[m], O[m], m = 64 - k */
@@ -573,7 +553,7 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) {
         const int k = r + 8 * k3;
-        const cplx t = c_mul(w128s[k], od[k3]);
+        const cplx t = c_mul(T.w128[k], od[k3]);
         const cplx zk = c_add(ev[k3], t), zk5 = c_sub(ev[k3], t);
         cplx pe, po;
         pe.x = bperm_f64(ev[7 - k3].x, mirror);
@@ -585,16 +565,16 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
             po = od[(8 - k3) & 7];
         }
         const int m = (64 - k) & 63;
-        const cplx tm = c_mul(w128s[m], po);
+        const cplx tm = c_mul(T.w128[m], po);
         cplx zm = c_add(pe, tm), zm5 = c_sub(pe, tm);       /* Z[m], Z[m+64] */
         if (k == 0) {
             zm5 = zk;
             zm = zk5;
         }
-        ig[k] = pair_intensity(zk, zm5, w256s[k], T.norm_short);
-        ig[k + 64] = pair_intensity(zk5, zm, w256s[k + 64], T.norm_short);
+        ig[k] = pair_intensity(zk, zm5, T.w256[k], T.norm_short);
+        ig[k + 64] = pair_intensity(zk5, zm, T.w256[k + 64], T.norm_short);
         if (k == 0)
-            ig[128] = pair_intensity(zk, zk, w256s[128], T.norm_short);
+            ig[128] = pair_intensity(zk, zk, T.w256[128], T.norm_short);
     }
     __syncthreads();
 
