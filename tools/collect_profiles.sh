@@ -34,6 +34,18 @@ if [ -f audio-codec_amd/libpacx_dbg.so ]; then
   PACX_LIB=$R/audio-codec_amd/libpacx_dbg.so python3 tools/mdct_phase_probe.py 262144 >> $OUT/phases_mdct.txt 2>&1
 fi
 python3 tools/mdct_sweep.py 8192 16384 65536 262144 > $OUT/mdct_sweep.txt 2>&1
+# the tail fused into the mask kernel: the same traffic passes with PACX_FUSE_TAIL=1
+cd /tmp
+PACX_FUSE_TAIL=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_f -- python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
+PACX_FUSE_TAIL=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_f -- python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
+python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_f $OUT/pmc_write_f $OUT/mdct_pmc_fused.json $OUT/step_traffic_fused.json
+rm -rf $OUT/pmc_fetch_f $OUT/pmc_write_f
+cd $R
+# large batches: one rank's share of BASELINE configs[4] and configs[2] at full size
+python3 bench.py --frames 131072 --steps 5 --warmup 2 --repeats 5 --no-cpu-baseline > $OUT/bench_scalar128_262144.log 2>&1 && tail -1 $OUT/bench_scalar128_262144.log > $OUT/bench_scalar128_262144.json
+python3 bench.py --workload bs128 --frames 862000 --steps 5 --warmup 2 --repeats 5 --no-cpu-baseline > $OUT/bench_bs128_x1000.log 2>&1 && tail -1 $OUT/bench_bs128_x1000.log > $OUT/bench_bs128_x1000.json
+python3 bench.py --corpus --corpus-frames 131072 --steps 5 --warmup 2 --repeats 5 --no-cpu-baseline > $OUT/bench_corpus_eighth.log 2>&1 && tail -1 $OUT/bench_corpus_eighth.log > $OUT/bench_corpus_eighth.json
+if [ -x audio-codec_amd/variants/ds_max_u64_probe ]; then ./audio-codec_amd/variants/ds_max_u64_probe > $OUT/ds_max_u64_probe.txt 2>&1; fi
 if [ -x audio-codec_amd/variants/hbm_mix_probe ]; then
   for n in 8192 65536 262144; do ./audio-codec_amd/variants/hbm_mix_probe $n 2; done > $OUT/hbm_mix_ceiling.txt 2>&1
   ./audio-codec_amd/variants/hbm_mix_probe 262144 0 >> $OUT/hbm_mix_ceiling.txt 2>&1
