@@ -681,7 +681,13 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     __shared__ __attribute__((aligned(16))) double bark_l[BARK_LDS ? M : 1];
     __shared__ __attribute__((aligned(16))) double quiet_l[QUIET_LDS ? M : 1];
     __shared__ __attribute__((aligned(16))) double chunk_c[PER][4];        /* zlo-0.5, zhi+0.5, qmin-0.01 */
-    __shared__ __attribute__((aligned(16))) double bufs[MASK_WAVES][M];    /* best, then mdct_spl - thr */
+    /* per-line state of each wave: running best, then mdct_spl - thr.  Long blocks pad one
+       double per 16 lines (line k at k + k/16), so that both access patterns are conflict-free:
+       lane + 64 j in the masker and per-line loops, 16 consecutive lines per lane in the band
+       reduction */
+    constexpr bool PAD = M / 64 == 16;
+    constexpr int JSTR = PAD ? 68 : 64;                                    /* stride of j in the strided view */
+    __shared__ __attribute__((aligned(16))) double bufs[MASK_WAVES][M + (PAD ? M / 16 : 0)];
     /* the 64 maskers of the current batch, (z, spl, slope, -) each: a surviving masker is
        fetched by all lanes with two broadcast LDS reads -- the LDS pipe idles in this
        kernel, the VALU is its bound, and six v_readlane + two v_mov per survivor were
@@ -715,6 +721,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     __syncthreads();
 
     double *buf = bufs[wv];
+    const int sl = lane + (PAD ? lane >> 4 : 0);       /* line lane + 64 j lives at buf[sl + JSTR * j] */
     double2 *mk_zs = mk_zs_all[wv];
     double *mk_u = mk_u_all[wv];
     const int nb = SHORT ? T.nb_short : T.nb_long;
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
            are software-pipelined one ahead, so no loop iteration waits on HBM */
 #pragma unroll
         for (int j = 0; j < PER; ++j)
-            buf[lane + 64 * j] = -INFINITY;
+            buf[sl + JSTR * j] = -INFINITY;
         PacxPeak qn;
         qn.z = 0.0; qn.spl = -1000.0; qn.slope = 0.0;             /* padding lanes never survive */
         if (lane < np)
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 if (!todo)
                     continue;
                 const double zj = bark_s[lane + 64 * j];
-                double bj = buf[lane + 64 * j];
+                double bj = buf[sl + JSTR * j];
                 /* survivors four at a time: their broadcast reads are issued together and
                    waited for once (the read latency, not the arithmetic, was what a survivor
                    cost); a short last group repeats its last masker -- max is idempotent */
@@ -854,7 +861,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                         asm("v_max_f64 %0, %1, %2" : "=v"(bj) : "v"(bj), "v"(cand));
                     }
                 }
-                buf[lane + 64 * j] = bj;
+                buf[sl + JSTR * j] = bj;
             }
         }
         wave_lds_fence();
@@ -871,7 +878,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 v_next = lines[loff + k + 64];
                 q_next = quiet_s[k + 64];
             }
-            const double bst = buf[k];
+            const double bst = buf[sl + JSTR * j];
             if (bst > -INFINITY)
                 thr = fmax(thr, mask_round_trip(bst));
             if (thr_out)
@@ -884,28 +891,62 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
             double spl = 96.0 + 10.0 * pacx_log10_pos(it + PACX_EPS);
             if (spl < -30.0)
                 spl = -30.0;
-            buf[k] = spl - thr;
+            buf[sl + JSTR * j] = spl - thr;
         }
         wave_lds_fence();
         PSY_T(2);
         double *__restrict__ out = smr ? smr + cf * T.band_stride + sb * T.nb_short : nullptr;
-        constexpr int NBR = SHORT ? 8 : 32;               /* bands handled by the reduction */
-        if (TAIL || nb <= NBR) {
-            /* all band maxima in one transposing reduction (wave_fft.h wave_max_n): six
-               LDS round trips for the lot instead of six per band */
-            double m[NBR];
+        /* band maxima.  Each lane takes the M/64 CONSECUTIVE lines it owns in the band layout
+           (bands are runs of lines), folds each run of one band in registers and posts it with one
+           64-bit LDS atomic max on an order-preserving key of the double; lanes < nb read the
+           results back.  Sixteen independent LDS reads and two or three atomics per lane, instead
+           of a dependent read per band and a 31-exchange transposing reduction.  max is exact, so
+           the SMRs are the same bits whatever the order */
+        double s_l;
+        {
+            constexpr int PERL = M / 64;
+            unsigned long long *key = (unsigned long long *)mk_zs;      /* the masker table is dead */
+            key[lane] = 0ull;                              /* below the key of every double */
+            int rl = lane;                                 /* opaque: the band ids are not to be hoisted */
+            asm volatile("" : "+v"(rl));
+            double v[PERL];
+            uint8_t bd[PERL];
+            if constexpr (SHORT) {
+                const double2 t = *(const double2 *)(buf + 2 * rl);
+                v[0] = t.x;
+                v[1] = t.y;
+                const uchar2 b2 = *(const uchar2 *)(T.line_band_short + 2 * rl);
+                bd[0] = b2.x;
+                bd[1] = b2.y;
+            } else {
+                const uint4 b16 = *(const uint4 *)(T.line_band_long + 16 * rl);
+                const unsigned w[4] = {b16.x, b16.y, b16.z, b16.w};
 #pragma unroll
-            for (int b = 0; b < NBR; ++b) {
-                double v = -INFINITY;
-                const int lo = __builtin_amdgcn_readlane(lo_v, b), hi = __builtin_amdgcn_readlane(hi_v, b);
-                for (int k = lo + lane; k < hi; k += 64)          /* empty for b >= nb */
-                    v = fmax(v, buf[k]);
-                m[b] = v;
+                for (int j = 0; j < PERL; ++j) {
+                    v[j] = buf[17 * rl + j];
+                    bd[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+                }
             }
-            wave_max_n<NBR>(m, lane);
-            constexpr int PER_BAND = 64 / NBR;            /* lanes that end up with one band's maximum */
-            if (out && !(lane & (PER_BAND - 1)) && lane / PER_BAND < nb)
-                out[lane / PER_BAND] = m[0];
+            wave_lds_fence();
+            int cur = bd[0];
+            double mx = v[0];
+#pragma unroll
+            for (int j = 1; j < PERL; ++j) {
+                if (bd[j] != cur) {
+                    atomicMax(&key[cur], mask_key_of(mx));
+                    cur = bd[j];
+                    mx = v[j];
+                } else {
+                    mx = fmax(mx, v[j]);
+                }
+            }
+            atomicMax(&key[cur], mask_key_of(mx));
+            wave_lds_fence();
+            s_l = mask_value_of(key[lane & 31]);
+            if (out && lane < nb)
+                out[lane] = s_l;
+        }
+        {
             if constexpr (TAIL) {
                 wave_lds_fence();                         /* the band maxima are taken: buf is free */
                 /* the lane number of the tail is opaque per frame: everything the tail derives from
@@ -923,8 +964,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 const int half = tl >> 5, l = tl & 31;
                 const unsigned fl = flags ? flags[cf / n_ch] : 0u;
                 const long long boff = cf * T.band_stride;
-                /* 1. BitAlloc: band l's SMR sits in lanes 2l, 2l+1 */
-                const double s_l = __shfl(m[0], (2 * l) & 63, 64);
+                /* 1. BitAlloc: band l's SMR is s_l of lanes l and l + 32 */
                 const int32_t *__restrict__ n_lines = T.use_sbr ? T.band_lines_long_alloc : T.band_lines_long;
                 const double budget = pacx_bit_budget(T.target_bps, PACX_M_LONG, 0, (fl & 5u) != 0, T.n_scale_bits,
                                                       T.n_mant_size_bits, nb, T.use_vq, T.use_sbr);
@@ -1021,16 +1061,6 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                     }
                     PSY_T(6);
                 }
-            }
-        } else {
-            for (int b = 0; b < nb; ++b) {
-                const int lo = lower[b], hi = lo + count[b];
-                double m = -INFINITY;
-                for (int k = lo + lane; k < hi; k += 64)
-                    m = fmax(m, buf[k]);
-                m = wave_max(m);
-                if (lane == 0)
-                    out[b] = m;
             }
         }
         wave_lds_fence();
