@@ -662,6 +662,19 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
  * buffer and the band tables.  Gain-shape handles stop after BitAlloc (k_vq takes the
  * allocation from HBM). */
 
+/* Order-preserving 64-bit key of a double (no NaNs): larger double <=> larger unsigned key.
+   Key 0 is below the key of every double, -inf included. */
+__device__ __forceinline__ unsigned long long mask_key_of(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double mask_value_of(unsigned long long k)
+{
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
 template <int M, bool TAIL>
 __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T, const uint8_t *__restrict__ flags,
                                                          int n_ch, long long n_units, int mixed,
@@ -727,12 +740,6 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     const int nb = SHORT ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = SHORT ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = SHORT ? T.band_lines_short : T.band_lines_long;
-    /* band bounds, one band per lane, read once: inside the frame loop they would be
-       vector loads from HBM/L2 with a full wait each (the compiler cannot keep them
-       scalar past the kernel's own stores), two dependent ones per band */
-    const int lo_v = lane < nb ? lower[lane] : 0;
-    const int hi_v = lane < nb ? lo_v + count[lane] : 0;
-
     /* mixed streams: walk the compacted list of the frames this kernel owns, so the
        static striding stays balanced whatever the pattern of long and short frames */
     if (cf_list)
