@@ -10,6 +10,9 @@ PACX_ABI_VERSION = 3
 PCM_I16, PCM_F64 = 0, 1
 FLAG_LAST, FLAG_CUR, FLAG_NEXT = 1, 2, 4
 ST_SHORT, ST_ZERO_SUBBLOCK, ST_ALLOC_CAP, ST_VQ_UNDEFINED, ST_GUARD, ST_MALFORMED = 1, 2, 4, 8, 16, 32
+ST_REF_RAISES = 64
+# what the reference raises where PACX_ST_REF_RAISES is set (coder/quantize.py:74, see include/pacx.h)
+REF_SCALAR_SBR_ERROR = "'numpy.int64' object does not support item assignment"
 MAX_BANDS = 32
 SUB = 8
 

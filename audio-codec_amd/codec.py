@@ -53,29 +53,31 @@ def _to_host(out):
 def Encode(data, codingParams, lastTrans=False, curTrans=False, nextTrans=False):
     """coder/codec.py:225-263.  data: list (nChannels) of float64 blocks of
     2*nMDCTLines samples.  Returns (scaleFactor, bitAlloc, mantissa,
-    overallScaleFactor), each a list over channels."""
-    import torch
+    overallScaleFactor), each a list over channels.  Like the reference's, this
+    function does not look at useSBR (PACFile.Encode does the routing)."""
     if getattr(codingParams, "useVQ", False):
         return _encode_vq(data, codingParams, lastTrans, curTrans, nextTrans, sbr=False)
-    if getattr(codingParams, "useSBR", False):
-        raise NotImplementedError("scalar-mantissa SBR is not produced by the reference's driver")
-    enc = context.encoder_for_params(codingParams)
-    n_ch = codingParams.nChannels
-    n = 2 * codingParams.nMDCTLines
-    flags = [(bool(lastTrans), bool(curTrans), bool(nextTrans))]
-    blk = np.zeros((1, n_ch, 2048))
-    if curTrans:
-        if n != 256:
-            raise ValueError("a short block is 256 samples (nMDCTLines 128)")
-        for ch in range(n_ch):
-            blk[0, ch, 448:448 + 256] = data[ch]
-    else:
-        if n != 2048:
-            raise NotImplementedError("long blocks are 2048 samples (nMDCTLines 1024)")
-        for ch in range(n_ch):
-            blk[0, ch] = data[ch]
+    return _encode_scalar(data, codingParams, lastTrans, curTrans, nextTrans, sbr=False)
+
+
+def _encode_scalar(data, codingParams, lastTrans, curTrans, nextTrans, sbr):
+    """Scalar mantissas: EncodeSingleChannel per channel (coder/codec.py:266-380) or, sbr,
+    EncodeSingleChannel_SBR's useVQ-False branch (:426-482, 529-555) -- which the reference
+    can only finish while no omitted band gets bits; where it raises, so does this
+    (PACX_ST_REF_RAISES, include/pacx.h).  The mantissa list holds the coded bands'
+    mantissas; the reference's array is longer there (it sizes it with the one-line omitted
+    bands, np.empty) and the excess is uninitialised memory."""
+    import torch
+    cp = codingParams
+    enc = context.encoder(cp.sampleRate, cp.targetBitsPerSample, cp.nScaleBits, cp.nMantSizeBits,
+                          getattr(cp, "sfBands", None), getattr(cp, "sfBandsShort", None),
+                          use_vq=False, use_sbr=bool(sbr))
+    n_ch = cp.nChannels
+    blk = _frame_block(data, n_ch, 2 * cp.nMDCTLines, curTrans)
     pcm = PcmView.frames(torch.as_tensor(blk, device=enc.device))
-    out = _to_host(enc.encode(pcm, flags))
+    out = _to_host(enc.encode(pcm, [(bool(lastTrans), bool(curTrans), bool(nextTrans))]))
+    if int(out["status"].max()) & _lib.ST_REF_RAISES:
+        raise TypeError(_lib.REF_SCALAR_SBR_ERROR)
     res = ([], [], [], [])
     for ch in range(n_ch):
         r = unpack_short(enc, out, ch, 0) if curTrans else unpack_long(enc, out, ch)
@@ -141,14 +143,14 @@ def _encode_vq(data, codingParams, lastTrans, curTrans, nextTrans, sbr):
 
 
 def Encode_SBR(data, codingParams, lastTrans=False, curTrans=False, nextTrans=False):
-    """coder/codec.py:383-423 (useVQ): long blocks of an SBR file.  Unlike the
+    """coder/codec.py:383-423: long blocks of an SBR file.  Unlike the
     reference this does not modify codingParams.sfBands.nLines (BitAlloc_SBR's
     in-place write, coder/bitalloc.py:141-143): the handle counts the omitted
     bands as one line itself."""
-    if not getattr(codingParams, "useVQ", False):
-        raise NotImplementedError("scalar-mantissa SBR is not produced by the reference's driver")
     if curTrans:
         raise ValueError("Encode_SBR codes long blocks (coder/pacfile.py:639-643)")
+    if not getattr(codingParams, "useVQ", False):
+        return _encode_scalar(data, codingParams, lastTrans, curTrans, nextTrans, sbr=True)
     return _encode_vq(data, codingParams, lastTrans, curTrans, nextTrans, sbr=True)
 
 

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(64, 4) void k_tail_long(PacxTables T, const uint8_t
     long long tail_last = 0;
 #endif
     TAIL_T(15);
+    unsigned long long raises = 0;                        /* lanes of the halves whose frame is flagged */
     /* 1. BitAlloc */
     {
         const long long cfh = cf0 + half;
@@ -378,6 +379,11 @@ __global__ __launch_bounds__(64, 4) void k_tail_long(PacxTables T, const uint8_t
             ba_2[half][nb] = 0;                           /* dummy band of the lines no band covers */
         if (alive && cap && status && l == 0)
             atomicOr(&status[cfh], ((cap & 1) ? 4u : 0u) | ((cap & 2) ? 16u : 0u));
+        /* scalar mantissas + SBR: bits on an omitted band are where the reference raises
+           (PACX_ST_REF_RAISES, include/pacx.h) */
+        raises = T.use_sbr && !T.use_vq && __builtin_amdgcn_ballot_w64(has && l >= T.first_omitted && bits != 0);
+        if (T.use_sbr && !T.use_vq && has && l >= T.first_omitted && bits != 0 && status)
+            atomicOr(&status[cfh], 64u);
     }
     TAIL_T(0);
     for (int c = 0; c < per_block; ++c) {
@@ -413,6 +419,11 @@ __global__ __launch_bounds__(64, 4) void k_tail_long(PacxTables T, const uint8_t
         }
         if (!payload)
             continue;
+        if ((raises >> (32 * c)) & 0xffffffffull) {      /* PACX_ST_REF_RAISES: no payload is defined */
+            if (lane == 0)
+                n_bytes[cf] = 0;
+            continue;
+        }
         TAIL_T(1);
         /* 3. payload (layout of pack_body) */
         const int a_mine = (lane < nb) ? ba_s[lane] : 0;

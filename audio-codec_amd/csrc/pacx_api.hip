@@ -514,11 +514,6 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     T.use_sbr = cfg->use_sbr ? 1 : 0;
     T.first_omitted = T.nb_long;
     T.band_lines_long_alloc = T.band_lines_long;
-    if (T.use_sbr && !T.use_vq) {
-        g_create_err = "pacx_create: use_sbr needs use_vq (the scalar SBR variant is not built)";
-        pacx_destroy(h);
-        return PACX_E_UNSUPPORTED;
-    }
     if (T.use_sbr) {
         /* sbr.omitted_bands (coder/sbr.py:6-9): bands starting at or above upperLine[-1] // 2 */
         std::vector<int32_t> alloc_lines(cfg->band_lines_long, cfg->band_lines_long + T.nb_long);
@@ -876,6 +871,31 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
     mt.overall = overall_scale; mt.bit_alloc = bit_alloc; mt.scale_factor = scale_factor; mt.mantissa = mantissa;
     mt.status = status; mt.payload = payload; mt.n_bytes = n_bytes; mt.payload_stride = PACX_PAYLOAD_STRIDE;
     int32_t *const list_long = h->ws_lists, *const list_short = h->ws_lists + n_cf, *const counts = h->ws_lists + 2 * n_cf;
+    if (T.use_sbr) {
+        /* scalar mantissas in an SBR file (coder/codec.py:426-482, 529-555; long blocks only, short
+           ones take the plain path, coder/pacfile.py:639-643): the side chain folds max|FFT| into
+           the overall scale the MDCT wrote, so it runs behind the MDCT on one stream; BitAlloc counts
+           the omitted bands as one line and budgets from the full block (T.use_sbr in the tail
+           kernels), and a frame whose omitted band gets bits is where the reference raises:
+           PACX_ST_REF_RAISES, n_bytes 0.  Not a tuned path -- the reference's driver never selects it. */
+        if (fast) {
+            pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
+                                h->n_cu, mixed ? list_long : nullptr, mixed ? counts : nullptr, st);
+            if (mixed)
+                pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale,
+                                 PACX_SUB, status, st);
+        } else {
+            pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
+                             PACX_SUB, status, st);
+        }
+        pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
+                         h->ws_sbr_mean, overall_scale, st);
+        pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
+                         nullptr, h->n_cu, list_long, list_short, counts, nullptr, st);
+        pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
+                         mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, list_short, counts + 1, 0, st);
+        return post_launch(h, what);
+    }
     /* fork: the side chain only reads the PCM, so it runs on its own stream next to the MDCT */
     HIP_TRY(h, hipEventRecord(h->ev_fork, st));
     HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));

@@ -12,7 +12,7 @@ from struct import pack
 
 import numpy as np
 
-from . import codec, context
+from . import _lib, codec, context
 from .audiofile import AudioFile
 from .detect_transients import hop_transients
 from .engine import PcmView
@@ -45,12 +45,30 @@ def header_bytes(cp):
     return out
 
 
+def _raise_like_reference(out):
+    """Scalar mantissas in an SBR file: the reference raises TypeError on the first long block
+    whose omitted band receives bits (coder/codec.py:541-546 -> coder/quantize.py:73-74); the
+    kernels flag those channel-blocks (PACX_ST_REF_RAISES, include/pacx.h)."""
+    if out["status"].numel() and int(out["status"].max().item()) & _lib.ST_REF_RAISES:
+        raise TypeError(_lib.REF_SCALAR_SBR_ERROR)
+
+
+def _refuse_coded_sbr_band(cp, codes):
+    """Scalar mantissas + SBR on the decode side: the reference's encoder cannot write a long block
+    that codes an omitted band (it raises there, see _raise_like_reference), so such a block does
+    not come from it and Decode_SBR's scalar branch (coder/codec.py:117-134) is not built; every
+    other block of such a file decodes through the plain path (coder/pacfile.py:659-668)."""
+    lo = int(omitted_bands(cp.sfBands)[0])
+    is_long = (codes["flags"] & 2) == 0
+    if bool((codes["bit_alloc"][is_long][:, lo:cp.sfBands.nBands] != 0).any().item()):
+        raise NotImplementedError("scalar-mantissa block with a coded SBR band: not something the "
+                                  "reference's encoder can write")
+
+
 class PACFile(AudioFile):
     tag = b"PAC "
 
     def WriteFileHeader(self, codingParams):
-        if getattr(codingParams, "useSBR", False) and not getattr(codingParams, "useVQ", False):
-            raise NotImplementedError("scalar-mantissa SBR is not produced by the reference's driver")
         self.fp.write(header_bytes(codingParams))
         codingParams.priorBlock = [np.zeros(codingParams.nMDCTLines, dtype=np.float64)
                                    for _ in range(codingParams.nChannels)]
@@ -69,6 +87,7 @@ class PACFile(AudioFile):
             payload, n_bytes = out["payload"], out["n_bytes"]
         else:
             out = enc.encode(pcm, flags)
+            _raise_like_reference(out)
             payload, n_bytes = enc.pack(out, cp.nChannels)
         n_bytes = n_bytes.cpu().numpy()
         if not n_bytes.any():
@@ -152,6 +171,8 @@ class PACFile(AudioFile):
             codes = enc.unpack(torch.as_tensor(buf, device=enc.device), sizes)
             if int(codes["status"].max().item()) & _ST_MALFORMED:
                 raise RuntimeError(_PARTIAL)
+            if getattr(cp, "useSBR", False):
+                _refuse_coded_sbr_band(cp, codes)
             blocks = enc.decode(codes, cp.nChannels, want_blocks=True, want_pcm=False).cpu().numpy()
         data = []
         for ch in range(cp.nChannels):
@@ -222,6 +243,7 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, hea
         payload, n_bytes = out["payload"], out["n_bytes"]
     else:
         out = enc.encode_pack(view, flags)
+        _raise_like_reference(out)
         payload, n_bytes = out["payload"], out["n_bytes"]
     body, total = enc.gather_body(payload, n_bytes)
     n = int(total.item())
@@ -274,8 +296,6 @@ def decode_stream(data):
     the reference's decode loop (coder/pacfile.py:745-757) writes as PCM."""
     import torch
     cp, pos = parse_header(data)
-    if cp.useSBR and not cp.useVQ:
-        raise NotImplementedError("scalar-mantissa SBR streams are not produced by the reference's driver")
     enc = context.encoder_for_params(cp)
     offs, sizes = record_chain(data, pos, enc.payload_stride)
     if len(offs) % cp.nChannels:
@@ -295,4 +315,6 @@ def decode_stream(data):
     codes = enc.unpack(body, sizes_t, offs_t)
     if len(sizes) and int(codes["status"].max().item()) & _ST_MALFORMED:
         raise RuntimeError(_PARTIAL)
+    if cp.useSBR and len(sizes):
+        _refuse_coded_sbr_band(cp, codes)
     return enc.decode(codes, cp.nChannels).cpu().numpy()

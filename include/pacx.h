@@ -102,6 +102,14 @@ extern "C" {
                                      reference raises "Only read a partial block of
                                      coded PACFile data", coder/pacfile.py:203-205):
                                      its outputs are zeros                          */
+#define PACX_ST_REF_RAISES   64u   /* scalar mantissas + SBR (use_sbr without use_vq), long frame:
+                                      an SBR-omitted band received bits.  The reference quantises the
+                                      band's one value with vMantissa(np.mean(..)) -- a NumPy scalar its
+                                      vQuantizeUniform assigns into -- and raises TypeError there
+                                      (coder/codec.py:541-546, coder/quantize.py:73-74; recorded in
+                                      tests/golden/sbr_scalar.json), so no output is defined: the
+                                      frame's n_bytes is 0, its other outputs are unspecified, and the
+                                      host mirror raises the reference's error                      */
 
 #define PACX_SHORT_PER_FRAME 8    /* sub-blocks of a short frame (coder/pacfile.py:527) */
 
@@ -151,8 +159,13 @@ typedef struct pacx_config {
                   serves pacx_encode_vq_batch instead of pacx_encode_batch;
        use_sbr -- long blocks go through EncodeSingleChannel_SBR: the bands of
                   sbr.omitted_bands (coder/sbr.py:6-9) carry one value each.
-                  Needs use_vq (the only SBR flavour the reference's driver
-                  ever selects). */
+                  With use_vq this is the configuration the reference's driver
+                  selects below 128 kb/s.  Without use_vq (scalar mantissas,
+                  coder/codec.py:529-555) the reference is defined only while the
+                  omitted bands get no bits -- pacx_encode_batch / _pack_batch then
+                  follow it bit for bit (budget from the full block, max|FFT| in the
+                  overall scale, BitAlloc_SBR's one-line bands) and flag the frames
+                  on which it raises with PACX_ST_REF_RAISES. */
     int32_t use_vq;
     int32_t use_sbr;
     const double *half_log2;        /* optional [max band lines + 1]: 0.5*np.log2(L) */

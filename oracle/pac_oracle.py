@@ -542,6 +542,62 @@ def encode_channel(data, p, last_trans=False, cur_trans=False,
     return sf, alloc, mant, overall
 
 
+REF_SCALAR_SBR_ERROR = "'numpy.int64' object does not support item assignment"
+
+
+def encode_channel_sbr(data, p, last_trans=False, cur_trans=False,
+                       next_trans=False):
+    """One long channel-frame of an SBR file with scalar mantissas:
+    coder/codec.py:426-482 and the useVQ-False branch :529-555.  Differences
+    from encode_channel: the budget comes from the full halfN whatever the flags
+    (:446-452), the overall scale also covers |rfft(Hann x)|/halfN (:459-472) and
+    BitAlloc_SBR counts an omitted band as ONE line -- in place, so the band table
+    keeps the 1s from the first call on (coder/bitalloc.py:141-145).
+    The reference then hands np.mean(...) -- a NumPy scalar -- to vMantissa for a
+    coded omitted band (:541-546); vQuantizeUniform assigns into that scalar
+    (coder/quantize.py:73-74) and raises TypeError in every NumPy version.  So the
+    branch is defined only for frames whose omitted bands all get zero bits, and
+    this restatement raises the same error otherwise
+    (tests/golden/sbr_scalar.json records the reference doing so)."""
+    half_n = p.nMDCTLines
+    n_scale_bits = p.nScaleBits
+    max_mant = min(1 << p.nMantSizeBits, 16)
+    bands = p.sfBands
+    budget = p.targetBitsPerSample * half_n
+    budget -= n_scale_bits * (bands.nBands + 1)
+    budget -= p.nMantSizeBits * bands.nBands
+
+    windowed = apply_window(data, last_trans, cur_trans, next_trans)
+    lines = mdct_forward(windowed, half_n, half_n)[:half_n]
+    fft_mag = np.abs(np.fft.rfft(hann_window(len(data)) * data)) / half_n
+    peak = max(np.max(np.abs(lines)), np.max(fft_mag))
+    overall = scale_factor(peak, n_scale_bits)
+    lines *= (1 << overall)
+    smr = calc_smrs(data, lines, overall, p.sampleRate, bands)
+    for b in p.omittedBands:
+        bands.nLines[b] = 1
+    alloc = bit_alloc(budget, max_mant, bands.nBands, bands.nLines, smr)
+
+    sf = np.empty(bands.nBands, dtype=np.int32)
+    n_mant = half_n
+    for b in range(bands.nBands):
+        if not alloc[b]:
+            n_mant -= bands.nLines[b]
+        elif b in p.omittedBands:
+            n_mant -= bands.nLines[b] - 1
+    mant = np.zeros(n_mant, dtype=np.int32)
+    at = 0
+    for b in range(bands.nBands):
+        lo, hi = bands.lowerLine[b], bands.upperLine[b] + 1
+        sf[b] = scale_factor(np.max(np.abs(lines[lo:hi])), n_scale_bits, alloc[b])
+        if alloc[b]:
+            if b in p.omittedBands:
+                raise TypeError(REF_SCALAR_SBR_ERROR)       # coder/quantize.py:74
+            mant[at:at + bands.nLines[b]] = mantissa_vec(lines[lo:hi], sf[b], n_scale_bits, alloc[b])
+            at += bands.nLines[b]
+    return sf, alloc, mant, overall
+
+
 def encode(data, p, last_trans=False, cur_trans=False, next_trans=False):
     """coder/codec.py:249-263: loop channels, return four lists."""
     out = ([], [], [], [])
@@ -676,7 +732,8 @@ def encode_hop(p, prior, hop, flags):
     n_ch = p.nChannels
     full = [np.concatenate((prior[ch], hop[ch])) for ch in range(n_ch)]
     if not cur_t:
-        return [[encode_channel(full[ch], p, last_t, cur_t, next_t)]
+        one = encode_channel_sbr if p.useSBR else encode_channel    # coder/pacfile.py:639-643
+        return [[one(full[ch], p, last_t, cur_t, next_t)]
                 for ch in range(n_ch)]
     long_n = p.nMDCTLines
     short_n = SHORT_LINES
@@ -730,7 +787,7 @@ def wav_effective_stream(raw, hop=1024):
 
 
 def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False,
-                  max_hops=None, collect=None, header_samples=None):
+                  max_hops=None, collect=None, header_samples=None, use_sbr=False):
     """Whole-file scalar-path encode: the driver loop of
     coder/pacfile.py:716-757 plus Close (:612-625) on int16 PCM [nSamples, nCh].
     Returns the .pac bytes.  The last hop is written twice (the loop body runs
@@ -740,6 +797,9 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False,
     pcm = np.asarray(pcm)
     n_samples, n_ch = pcm.shape
     p = make_params(sample_rate, n_ch, kbps_per_channel)
+    if use_sbr:                                   # scalar mantissas + SBR: see encode_channel_sbr
+        p.useSBR = True
+        p.omittedBands = list(omitted_bands(p.sfBands))
     hop_n = p.nMDCTLines
     out = [pac_header(p, n_samples if header_samples is None else header_samples)]
     n_hops = -(-n_samples // hop_n)
@@ -824,6 +884,10 @@ def parse_block_body(br, p, cur_t):
         alloc.append(a)
         sf.append(br.get(p.nScaleBits))
         if a:
+            if not cur_t and b in p.omittedBands:
+                # coder/pacfile.py:204-205 + Decode_SBR's scalar branch: a block the reference's
+                # encoder cannot write (it raises there, see encode_channel_sbr) -- not restated
+                raise NotImplementedError("scalar-mantissa block with a coded SBR band")
             for j in range(bands.nLines[b]):
                 mant[bands.lowerLine[b] + j] = br.get(a)
     return sf, alloc, mant, overall
@@ -837,8 +901,11 @@ def parse_header(data):
     pos = 4 + struct.calcsize('<LHLLHHHH')
     n_bands = struct.unpack('<L', data[pos:pos + 4])[0]
     pos += 4 + 2 * n_bands
-    assert not use_sbr and not use_vq and n_lines == 1024
+    assert not use_vq and n_lines == 1024
     p = make_params(sr, n_ch, 128, n_lines, n_scale, n_mant_size)
+    if use_sbr:                                   # scalar mantissas + SBR, see encode_channel_sbr
+        p.useSBR = True
+        p.omittedBands = list(omitted_bands(p.sfBands))
     return p, n_samples, pos
 
 

@@ -26,6 +26,10 @@ Outputs
   excerpt_vq_*.npz  (--vq) 24-hop excerpts in the shipped configuration
   decoded_vq_*.npz  (--vq-decoded) those excerpts through the reference's decoder
   vqwav.json        (--vq-decoded) hashes of the decoded WAVs the reference committed
+  sbr_scalar.json   (--sbr-scalar) what the reference does with scalar mantissas + spectral band
+                    replication (useVQ off, useSBR on: the branch of EncodeSingleChannel_SBR the
+                    shipped driver never selects, coder/codec.py:529-555): it raises as soon as an
+                    omitted band receives bits
   kbd.npz           (--kbd) window.KBDWindow tables and MDCT(KBDWindow(x)) of the six-tone
                     block, the expression at coder/bitalloc.py:161
 """
@@ -121,7 +125,7 @@ def ref_params(sr, n_ch, kbps, n_lines=1024):
     return cp
 
 
-def ref_encode_file(wav_path, kbps, block_switching, out_path, vq=False):
+def ref_encode_file(wav_path, kbps, block_switching, out_path, vq=False, sbr=None):
     """The reference's own PCMFile -> PACFile objects driven the way its
     encode_decode_test does, with the scalar mantissa path selected (or, with
     vq=True, exactly the shipped settings: useVQ, useSBR below 128 kb/s)."""
@@ -132,7 +136,7 @@ def ref_encode_file(wav_path, kbps, block_switching, out_path, vq=False):
     cp.nScaleBits = 4
     cp.nMantSizeBits = 12
     cp.targetBitsPerSample = kbps / (cp.sampleRate / 1000)
-    cp.useSBR = bool(vq and kbps < 128)
+    cp.useSBR = bool(vq and kbps < 128) if sbr is None else bool(sbr)
     cp.useVQ = bool(vq)
     cp.nSamplesPerBlock = cp.nMDCTLines
     dst.OpenForWriting(cp)
@@ -610,7 +614,46 @@ def make_kbd():
     print("kbd.npz written")
 
 
+def make_sbr_scalar():
+    """Scalar mantissas + SBR (useVQ off, useSBR on) through the reference's own file loop.
+    Records what the reference does with each case in sbr_scalar.json: the branch at
+    coder/codec.py:541-548 hands a NumPy SCALAR to vMantissa, whose vQuantizeUniform then
+    assigns into it (coder/quantize.py:73-74) -- a TypeError in every NumPy version as soon
+    as an omitted band receives bits."""
+    import traceback
+    report = []
+    for name, kbps, bs in (("castanet", 96, True), ("harpsichord", 96, False), ("quar48_1", 64, True),
+                           ("harpsichord", 128, True), ("quar48_1", 32, False), ("castanet", 24, False)):
+        ex = np.load(os.path.join(HERE, f"excerpt_{name}.npz"))
+        pcm, sr = ex["pcm"][:24 * 1024], int(ex["sr"])
+        wav = os.path.join(_work, f"sbrs_{name}.wav")
+        open(wav, "wb").write(wav_bytes(sr, pcm))
+        pac_path = os.path.join(_work, f"sbrs_{name}_{kbps}.pac")
+        entry = {"excerpt": name, "hops": 24, "kbps_per_channel": kbps, "block_switching": bs,
+                 "useVQ": False, "useSBR": True}
+        try:
+            pac, flags = ref_encode_file(wav, kbps, bs, pac_path, vq=False, sbr=True)
+            entry["outcome"] = "encoded"
+            entry["bytes"] = len(pac)
+            entry["sha256"] = hashlib.sha256(pac).hexdigest()
+            dec = ref_decode_file(pac_path, os.path.join(_work, f"sbrs_{name}_{kbps}_dec.wav"))
+            entry["decoded_shape"] = list(dec.shape)
+            entry["decoded_sha256"] = hashlib.sha256(np.ascontiguousarray(dec).astype("<i2").tobytes()).hexdigest()
+        except Exception as e:                                   # noqa: BLE001
+            tb = traceback.extract_tb(e.__traceback__)
+            entry["outcome"] = "raised"
+            entry["error"] = f"{type(e).__name__}: {e}"
+            entry["where"] = [f"{os.path.relpath(f.filename, REF)}:{f.lineno} {f.name}" for f in tb
+                              if f.filename.startswith(REF)]
+        report.append(entry)
+        print(entry)
+    json.dump(report, open(os.path.join(HERE, "sbr_scalar.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    if "--sbr-scalar" in sys.argv:
+        make_sbr_scalar()
+        sys.exit(0)
     if "--kbd" in sys.argv:
         make_kbd()
         sys.exit(0)

@@ -582,10 +582,6 @@ def test_edge_cases(A, torch):
         enc.encode(bad)
     with pytest.raises(A.PacxError, match="1024"):
         A.engine.Encoder(48000, 128 / 48.0, n_mdct_lines=512)
-    with pytest.raises(NotImplementedError):          # scalar-mantissa SBR: never selected by the driver
-        cp = A.audiofile.CodingParams()
-        cp.useVQ, cp.useSBR = False, True
-        A.codec.Encode([np.zeros(2048)], cp)
     with pytest.raises(A.PacxError, match="use_vq"):  # a scalar handle refuses the gain-shape entry point
         enc.encode_vq(A.engine.PcmView.stream(planar))
 

@@ -353,3 +353,107 @@ def test_corpus_shard_equals_its_sub_shards(A, torch):
     flagged = int(np.count_nonzero(st_whole & A._lib.ST_GUARD))
     print(f"corpus shard: {whole.numel()} body bytes for {2 * (hi - lo)} channel-frames, {flagged} flagged PACX_ST_GUARD")
     enc.close()
+
+
+# ------------------------------------------- scalar mantissas + SBR (useVQ off, useSBR on)
+def _sbr_scalar_cases():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "sbr_scalar.json")))
+
+
+@pytest.mark.parametrize("case", _sbr_scalar_cases(), ids=lambda e: f"{e['excerpt']}_{e['kbps_per_channel']}")
+def test_scalar_sbr_files_follow_the_reference(A, torch, case):
+    """The branch of EncodeSingleChannel_SBR the shipped driver never selects (coder/codec.py:529-555):
+    where the reference finishes the file the GPU path writes the same bytes (hash of the reference's
+    own output, tests/golden/sbr_scalar.json), where it raises -- an omitted band got bits -- the
+    kernels flag the block (PACX_ST_REF_RAISES) and the mirror raises the reference's TypeError."""
+    import hashlib
+    ex = np.load(os.path.join(GOLDEN, f"excerpt_{case['excerpt']}.npz"))
+    pcm, sr = ex["pcm"][:case["hops"] * 1024], int(ex["sr"])
+    kbps, bs = case["kbps_per_channel"], case["block_switching"]
+    if case["outcome"] == "raised":
+        with pytest.raises(TypeError, match="item assignment"):
+            A.pacfile.encode_stream(pcm, sr, kbps, bs, use_sbr=True)
+        return
+    pac = A.pacfile.encode_stream(pcm, sr, kbps, bs, use_sbr=True)
+    assert len(pac) == case["bytes"]
+    assert hashlib.sha256(pac).hexdigest() == case["sha256"]
+    # and such a file decodes (no omitted band is coded: plain path, coder/pacfile.py:659-668)
+    got = A.pacfile.decode_stream(pac)
+    assert list(got.shape) == case["decoded_shape"]
+    assert hashlib.sha256(np.ascontiguousarray(got).astype("<i2").tobytes()).hexdigest() == case["decoded_sha256"]
+
+
+def test_scalar_sbr_block_mirrors(A, torch):
+    """codec.Encode_SBR with useVQ off for one long block (the oracle's encode_channel_sbr on the same
+    samples), PACFile.Encode's routing (long -> Encode_SBR, short -> Encode), and the file-object loop
+    (PACFile.WriteDataBlock) against the batched encode."""
+    import io
+    ex = np.load(os.path.join(GOLDEN, "excerpt_castanet.npz"))
+    pcm, sr = ex["pcm"][:24 * 1024], int(ex["sr"])
+    cp = A.audiofile.CodingParams()
+    cp.sampleRate, cp.nChannels = sr, 2
+    cp.nMDCTLines = cp.nSamplesPerBlock = 1024
+    cp.nScaleBits, cp.nMantSizeBits = 4, 12
+    cp.targetBitsPerSample = 96 / (sr / 1000)
+    cp.useSBR, cp.useVQ = True, False
+    cp.numSamples = len(pcm)
+    cp.sfBands = A.psychoac.ScaleFactorBands(A.psychoac.AssignMDCTLinesFromFreqLimits(1024, sr))
+    cp.sfBandsShort = A.psychoac.ScaleFactorBands(A.psychoac.AssignMDCTLinesFromFreqLimits(128, sr))
+    p = po.make_params(sr, 2, 96)
+    p.useSBR = True
+    p.omittedBands = list(po.omitted_bands(p.sfBands))
+    frac = np.stack([po.pcm16_to_fraction(pcm[:2048, c]) for c in range(2)])
+    for flags in ((False, False, False), (False, False, True), (True, False, False)):
+        sf, ba, mant, ov = A.codec.Encode_SBR([frac[0], frac[1]], cp, *flags)
+        for c in range(2):
+            want = po.encode_channel_sbr(frac[c], p, *flags)
+            assert np.array_equal(sf[c], want[0]) and np.array_equal(ba[c], want[1]) and ov[c] == want[3]
+            n = len(mant[c])
+            assert np.array_equal(mant[c], want[2][:n]) and not np.any(want[2][n:])
+    # a frame on which the reference raises: a loud harpsichord block
+    hx = np.load(os.path.join(GOLDEN, "excerpt_harpsichord.npz"))
+    hp = po.make_params(int(hx["sr"]), 2, 96)
+    hp.useSBR = True
+    hp.omittedBands = list(po.omitted_bands(hp.sfBands))
+    cph = A.audiofile.CodingParams()
+    cph.__dict__.update(cp.__dict__)
+    cph.sampleRate = int(hx["sr"])
+    cph.targetBitsPerSample = 96 / (cph.sampleRate / 1000)
+    cph.sfBands = A.psychoac.ScaleFactorBands(A.psychoac.AssignMDCTLinesFromFreqLimits(1024, cph.sampleRate))
+    cph.sfBandsShort = A.psychoac.ScaleFactorBands(A.psychoac.AssignMDCTLinesFromFreqLimits(128, cph.sampleRate))
+    hit = False
+    for h in range(1, 12):
+        blk = [po.pcm16_to_fraction(hx["pcm"][(h - 1) * 1024:(h + 1) * 1024, c]) for c in range(2)]
+        try:
+            po.encode_channel_sbr(blk[0], hp)
+            po.encode_channel_sbr(blk[1], hp)
+        except TypeError:
+            with pytest.raises(TypeError, match="item assignment"):
+                A.codec.Encode_SBR(blk, cph)
+            hit = True
+            break
+    assert hit
+    # the file-object loop writes what the batched call writes
+    want = A.pacfile.encode_stream(pcm, sr, 96, True, use_sbr=True)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "x.pac")
+        f = A.pacfile.PACFile(path)
+        cp2 = A.audiofile.CodingParams()
+        cp2.__dict__.update(cp.__dict__)
+        f.OpenForWriting(cp2)
+        look = np.zeros((2, 2048))
+        last = cur = False
+        n_hops = len(pcm) // 1024
+        for h in range(n_hops + 1):
+            if h < n_hops:
+                data = np.stack([po.pcm16_to_fraction(pcm[h * 1024:(h + 1) * 1024, c]) for c in range(2)])
+                look = np.concatenate((data, look[:, 1024:]), axis=1)
+                nxt = bool(po.transient_detect(look))
+            else:
+                nxt = False
+            f.WriteDataBlock([look[c, :1024] for c in range(2)], cp2, last, cur, nxt)
+            last, cur = cur, nxt
+        f.Close(cp2)
+        assert open(path, "rb").read() == want

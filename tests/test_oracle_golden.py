@@ -264,3 +264,32 @@ def test_full_file_hash(name):
     for tag, bs in (("long", False), ("bs", True)):
         got = po.encode_stream(pcm, sr, 128, block_switching=bs, header_samples=declared)
         assert hashlib.sha256(got).hexdigest() == want[f"{name}:{tag}"]["sha256"]
+
+
+# ------------------------------------------- scalar mantissas + SBR (useVQ off, useSBR on)
+def _sbr_scalar_cases():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "sbr_scalar.json")))
+
+
+@pytest.mark.parametrize("case", _sbr_scalar_cases(), ids=lambda e: f"{e['excerpt']}_{e['kbps_per_channel']}")
+def test_scalar_sbr_restatement_follows_the_reference(case):
+    """tests/golden/sbr_scalar.json holds what the reference's own file loop does with useVQ off and
+    useSBR on (make_golden.py --sbr-scalar): whole-file hashes where it finishes, its exception where
+    an omitted band receives bits (coder/codec.py:541-546 -> coder/quantize.py:73-74)."""
+    import hashlib
+    ex = np.load(os.path.join(GOLDEN, f"excerpt_{case['excerpt']}.npz"))
+    pcm, sr = ex["pcm"][:case["hops"] * 1024], int(ex["sr"])
+    if case["outcome"] == "raised":
+        assert case["error"] == "TypeError: " + po.REF_SCALAR_SBR_ERROR
+        assert case["where"][-1].startswith("coder/quantize.py:74")
+        with pytest.raises(TypeError, match="item assignment"):
+            po.encode_stream(pcm, sr, case["kbps_per_channel"], case["block_switching"], use_sbr=True)
+    else:
+        pac = po.encode_stream(pcm, sr, case["kbps_per_channel"], case["block_switching"], use_sbr=True)
+        assert len(pac) == case["bytes"]
+        assert hashlib.sha256(pac).hexdigest() == case["sha256"]
+        # the reference's decoder on its own file (no omitted band is coded: plain Decode)
+        dec = po.decode_stream(pac)
+        assert list(dec.shape) == case["decoded_shape"]
+        assert hashlib.sha256(np.ascontiguousarray(dec).astype("<i2").tobytes()).hexdigest() == case["decoded_sha256"]
