@@ -301,12 +301,15 @@ class Encoder:
                    self._stream())
         return payload, n_bytes
 
-    def gather_body(self, payload, n_bytes, capacity=None):
-        """'<L nBytes' + payload of every cf, back to back (the .pac body)."""
+    def gather_body(self, payload, n_bytes, capacity=None, out=None):
+        """'<L nBytes' + payload of every cf, back to back (the .pac body).  `out`: a uint8 device
+        tensor to write into (e.g. a gather slot of dist.BitstreamGather); its length is the capacity."""
         n_cf = n_bytes.shape[0]
-        if capacity is None:
+        if out is not None:
+            capacity = out.numel()
+        elif capacity is None:
             capacity = n_cf * (self.payload_stride + 4)
-        body = self._empty((capacity,), torch.uint8)
+        body = out if out is not None else self._empty((capacity,), torch.uint8)
         total = torch.zeros((1,), dtype=torch.int64, device=self.device)
         self._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(payload), _ptr(n_bytes), _ptr(body),
                    ctypes.c_int64(capacity), _ptr(total), self._stream())

@@ -201,7 +201,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    # PACX_BENCH_FORCE_DIST=1: take the N > 1 path (process group over RCCL, barriers, max over ranks,
+    # asynchronous gather of the bodies) with whatever world size the launcher gave, 1 included -- the
+    # rehearsal of that control flow on the one GPU of a test box (tests/test_gpu_rccl.py)
+    multi = world > 1 or bool(os.environ.get("PACX_BENCH_FORCE_DIST"))
+    if args.gpus > 1 or multi:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
         rehearsal = bool(os.environ.get("PACX_BENCH_ONE_GPU"))
         if rehearsal:
@@ -260,7 +264,7 @@ def main():
     total = torch.zeros(1, dtype=torch.int64, device=dev)
     gather = None
     slot = A.dist.slot_bytes(n_cf, kbps / (sample_rate / 1000))      # bound on one rank's body
-    if world > 1:
+    if multi:
         # fixed-slot asynchronous gather of the packed bodies to rank 0 (RCCL): two send
         # buffers alternate, the gather of step i overlaps the encode of step i+1, no host
         # synchronisation and no size exchange inside a step
@@ -304,7 +308,7 @@ def main():
 
     # optional: the kernel launches of a step captured once into a hipGraph and replayed
     graph = None
-    if args.graph and world == 1:
+    if args.graph and not multi:
         device_step()
         torch.cuda.synchronize()
         try:
@@ -328,7 +332,7 @@ def main():
             for k in range(len(bodies)):
                 gather.wait(k)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -339,7 +343,7 @@ def main():
             step()
         sync_all()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -350,7 +354,7 @@ def main():
     regions = [timed_region() for _ in range(max(1, args.repeats))]
     dt = float(np.median(regions))
     regions_nogather = None
-    if corpus and world > 1:                   # with and without the gather
+    if corpus and multi:                   # with and without the gather
         do_gather[0] = False
         regions_nogather = [timed_region() for _ in range(max(1, args.repeats))]
         do_gather[0] = True
@@ -449,7 +453,7 @@ def main():
             "verified_cf": verified,
             "config": {"workload": wl + f"{kbps} kb/s/ch, {what}, int16 PCM resident in HBM; step = encode + "
                                         ".pac bit packing + body assembly" +
-                                   (" + asynchronous RCCL gather of the bodies to rank 0" if world > 1 else ""),
+                                   (" + asynchronous RCCL gather of the bodies to rank 0" if multi else ""),
                        "stereo_frames_per_s": total_cf / N_CH * args.steps / dt,
                        "timing": f"median of {len(regions)} regions of {args.steps} steps",
                        "value_min": total_cf * args.steps / max(regions),
@@ -476,13 +480,13 @@ def main():
             d2 = float(np.median(regions_nogather))
             res["config"]["value_without_gather"] = total_cf * args.steps / d2
             res["config"]["ms_per_step_without_gather"] = d2 / args.steps * 1e3
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not multi:
             if block_switched:
                 res["cpu_baseline"] = cpu_baseline_bs(pcm, sample_rate)
             else:
                 res["cpu_baseline"] = cpu_baseline(vq_kbps)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
