@@ -117,6 +117,9 @@ __shared__ int vq_row_off_s[VQ_LMAX + 1];
    after it: N(l1,k) + 2 (P(l1,k-1) - P(l1,k-a)) (+ N(l1,k-a) if negative) */
 __device__ __forceinline__ unsigned long long vq_term(const VqView &V, int l1, long long k, long long a, bool neg)
 {
+#ifdef VQ_STUB_TERM        /* timing experiment only (wrong indices): what the table lookups cost */
+    return (unsigned long long)(k + a + (neg ? 1 : 0) + l1);
+#endif
     if (l1 >= 3) {
         const long long base = vq_row_off_s[l1], ka = k - a;
         const uint64_t nk = V.n_tab[base + k], pk1 = V.p_tab[base + k - 1];
@@ -188,25 +191,52 @@ struct VqOut {
     int log_cap, log_n;
     int band;
     unsigned flags;            /* PACX_ST_VQ_* raised while coding          */
+#ifdef PACX_VQ_DEBUG
+    long long t_last;          /* phase stamps inside the band walk (measuring aid) */
+#endif
 };
+
+#ifdef PACX_VQ_DEBUG
+__device__ long long g_vq_dbg[16];
+/* inside the band walk: slots 8.. = split arithmetic, quad attempt, leaf pair, single leaf, climb, band set-up, gain */
+#define VQ_S(o, k) do { long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                        if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_vq_dbg[k], (unsigned long long)(t_ - (o).t_last)); \
+                        (o).t_last = t_; } while (0)
+#else
+#define VQ_S(o, k) do { } while (0)
+#endif
 
 __device__ __forceinline__ void vq_emit(VqOut &o, unsigned long long hi, unsigned long long lo, int width,
                                         int lane)
 {
-    if (lane == 0) {
-        if (width > 64) {
-            vq_put64(o.words, o.pos, hi, width - 64);
-            vq_put64(o.words, o.pos + width - 64, lo, 64);
-        } else {
-            vq_put64(o.words, o.pos, lo, width);
-        }
-        if (o.log && o.log_n < o.log_cap) {
-            pacx_vq_entry e;
-            e.value = lo;
-            e.width = width;
-            e.band = o.band;
-            o.log[o.log_n] = e;
-        }
+    /* The field (hi:lo < 2^width, wave-uniform) goes MSB-first to stream bit o.pos and touches at most
+       five words.  Lane k < 5 cuts word w + k out of the field itself and ORs it in: one LDS atomic for
+       the whole field and no branches, where a lane-0 writer went through up to eight atomics behind a
+       ladder of width tests (a seventh of this kernel's instructions). */
+    if (width > 0) {
+        if (width < 64)
+            lo &= (1ull << width) - 1ull;
+        const int w = o.pos >> 5;
+        const int S = 160 - (o.pos & 31) - width;         /* left shift of the field in the window of words w..w+4 */
+        const int d = S - (128 - 32 * lane);              /* word w + lane = window bits 159-32 lane .. 128-32 lane */
+        const int r = -d;
+        const unsigned up = (unsigned)lo << (d & 31);                                         /* 0 <= d < 32 */
+        const unsigned mid = (unsigned)((lo >> (r & 63)) | ((hi << ((64 - r) & 63))));          /* 1 <= r < 64 */
+        const unsigned top = (unsigned)(hi >> ((r - 64) & 63));                                /* 64 <= r     */
+        unsigned word = 0u;
+        if (d >= 0)
+            word = d < 32 ? up : 0u;
+        else
+            word = r < 64 ? mid : top;
+        if (lane < 5 && word)
+            atomicOr(&o.words[w + lane], word);
+    }
+    if (o.log && lane == 0 && o.log_n < o.log_cap) {
+        pacx_vq_entry e;
+        e.value = lo;
+        e.width = width;
+        e.band = o.band;
+        o.log[o.log_n] = e;
     }
     o.log_n += 1;
     o.pos += width;
@@ -396,6 +426,7 @@ __device__ __forceinline__ unsigned long long vq_leaf_group(const VqView &V, dou
     for (int off = W / 2; off > 0; off >>= 1)
         ysum = ysum + __shfl_xor(ysum, off, W);
     const int missing = K - (int)ysum;
+#ifndef VQ_STUB_RANK       /* timing experiment only: what the pulse ranking costs */
     {
         const double r = (l < n) ? (tgt - y) : -1.0;
         int rank = 0;
@@ -406,6 +437,10 @@ __device__ __forceinline__ unsigned long long vq_leaf_group(const VqView &V, dou
         if (l < n && rank < missing)
             y += 1.0;
     }
+#else
+    if (l < missing)
+        y += 1.0;
+#endif
     const int a = (l < n && x != 0.0 && ok) ? (int)y : 0;
     int incl = a;
 #pragma unroll
@@ -631,15 +666,19 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
             /* children live one level down */
             reg = reg + 2 * half;
             depth += 1;
+            VQ_S(o, 8);
             if (a_mid > PACX_VQ_SPLIT_BITS && a_side > PACX_VQ_SPLIT_BITS && half >= 4 && half <= 32 &&
                 depth < VQ_DEPTH && vq_quad_try(V, o, mv, sv, half, a_mid, a_side, lane)) {
                 /* both children were bottom splits: their six fields are out */
                 stack[2 * (depth - 1) + 1] = -1;            /* side done */
+                VQ_S(o, 9);
             } else if (a_mid > 0 && a_mid <= PACX_VQ_SPLIT_BITS && a_side > 0 && a_side <= PACX_VQ_SPLIT_BITS &&
                        half >= 2 && half <= 32) {
+                VQ_S(o, 9);                                 /* a quad attempt that fell through counts as one */
                 /* both children are small leaves: code them side by side */
                 vq_leaf_pair(V, o, mv, sv, half, a_mid, a_side, lane);
                 stack[2 * (depth - 1) + 1] = -1;            /* side done */
+                VQ_S(o, 10);
             } else if (a_mid > 0) {
                 cur = mv;
                 n = half;
@@ -650,6 +689,7 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
             if (bits > PACX_VQ_SPLIT_BITS)
                 o.flags |= PACX_ST_VQ_UNDEFINED;           /* deeper than any real tree */
             vq_leaf(V, o, cur, n, bits > 32 ? 32 : bits, reg, reg + n, lane);
+            VQ_S(o, 11);
         }
         if (descend)
             continue;
@@ -672,6 +712,7 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
             reg = reg - 2 * half;
             depth -= 1;
         }
+        VQ_S(o, 12);
         if (!found)
             return;
     }
@@ -701,7 +742,6 @@ struct VqArgs {
 
 #ifdef PACX_VQ_DEBUG
 /* phase stamps (s_memtime) summed over all waves: a measuring aid (build.py --phase-debug) */
-__device__ long long g_vq_dbg[16];
 #define VQ_T(k) do { long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
                      if ((threadIdx.x & 63) == 0 && vq_last) atomicAdd((unsigned long long *)&g_vq_dbg[k], (unsigned long long)(t_ - vq_last)); \
                      vq_last = t_; } while (0)
@@ -725,7 +765,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
     int *start_s = ba_s + PACX_MAX_BANDS;                             /* 33              */
     int *ticket = start_s + PACX_MAX_BANDS + 1;                       /* 1 (+2 pad)      */
     int *stack_all = ticket + 3;                                      /* waves * 2*DEPTH */
-    double *scr_all = (double *)(stack_all + VQ_WAVES * 2 * VQ_DEPTH);
+    double *xs = (double *)(stack_all + VQ_WAVES * 2 * VQ_DEPTH);     /* 1024: the block's unit shapes */
+    double *scr_all = xs + PACX_M_LONG;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long unit = blockIdx.x;
@@ -778,9 +819,14 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
             double acc = 0.0;
             for (int i = lane; i < cnt; i += 64) {
                 const double x = lin[lo + i] * up;
+                xs[lo + i] = x;
                 acc = fma(x, x, acc);
             }
             g = sqrt(wave_sum_f64(acc));
+            /* the band's shape x / gain stays in LDS for phase B (whichever wave codes the band):
+               the lines are read from memory once and no band starts with a round trip to L2 */
+            for (int i = lane; i < cnt; i += 64)
+                xs[lo + i] = xs[lo + i] / g;
         }
         if (lane == 0)
             gain_s[b] = g;
@@ -854,6 +900,9 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
         o.log_n = 0;
         o.band = b;
         o.flags = 0;
+#ifdef PACX_VQ_DEBUG
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(o.t_last) :: "memory");
+#endif
         const double gain = gain_s[b];
         if (b >= first_omit) {
             /* L = 1: every bit goes to the gain (gain_shape_alloc(R, 1)) */
@@ -867,18 +916,17 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
             if (bits_shape < 0)
                 bits_shape = 0;
             if (bits_shape != 0) {
-                double *x0 = scr;                          /* [cnt] shape = x / gain */
-                for (int i = lane; i < cnt; i += 64)
-                    x0[i] = (lin[lo + i] * up) / gain;
-                vq_fence();
+                const double *x0 = xs + lo;                /* [cnt] shape = x / gain, from phase A */
                 const int before = o.pos;
-                vq_shape(V, o, x0, cnt, bits_shape, x0 + cnt, stack, lane);
+                VQ_S(o, 13);
+                vq_shape(V, o, x0, cnt, bits_shape, scr, stack, lane);
                 bits_gain += bits_shape - (o.pos - before);
             }
             if (bits_gain < 0)
                 bits_gain = 0;
             const double g = vq_log(1.0 + 255.0 * fabs(gain / (double)cnt)) / V.log_mu1;
             vq_quantize_emit(o, g, bits_gain, lane);
+            VQ_S(o, 14);
         }
         if (o.pos != start_s[b + 1])
             o.flags |= PACX_ST_VQ_UNDEFINED;               /* a band must fill its slot exactly */
@@ -1003,7 +1051,8 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
     A.log_cap = log_cap;
     const size_t fixed = VQ_WORDS * 4 + PACX_MAX_BANDS * 8 + (PACX_MAX_BANDS + PACX_MAX_BANDS + 1 + 3) * 4 +
                          VQ_WAVES * 2 * VQ_DEPTH * 4;
-    const size_t smem = ((fixed + 15) & ~(size_t)15) + (size_t)V.scr_off[VQ_WAVES] * 8;
+    static_assert(fixed % 8 == 0, "the shapes behind the fixed part are doubles");
+    const size_t smem = fixed + PACX_M_LONG * 8 + (size_t)V.scr_off[VQ_WAVES] * 8;
     const long long units = A.mixed ? n_cf * PACX_SUB : n_cf;
     hipLaunchKernelGGL(k_vq, dim3((unsigned)units), dim3(64 * VQ_WAVES), smem, st, T, V, A);
     if (A.mixed)
@@ -1045,8 +1094,8 @@ void pacx_vq_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, 
             n = sizes_long[v->order_long[VQ_WAVES]];
         if (VQ_WAVES < nb_short && sizes_short[v->order_short[VQ_WAVES]] > n)
             n = sizes_short[v->order_short[VQ_WAVES]];
-        /* shape [n] + mid/side regions [2n + 4 depth] */
-        v->scr_off[w + 1] = v->scr_off[w] + ((3 * n + 4 * VQ_DEPTH + 1) & ~1);
+        /* mid/side regions [2n + 4 depth] (the shape itself lives in the block's xs) */
+        v->scr_off[w + 1] = v->scr_off[w] + ((2 * n + 4 * VQ_DEPTH + 1) & ~1);
     }
     v->n_tab = n_tab;
     v->p_tab = p_tab;

@@ -24,3 +24,10 @@ names = ["phase A: band gains", "wait at barrier 1", "header (wave 0) + barrier 
 print("k_vq at %d kb/s, all waves, share of a wave's time:" % kbps)
 for n, v in zip(names, t):
     print("  %-30s %.1f %%" % (n, 100.0 * v / t.sum()))
+inner = np.array(out[8:15], dtype=np.float64)
+inames = ["split arithmetic (fold, norms, angle, bit split)", "sibling bottom splits four leaves at once (or the attempt)",
+          "two sibling leaves side by side", "single leaf", "climb to the next pending half", "band set-up (x / gain)",
+          "gain quantisation"]
+print("inside the band walk (share of phase B's stamped time):")
+for n, v in zip(inames, inner):
+    print("  %-58s %.1f %%" % (n, 100.0 * v / max(inner.sum(), 1.0)))
