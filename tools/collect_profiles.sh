@@ -28,10 +28,16 @@ cd $R
 rm -rf gpurun_out/pmcs
 bash tools/pmc_step.sh && python3 tools/pmc_step_summary.py > $OUT/sq_counters_scalar128.txt
 echo "done sq counters"
+rm -rf gpurun_out/pmcs
+PMC_BENCH_ARGS="--workload vq128" bash tools/pmc_step.sh && python3 tools/pmc_step_summary.py > $OUT/sq_counters_vq128.txt
+rm -rf gpurun_out/pmcs
+echo "done sq counters vq128"
 if [ -f audio-codec_amd/libpacx_dbg.so ]; then
   PACX_LIB=$R/audio-codec_amd/libpacx_dbg.so python3 tools/psy_phase_probe.py 4096 > $OUT/phases_side_mask_tail.txt 2>&1
   PACX_LIB=$R/audio-codec_amd/libpacx_dbg.so python3 tools/mdct_phase_probe.py 8192 > $OUT/phases_mdct.txt 2>&1
   PACX_LIB=$R/audio-codec_amd/libpacx_dbg.so python3 tools/mdct_phase_probe.py 262144 >> $OUT/phases_mdct.txt 2>&1
+  PACX_LIB=$R/audio-codec_amd/libpacx_dbg.so python3 tools/vq_phase_probe.py 128 > $OUT/phases_vq.txt 2>&1
+  PACX_LIB=$R/audio-codec_amd/libpacx_dbg.so python3 tools/vq_phase_probe.py 96 >> $OUT/phases_vq.txt 2>&1
 fi
 python3 tools/mdct_sweep.py 8192 16384 65536 262144 > $OUT/mdct_sweep.txt 2>&1
 # the tail fused into the mask kernel: the same traffic passes with PACX_FUSE_TAIL=1
@@ -41,6 +47,9 @@ PACX_FUSE_TAIL=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -
 python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_f $OUT/pmc_write_f $OUT/mdct_pmc_fused.json $OUT/step_traffic_fused.json
 rm -rf $OUT/pmc_fetch_f $OUT/pmc_write_f
 cd $R
+# the step replayed from a hipGraph (not the default)
+python3 bench.py --graph --no-cpu-baseline > $OUT/bench_scalar128_graph.log 2>&1 && tail -1 $OUT/bench_scalar128_graph.log > $OUT/bench_scalar128_graph.json
+python3 bench.py --graph --workload bs128 --no-cpu-baseline > $OUT/bench_bs128_graph.log 2>&1 && tail -1 $OUT/bench_bs128_graph.log > $OUT/bench_bs128_graph.json
 # large batches: one rank's share of BASELINE configs[4] and configs[2] at full size
 python3 bench.py --frames 131072 --steps 5 --warmup 2 --repeats 5 --no-cpu-baseline > $OUT/bench_scalar128_262144.log 2>&1 && tail -1 $OUT/bench_scalar128_262144.log > $OUT/bench_scalar128_262144.json
 python3 bench.py --workload bs128 --frames 862000 --steps 5 --warmup 2 --repeats 5 --no-cpu-baseline > $OUT/bench_bs128_x1000.log 2>&1 && tail -1 $OUT/bench_bs128_x1000.log > $OUT/bench_bs128_x1000.json
