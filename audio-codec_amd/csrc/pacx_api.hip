@@ -125,7 +125,7 @@ struct pacx_handle {
     /* mixed batches: the short-coded frames' chain (MDCT, side chain, mask, tail) runs on
        streams of its own beside the long-coded frames' */
     hipStream_t short_stream, short_side_stream;
-    hipEvent_t ev_short_side, ev_short_done;
+    hipEvent_t ev_short_side, ev_short_done, ev_lists;
     std::vector<char> vq_view;        /* VqView of k_vq.hip (device pointers)   */
     std::vector<char> vqdec_view;     /* VqDecView of k_vq_dec.hip              */
     int tables_exact;                 /* every float64 table is the NumPy-evaluated one */
@@ -320,6 +320,7 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->short_side_stream = nullptr;
     h->ev_short_side = nullptr;
     h->ev_short_done = nullptr;
+    h->ev_lists = nullptr;
     h->ws_mant_cf = 0;
     h->ws_mant = nullptr;
     h->ws_dec_cf = 0;
@@ -349,7 +350,8 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         hipStreamCreateWithFlags(&h->short_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->short_side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_short_side, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_short_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_short_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_lists, hipEventDisableTiming) != hipSuccess) {
         g_create_err = "pacx_create: could not create the side stream / events";
         pacx_destroy(h);
         return PACX_E_HIP;
@@ -625,7 +627,7 @@ extern "C" void pacx_destroy(pacx_handle *h)
             (void)hipStreamSynchronize(s2);
             (void)hipStreamDestroy(s2);
         }
-    for (hipEvent_t e2 : {h->ev_short_side, h->ev_short_done})
+    for (hipEvent_t e2 : {h->ev_short_side, h->ev_short_done, h->ev_lists})
         if (e2)
             (void)hipEventDestroy(e2);
     if (h->ev_fork)
@@ -852,11 +854,19 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
         HIP_TRY(h, hipMemsetAsync(overall_scale, 0, (size_t)n_cf * PACX_SUB * sizeof(int32_t), st));
     }
-    /* mixed streams: compacted lists of the long- and of the short-coded frames, first --
-       every persistent kernel below walks its own list */
+    /* mixed streams: compacted lists of the long- and of the short-coded frames -- every
+       persistent kernel below walks its own list.  The four-stream schedule forks first: the side
+       chains and the short-block MDCT go by the flags alone and start while the lists are made
+       (+2.3 % on the block-switched bench, A/B on one box) */
+    const char *split_env = getenv("PACX_SPLIT_SHORT");       /* 0: short frames on the long frames' streams */
+    const bool split = mixed && fast && !h->T.use_sbr && !(split_env && atoi(split_env) == 0);
+    if (split)
+        HIP_TRY(h, hipEventRecord(h->ev_fork, st));
     if (mixed)
         pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,
                                 h->ws_lists + 2 * n_cf, st);
+    if (split)
+        HIP_TRY(h, hipEventRecord(h->ev_lists, st));
     /* long frames: masked threshold, SMRs, BitAlloc, scale factors / mantissas and the payload
        in ONE kernel (k_mask<1024, true>: the wave that has a frame's SMRs goes on with it; the
        lines are read from HBM once and the SMRs never leave the chip: 210 MB of HBM traffic per
@@ -897,10 +907,10 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         return post_launch(h, what);
     }
     /* fork: the side chain only reads the PCM, so it runs on its own stream next to the MDCT */
-    HIP_TRY(h, hipEventRecord(h->ev_fork, st));
+    if (!split)
+        HIP_TRY(h, hipEventRecord(h->ev_fork, st));
     HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-    const char *split_env = getenv("PACX_SPLIT_SHORT");       /* 0: short frames on the long frames' streams */
-    if (mixed && fast && !(split_env && atoi(split_env) == 0)) {
+    if (split) {
         /* A block-switched batch is two independent chains that touch disjoint frames:
              long-coded :  k_mdct_long_v2 || k_side_long  ->  k_mask<1024> (+ tail)
              short-coded:  k_mdct_short  || k_side_short ->  k_mask<128> -> k_tail_short
@@ -919,6 +929,7 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale, PACX_SUB, status,
                          h->short_stream);
         HIP_TRY(h, hipStreamWaitEvent(h->short_stream, h->ev_short_side, 0));
+        HIP_TRY(h, hipStreamWaitEvent(h->short_stream, h->ev_lists, 0));
         pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_nkept, h->ws_lines,
                          h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, nullptr, h->short_stream);
         pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
