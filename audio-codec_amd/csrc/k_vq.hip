@@ -280,27 +280,20 @@ __device__ __forceinline__ void vq_quantize_emit(VqOut &o, double x, int n_bits,
 }
 
 /* ---- one PVQ leaf --------------------------------------------------------- */
-/* xs[0..n): unit vector in LDS; t1, t2: n doubles of LDS scratch each. */
-__device__ __forceinline__ void vq_leaf(const VqView &V, VqOut &o, const double *xs, int n, int bits,
-                                        double *t1, double *t2, int lane)
+/* xs[0..n): unit vector in LDS; t1, t2: n doubles of LDS scratch each.  Returns the enumeration
+   index of the K-pulse vector (ok = false for an all-zero vector: NaN pulses in the reference). */
+__device__ __forceinline__ unsigned long long vq_leaf_idx(const VqView &V, const double *xs, int n, int K,
+                                                          double *t1, double *t2, int lane, bool &ok)
 {
-    const int K = ldc(&V.k_of[n * 33 + bits]);
-    const int width = ldc(&V.w_of[n * 33 + bits]);
-    if (K < 0) {                              /* a 1-dimensional leaf: the reference never returns */
-        o.flags |= PACX_ST_VQ_UNDEFINED;
-        return;
-    }
     /* L1 norm in np.sum order */
     for (int i = lane; i < n; i += 64)
         t1[i] = fabs(xs[i]);
     vq_fence();
     const double l1 = wave_np_sum(t1, n, lane);
     vq_fence();
-    if (!(l1 > 0.0)) {                        /* all-zero half: NaN pulses in the reference */
-        o.flags |= PACX_ST_VQ_UNDEFINED;
-        vq_emit(o, 0, 0, width, lane);
-        return;
-    }
+    ok = l1 > 0.0;
+    if (!ok)
+        return 0ull;
     /* target = |K x / l1|, y = floor(target) */
     const double kd = (double)K;
     double part = 0.0;
@@ -379,8 +372,23 @@ __device__ __forceinline__ void vq_leaf(const VqView &V, VqOut &o, const double 
             acc += vq_term(V, n - i - 1, k, a, neg);
         k_left -= __shfl(incl, 63, 64);
     }
-    const unsigned long long idx = wave_sum_u64(acc);
-    vq_emit(o, 0, idx, width, lane);
+    return wave_sum_u64(acc);
+}
+
+__device__ __forceinline__ void vq_leaf(const VqView &V, VqOut &o, const double *xs, int n, int bits,
+                                        double *t1, double *t2, int lane)
+{
+    const int K = ldc(&V.k_of[n * 33 + bits]);
+    const int width = ldc(&V.w_of[n * 33 + bits]);
+    if (K < 0) {                              /* a 1-dimensional leaf: the reference never returns */
+        o.flags |= PACX_ST_VQ_UNDEFINED;
+        return;
+    }
+    bool ok;
+    const unsigned long long idx = vq_leaf_idx(V, xs, n, K, t1, t2, lane, ok);
+    if (!ok)                                  /* all-zero half: NaN pulses in the reference */
+        o.flags |= PACX_ST_VQ_UNDEFINED;
+    vq_emit(o, 0, ok ? idx : 0ull, width, lane);
 }
 
 /* ---- several small leaves at once ------------------------------------------ */
@@ -667,12 +675,15 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
             reg = reg + 2 * half;
             depth += 1;
             VQ_S(o, 8);
+#ifdef VQ_WITH_QUAD      /* depth-first walk only: the level-by-level walk takes the trees with sibling bottom splits */
             if (a_mid > PACX_VQ_SPLIT_BITS && a_side > PACX_VQ_SPLIT_BITS && half >= 4 && half <= 32 &&
                 depth < VQ_DEPTH && vq_quad_try(V, o, mv, sv, half, a_mid, a_side, lane)) {
                 /* both children were bottom splits: their six fields are out */
                 stack[2 * (depth - 1) + 1] = -1;            /* side done */
                 VQ_S(o, 9);
-            } else if (a_mid > 0 && a_mid <= PACX_VQ_SPLIT_BITS && a_side > 0 && a_side <= PACX_VQ_SPLIT_BITS &&
+            } else
+#endif
+            if (a_mid > 0 && a_mid <= PACX_VQ_SPLIT_BITS && a_side > 0 && a_side <= PACX_VQ_SPLIT_BITS &&
                        half >= 2 && half <= 32) {
                 VQ_S(o, 9);                                 /* a quad attempt that fell through counts as one */
                 /* both children are small leaves: code them side by side */
@@ -718,6 +729,444 @@ __device__ __forceinline__ void vq_shape(const VqView &V, VqOut &o, const double
     }
 }
 
+/* ---- the split tree of one band, level by level ----------------------------- */
+/* vq_shape walks the tree depth first, one node at a time: per node a whole wave runs the
+ * scalar arithmetic of a split (two norms, six FP64 divisions, atan, quantise/dequantise of the
+ * angle, the bit split) for a handful of useful lanes, and the kernel is bound by its instruction
+ * count.  vq_shape_bfs walks the same tree breadth first:
+ *   - the nodes of one depth are independent once their parents are split;
+ *   - their folds / norms / normalisations run PACKED: P = power of two >= the largest half of the
+ *     level, 64/P nodes per pass, one node per aligned block of P lanes.  The xor butterfly over a
+ *     block adds the same numbers in the same order as the 64-lane one (plus exact zeros);
+ *   - the scalar arithmetic of a level runs once, one node per LANE;
+ *   - leaves are coded four or two at a time (vq_leaf_group), whoever their parents are;
+ *   - nothing is written while walking: every node keeps its field (value, width); at the end
+ *     the subtree widths go bottom-up, the stream positions top-down (the reference writes depth
+ *     first: angle, mid subtree, side subtree) and all fields are ORed in at once, one per lane.
+ * Same arithmetic per node as vq_shape; returns false without having written anything when the
+ * tree does not fit the node store (then vq_shape codes the band). */
+#define VQ_NC 96                       /* nodes per band tree */
+#define VQ_NODE_BYTES (VQ_NC * 8 + 5 * VQ_NC * 2 + 4 * VQ_NC + 128 + 32)
+struct VqNodes {
+    unsigned long long *val;           /* [NC] field value (a split's |side|/|mid| while its level is open) */
+    unsigned short *nn, *bb, *off, *tot, *pos;   /* [NC] length, bits, vector offset, subtree bits, stream bit */
+    unsigned char *kind, *wid, *kid;   /* [NC] 0 split / 1 leaf / 3 leaf without a field; field width; [2 NC] children */
+    unsigned char *sl, *ll;            /* [64] split / leaf nodes of the open level */
+    unsigned char *lvl;                /* [VQ_DEPTH + 2] first node of every depth */
+    __device__ __forceinline__ void bind(unsigned char *p)
+    {
+        val = (unsigned long long *)p;
+        nn = (unsigned short *)(p + VQ_NC * 8);
+        bb = nn + VQ_NC;
+        off = bb + VQ_NC;
+        tot = off + VQ_NC;
+        pos = tot + VQ_NC;
+        kind = (unsigned char *)(pos + VQ_NC);
+        wid = kind + VQ_NC;
+        kid = wid + VQ_NC;
+        sl = kid + 2 * VQ_NC;
+        ll = sl + 64;
+        lvl = ll + 64;
+    }
+};
+
+/* a field of up to 64 bits, by ONE lane (fields of different lanes may share words) */
+__device__ __forceinline__ void vq_put_field(unsigned *words, int pos, unsigned long long val, int width)
+{
+    const int w = pos >> 5, t = (pos & 31) + width;
+    if (t <= 32) {
+        atomicOr(&words[w], (unsigned)val << (32 - t));
+    } else if (t <= 64) {
+        const unsigned long long v = val << (64 - t);
+        atomicOr(&words[w], (unsigned)(v >> 32));
+        atomicOr(&words[w + 1], (unsigned)v);
+    } else {
+        const int r = t - 64;
+        const unsigned long long v = val >> r;
+        atomicOr(&words[w], (unsigned)(v >> 32));
+        atomicOr(&words[w + 1], (unsigned)v);
+        atomicOr(&words[w + 2], (unsigned)val << (32 - r));
+    }
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int lane, int &total)
+{
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off)
+            incl += t;
+    }
+    total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+
+__device__ __forceinline__ bool vq_shape_bfs(const VqView &V, VqOut &o, const double *x0, int n0, int bits0,
+                                             double *region, int region_len, const VqNodes &N, int lane)
+{
+    const double half_pi = 1.5707963267948966;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int buf_cap = region_len / 2;
+    double *bufs[2] = {region, region + buf_cap};
+    if (lane == 0) {
+        N.nn[0] = (unsigned short)n0;
+        N.bb[0] = (unsigned short)bits0;
+        N.off[0] = 0;
+        N.kind[0] = 1;                                     /* the caller only comes with bits0 > 0 */
+        N.wid[0] = 0;
+        N.val[0] = 0ull;
+        N.kid[0] = N.kid[1] = 0xFF;
+        N.lvl[0] = 0;
+    }
+    if (bits0 > PACX_VQ_SPLIT_BITS && lane == 0)
+        N.kind[0] = 0;
+    int count = 1, lev_b = 0, lev_e = 1, depth = 0;
+    bool undefined = false;                                /* per lane; joined at the end */
+    const double *cur = x0;
+    for (;;) {
+        vq_fence();
+        /* the open level: its splits and its leaves */
+        int n_split = 0, n_leaf = 0;
+        for (int base = lev_b; base < lev_e; base += 64) {
+            const int j = base + lane;
+            const int kd = (j < lev_e) ? N.kind[j] : 2;
+            const unsigned long long ms = __builtin_amdgcn_ballot_w64(kd == 0);
+            const unsigned long long ml = __builtin_amdgcn_ballot_w64(kd == 1);
+            if (n_split + __popcll(ms) > 64 || n_leaf + __popcll(ml) > 64)
+                return false;
+            if (kd == 0)
+                N.sl[n_split + __popcll(ms & below)] = (unsigned char)j;
+            if (kd == 1)
+                N.ll[n_leaf + __popcll(ml & below)] = (unsigned char)j;
+            n_split += __popcll(ms);
+            n_leaf += __popcll(ml);
+        }
+        vq_fence();
+        double *nxt = bufs[depth & 1];                     /* free while this level's leaves are coded */
+        /* ---- leaves of this level (vectors in cur) */
+        if (n_leaf) {
+            const int my = (lane < n_leaf) ? N.ll[lane] : 0;
+            const int myn = (lane < n_leaf) ? N.nn[my] : 0;
+            const unsigned long long big = __builtin_amdgcn_ballot_w64(myn > 32);
+            const int nmax = wave_max_i32(myn > 32 ? 0 : myn);
+            /* single leaves of more than 32 components (upper levels only) */
+            for (unsigned long long m = big; m; m &= m - 1) {
+                const int k = __builtin_ctzll(m);
+                const int node = N.ll[k];
+                const int n = N.nn[node];
+                int bits = N.bb[node];
+                bits = bits > 32 ? 32 : bits;
+                const int K = ldc(&V.k_of[n * 33 + bits]);
+                const int width = ldc(&V.w_of[n * 33 + bits]);
+                bool ok = true;
+                const unsigned long long idx = vq_leaf_idx(V, cur + N.off[node], n, K, nxt, nxt + n, lane, ok);
+                if (!ok)
+                    undefined = true;
+                if (lane == 0) {
+                    N.val[node] = ok ? idx : 0ull;
+                    N.wid[node] = (unsigned char)width;
+                }
+            }
+            if (nmax > 0) {
+                const int lw = nmax <= 16 ? 4 : 5;           /* log2 of the group width */
+                const int W = 1 << lw, G = 64 >> lw;
+                /* compact list of the small leaves in lane order */
+                const bool small = lane < n_leaf && myn <= 32;
+                const unsigned long long msm = __builtin_amdgcn_ballot_w64(small);
+                const int n_small = __popcll(msm);
+                vq_fence();
+                if (small)
+                    N.sl[__popcll(msm & below)] = (unsigned char)my;   /* the split list is rebuilt below */
+                vq_fence();
+                for (int p0 = 0; p0 < n_small; p0 += G) {
+                    const int g = lane >> lw, l = lane & (W - 1);
+                    const bool valid = p0 + g < n_small;
+                    const int node = valid ? N.sl[p0 + g] : 0;
+                    const int n = valid ? N.nn[node] : 0;
+                    int bits = valid ? N.bb[node] : 0;
+                    bits = bits > 32 ? 32 : bits;
+                    const int K = valid ? V.k_of[n * 33 + bits] : 0;
+                    const int width = valid ? V.w_of[n * 33 + bits] : 0;
+                    const double x = (valid && l < n) ? cur[N.off[node] + l] : 0.0;
+                    bool ok = false;
+                    unsigned long long term;
+                    if (lw == 4)
+                        term = vq_leaf_group<16>(V, x, n, K < 0 ? 0 : K, l, ok);
+                    else
+                        term = vq_leaf_group<32>(V, x, n, K < 0 ? 0 : K, l, ok);
+                    if (valid && l == 0) {
+                        if (K < 0) {                       /* a 1-dimensional leaf: the reference never returns */
+                            N.kind[node] = 3;
+                            N.wid[node] = 0;
+                            N.val[node] = 0ull;
+                        } else {
+                            N.val[node] = ok ? term : 0ull;
+                            N.wid[node] = (unsigned char)width;
+                        }
+                    }
+                    if (valid && (K < 0 || !ok))
+                        undefined = true;
+                }
+                /* the split list again (the leaf passes borrowed it) */
+                vq_fence();
+                int ns2 = 0;
+                for (int base = lev_b; base < lev_e; base += 64) {
+                    const int j = base + lane;
+                    const int kd = (j < lev_e) ? N.kind[j] : 2;
+                    const unsigned long long ms = __builtin_amdgcn_ballot_w64(kd == 0);
+                    if (kd == 0)
+                        N.sl[ns2 + __popcll(ms & below)] = (unsigned char)j;
+                    ns2 += __popcll(ms);
+                }
+                vq_fence();
+            }
+        }
+        if (!n_split)
+            break;
+        if (depth + 1 > VQ_DEPTH)
+            return false;
+        /* ---- splits of this level: where their children's vectors go */
+        const int snode = (lane < n_split) ? N.sl[lane] : 0;
+        const int sn = (lane < n_split) ? N.nn[snode] : 0;
+        const int shalf = sn - sn / 2;
+        int room;
+        const int noff = wave_excl_scan_i32(2 * shalf, lane, room);
+        if (room > buf_cap)
+            return false;
+        if (lane < n_split)
+            N.tot[snode] = (unsigned short)noff;
+        const unsigned long long wide = __builtin_amdgcn_ballot_w64(shalf > 64);
+        const int hmax = wave_max_i32(shalf > 64 ? 0 : shalf);
+        vq_fence();
+        /* nodes of more than 128 components: one at a time, lanes strided over the half */
+        for (unsigned long long m = wide; m; m &= m - 1) {
+            const int k = __builtin_ctzll(m);
+            const int node = N.sl[k];
+            const int n = N.nn[node];
+            const double *src = cur + N.off[node];
+            const int cut = n / 2, half = n - cut;
+            double *mv = nxt + N.tot[node], *sv = mv + half;
+            double mm = 0.0, ss = 0.0;
+            for (int i = lane; i < half; i += 64) {
+                const double left = (i < cut) ? src[i] : 0.0;
+                const double right = src[cut + i];
+                const double mid = (left + right) / 2.0;
+                const double sd = (left - right) / 2.0;
+                mv[i] = mid;
+                sv[i] = sd;
+                mm = fma(mid, mid, mm);
+                ss = fma(sd, sd, ss);
+            }
+            const double m_l2 = sqrt(wave_sum_f64(mm));
+            const double s_l2 = sqrt(wave_sum_f64(ss));
+            for (int i = lane; i < half; i += 64) {
+                if (m_l2 != 0.0)
+                    mv[i] = mv[i] / m_l2;
+                if (s_l2 != 0.0)
+                    sv[i] = sv[i] / s_l2;
+            }
+            if (lane == 0)
+                N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
+        }
+        /* the others packed: one node per aligned block of P lanes */
+        if (hmax > 0) {
+            int lp = 0;
+            while ((1 << lp) < hmax)
+                ++lp;
+            const int P = 1 << lp, G = 64 >> lp;
+            const bool narrow = lane < n_split && shalf <= 64;
+            const unsigned long long mn = __builtin_amdgcn_ballot_w64(narrow);
+            const int n_narrow = __popcll(mn);
+            if (narrow)
+                N.ll[__popcll(mn & below)] = (unsigned char)snode;   /* the leaf list is done with */
+            vq_fence();
+            for (int p0 = 0; p0 < n_narrow; p0 += G) {
+                const int g = lane >> lp, i = lane & (P - 1);
+                const bool valid = p0 + g < n_narrow;
+                const int node = valid ? N.ll[p0 + g] : 0;
+                const int n = valid ? N.nn[node] : 0;
+                const int cut = n / 2, half = n - cut;
+                const double *src = cur + (valid ? N.off[node] : 0);
+                const bool mine = i < half;
+                const double left = (mine && i < cut) ? src[i] : 0.0;
+                const double right = mine ? src[cut + i] : 0.0;
+                double mid = mine ? (left + right) / 2.0 : 0.0;
+                double sd = mine ? (left - right) / 2.0 : 0.0;
+                double mm = fma(mid, mid, 0.0), ss = fma(sd, sd, 0.0);
+                for (int off = P >> 1; off > 0; off >>= 1) {
+                    mm = mm + __shfl_xor(mm, off, 64);
+                    ss = ss + __shfl_xor(ss, off, 64);
+                }
+                const double m_l2 = sqrt(mm), s_l2 = sqrt(ss);
+                if (m_l2 != 0.0)
+                    mid = mid / m_l2;
+                if (s_l2 != 0.0)
+                    sd = sd / s_l2;
+                if (mine) {
+                    double *mv = nxt + N.tot[node];
+                    mv[i] = mid;
+                    mv[half + i] = sd;
+                }
+                if (valid && i == 0)
+                    N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
+            }
+        }
+        vq_fence();
+        /* ---- the level's scalar arithmetic, one split per lane; its children join the store */
+        {
+            const bool has = lane < n_split;
+            const int bits = has ? N.bb[snode] : 0;
+            const int half = has ? shalf : 1;
+            const double q = has ? __longlong_as_double((long long)N.val[snode]) : -1.0;
+            const double theta = (q < 0.0) ? 0.0 : vq_atan(q);
+            const int a_theta = (int)floor((double)bits / (double)half + V.half_log2[half]);
+            int a_rest = bits - a_theta;
+            if (a_rest < 0)
+                a_rest = 0;
+            const double tn = theta / half_pi;
+            double theta_q = 0.0;
+            unsigned long long code = 0ull;
+            int w_theta = 0;
+            if (a_theta > 62) {
+                if (has)
+                    undefined = true;
+            } else if (a_theta > 0) {
+                if (tn >= 1.0) {
+                    code = (1ull << (a_theta - 1)) - 1ull;
+                } else {
+                    const double factor = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+                    code = (unsigned long long)floor((factor * tn + 1.0) * 0.5);
+                }
+                w_theta = a_theta;
+                const unsigned long long mag = code & ((1ull << (a_theta - 1)) - 1ull);
+                const double den = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+                double dq = (double)(2ull * mag) / den;
+                if (code >> (a_theta - 1))
+                    dq = -dq;
+                theta_q = dq * half_pi;
+            }
+            int a_mid = 0;
+            if (theta_q != 0.0) {
+                double lt;
+                if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta_q > 0.0)
+                    lt = V.log2_tan[((1 << (a_theta - 1)) - 1) + (int)code];
+                else
+                    lt = vq_log2_tan(theta_q);
+                const double v = ((double)a_rest - (double)(half - 1) * lt) / 2.0;
+                const double f = floor(v);
+                a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
+            }
+            const int a_side = a_rest - a_mid;
+            const int c_mid = (has && a_mid > 0) ? 1 : 0, c_side = (has && a_side > 0) ? 1 : 0;
+            int born;
+            const int first = count + wave_excl_scan_i32(c_mid + c_side, lane, born);
+            if (count + born > VQ_NC)
+                return false;
+            if (has) {
+                N.val[snode] = code;
+                N.wid[snode] = (unsigned char)w_theta;
+                N.kid[2 * snode] = c_mid ? (unsigned char)first : 0xFF;
+                N.kid[2 * snode + 1] = c_side ? (unsigned char)(first + c_mid) : 0xFF;
+                const int at = N.tot[snode];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int a = c ? a_side : a_mid;
+                    if (a <= 0)
+                        continue;
+                    const int id = c ? first + c_mid : first;
+                    const bool splits = a > PACX_VQ_SPLIT_BITS && depth + 1 < VQ_DEPTH;
+                    if (a > PACX_VQ_SPLIT_BITS && !splits)
+                        undefined = true;                  /* deeper than any real tree */
+                    N.nn[id] = (unsigned short)half;
+                    N.bb[id] = (unsigned short)(a > 65535 ? 65535 : a);
+                    N.off[id] = (unsigned short)(at + (c ? half : 0));
+                    N.kind[id] = splits ? 0 : 1;
+                    N.wid[id] = 0;
+                    N.val[id] = 0ull;
+                    N.kid[2 * id] = N.kid[2 * id + 1] = 0xFF;
+                }
+            }
+            count += born;
+        }
+        depth += 1;
+        if (lane == 0)
+            N.lvl[depth] = (unsigned char)lev_e;
+        lev_b = lev_e;
+        lev_e = count;
+        cur = nxt;
+    }
+    /* ---- widths bottom-up, positions (and field numbers) top-down, then every field at once */
+    if (lane == 0)
+        N.lvl[depth + 1] = (unsigned char)count;
+    vq_fence();
+    /* field counts ride in nn[] (lengths are not needed any more), field numbers in off[] */
+    for (int d = depth; d >= 0; --d) {
+        const int b = N.lvl[d], e = N.lvl[d + 1];
+        for (int j = b + lane; j < e; j += 64) {
+            const int k0 = N.kid[2 * j], k1 = N.kid[2 * j + 1];
+            int t = N.wid[j], f = (N.kind[j] == 3) ? 0 : 1;
+            if (k0 != 0xFF) { t += N.tot[k0]; f += N.nn[k0]; }
+            if (k1 != 0xFF) { t += N.tot[k1]; f += N.nn[k1]; }
+            N.tot[j] = (unsigned short)t;
+            N.nn[j] = (unsigned short)f;
+        }
+        vq_fence();
+    }
+    if (lane == 0) {
+        N.pos[0] = (unsigned short)o.pos;
+        N.off[0] = (unsigned short)o.log_n;
+    }
+    vq_fence();
+    for (int d = 0; d <= depth; ++d) {
+        const int b = N.lvl[d], e = N.lvl[d + 1];
+        for (int j = b + lane; j < e; j += 64) {
+            const int k0 = N.kid[2 * j], k1 = N.kid[2 * j + 1];
+            int p = N.pos[j] + N.wid[j], r = N.off[j] + ((N.kind[j] == 3) ? 0 : 1);
+            if (k0 != 0xFF) {
+                N.pos[k0] = (unsigned short)p;
+                N.off[k0] = (unsigned short)r;
+                p += N.tot[k0];
+                r += N.nn[k0];
+            }
+            if (k1 != 0xFF) {
+                N.pos[k1] = (unsigned short)p;
+                N.off[k1] = (unsigned short)r;
+            }
+        }
+        vq_fence();
+    }
+    for (int j = lane; j < count; j += 64) {
+        const int w = N.wid[j];
+        unsigned long long v = N.val[j];
+        if (w > 0 && w < 64)
+            v &= (1ull << w) - 1ull;
+        if (w > 0)
+            vq_put_field(o.words, N.pos[j], v, w);
+        if (o.log && N.kind[j] != 3 && N.off[j] < o.log_cap) {
+            pacx_vq_entry e;
+            e.value = v;
+            e.width = w;
+            e.band = o.band;
+            o.log[N.off[j]] = e;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(undefined))
+        o.flags |= PACX_ST_VQ_UNDEFINED;
+    o.pos += N.tot[0];
+    o.log_n += N.nn[0];
+    vq_fence();
+    return true;
+}
+
 /* ------------------------------------------------------------------ kernel */
 struct VqArgs {
     const uint8_t *flags;
@@ -738,6 +1187,7 @@ struct VqArgs {
     pacx_vq_entry *log;
     int32_t *log_count;
     int log_cap;               /* entries per band                          */
+    int bfs;                   /* shape bits from which a band's tree is walked level by level (vq_shape_bfs); 0: never */
 };
 
 #ifdef PACX_VQ_DEBUG
@@ -768,7 +1218,10 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
     double *xs = (double *)(stack_all + VQ_WAVES * 2 * VQ_DEPTH);     /* 1024: the block's unit shapes */
     double *scr_all = xs + PACX_M_LONG;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          /* uniform: the per-wave LDS pointers stay scalar */
+    VqNodes N;
+    N.bind((unsigned char *)(scr_all + V.scr_off[VQ_WAVES]) + wave * VQ_NODE_BYTES);
     const long long unit = blockIdx.x;
     const long long cf = A.mixed ? unit / PACX_SUB : unit;
     const int sb = A.mixed ? (int)(unit % PACX_SUB) : 0;
@@ -919,7 +1372,14 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
                 const double *x0 = xs + lo;                /* [cnt] shape = x / gain, from phase A */
                 const int before = o.pos;
                 VQ_S(o, 13);
+#if defined(VQ_ONLY_BFS)
+                vq_shape_bfs(V, o, x0, cnt, bits_shape, scr, 2 * cnt + 4 * VQ_DEPTH, N, lane);
+#elif defined(VQ_ONLY_DFS)
                 vq_shape(V, o, x0, cnt, bits_shape, scr, stack, lane);
+#else
+                if (!A.bfs || bits_shape < A.bfs || !vq_shape_bfs(V, o, x0, cnt, bits_shape, scr, 2 * cnt + 4 * VQ_DEPTH, N, lane))
+                    vq_shape(V, o, x0, cnt, bits_shape, scr, stack, lane);
+#endif
                 bits_gain += bits_shape - (o.pos - before);
             }
             if (bits_gain < 0)
@@ -1049,10 +1509,17 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
     A.log = log;
     A.log_count = log_count;
     A.log_cap = log_cap;
+    {
+        /* PACX_VQ_BFS: 0 = depth-first walk only, n = level by level from n shape bits (1: every band).
+           Small trees are quicker depth first (the level walk has a fixed cost per level); the crossover
+           was measured at 96-128 bits (tools/vq_bfs_sweep.sh) */
+        const char *e = getenv("PACX_VQ_BFS");
+        A.bfs = e ? atoi(e) : 112;
+    }
     const size_t fixed = VQ_WORDS * 4 + PACX_MAX_BANDS * 8 + (PACX_MAX_BANDS + PACX_MAX_BANDS + 1 + 3) * 4 +
                          VQ_WAVES * 2 * VQ_DEPTH * 4;
     static_assert(fixed % 8 == 0, "the shapes behind the fixed part are doubles");
-    const size_t smem = fixed + PACX_M_LONG * 8 + (size_t)V.scr_off[VQ_WAVES] * 8;
+    const size_t smem = fixed + PACX_M_LONG * 8 + (size_t)V.scr_off[VQ_WAVES] * 8 + (size_t)VQ_WAVES * VQ_NODE_BYTES;
     const long long units = A.mixed ? n_cf * PACX_SUB : n_cf;
     hipLaunchKernelGGL(k_vq, dim3((unsigned)units), dim3(64 * VQ_WAVES), smem, st, T, V, A);
     if (A.mixed)
