@@ -1187,6 +1187,7 @@ struct VqArgs {
     pacx_vq_entry *log;
     int32_t *log_count;
     int log_cap;               /* entries per band                          */
+    int redo;                  /* 1: code only the units k_vq_frame left (n_bytes / unit_bits = -1) */
     int bfs;                   /* shape bits from which a band's tree is walked level by level (vq_shape_bfs); 0: never */
 };
 
@@ -1239,6 +1240,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
         if (st & PACX_ST_ZERO_SUBBLOCK)
             return;
     }
+    if (A.redo && (is_short ? A.unit_bits[unit * 2] : A.n_bytes[cf]) != -1)
+        return;                                /* k_vq_frame coded this unit */
     const int nb = is_short ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = is_short ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = is_short ? T.band_lines_short : T.band_lines_long;
@@ -1425,6 +1428,672 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
     VQ_T(5);
 }
 
+/* ------------------------------------------------ frame-level walk (k_vq_frame) */
+/* The trees of ALL bands of a (sub-)block, level by level, by one workgroup.
+ *
+ * k_vq hands bands to waves; inside a band a wave works on one tree node (or a few siblings) at a
+ * time, and most bands are small: a root split and two leaves keep a whole wave busy for three
+ * passes.  Here every node of every band's tree goes into one store:
+ *   level 0 = the bands' roots, level d+1 = the children of level d;
+ *   per level the nodes are sorted into classes of equal lane footprint (leaves of up to 16 / up to
+ *   32 components, splits whose half fits 8 / 16 / 32 / 64 lanes, the few larger ones) and coded in
+ *   PACKED passes -- eight small splits or four small leaves per pass whichever bands they belong
+ *   to -- the passes dealt round-robin to the four waves;
+ *   the scalar arithmetic of the level's splits runs one split per LANE, 64 at a time;
+ *   nothing is written while walking; at the end subtree widths go bottom-up and stream positions
+ *   top-down (depth-first order inside a band, bands at their static positions), every field is
+ *   ORed in by its own lane, and the gains of all bands are quantised side by side.
+ * Arithmetic per node is that of vq_shape / vq_leaf / vq_leaf_group.  A unit whose trees do not fit
+ * the store (bit rates far above the shipped ones) is left to k_vq: n_bytes / unit_bits = -1. */
+#define VQF_NCAP 448                   /* nodes per (sub-)block */
+#define VQF_NLV 256                    /* nodes per level */
+#define VQF_BUF (PACX_M_LONG + 160)    /* doubles per level buffer */
+#define VQF_FIXED 3056                 /* words, gains, allocations, starts, ticket, gain bits, roots, counters */
+#define VQF_SMEM (VQF_FIXED + 2 * VQF_BUF * 8 + VQF_NCAP * 8 + 6 * VQF_NCAP * 2 + 4 * VQF_NCAP + VQF_NLV * 2 + 64 + 64)
+
+struct VqfStore {
+    unsigned long long *val;
+    unsigned short *nn, *bb, *off, *tot, *pos, *kid;
+    unsigned char *kind, *wid, *band, *has;
+    unsigned short *ord;               /* [NLV] the open level's nodes grouped by class */
+    int *cls;                          /* [9] class starts in ord, [9..15] spare */
+    unsigned short *lvl;               /* [VQ_DEPTH + 2] first node of every depth */
+    __device__ __forceinline__ void bind(unsigned char *p)
+    {
+        val = (unsigned long long *)p;
+        nn = (unsigned short *)(p + VQF_NCAP * 8);
+        bb = nn + VQF_NCAP;
+        off = bb + VQF_NCAP;
+        tot = off + VQF_NCAP;
+        pos = tot + VQF_NCAP;
+        kid = pos + VQF_NCAP;
+        kind = (unsigned char *)(kid + VQF_NCAP);
+        wid = kind + VQF_NCAP;
+        band = wid + VQF_NCAP;
+        has = band + VQF_NCAP;
+        ord = (unsigned short *)(has + VQF_NCAP);
+        cls = (int *)(ord + VQF_NLV);
+        lvl = (unsigned short *)(cls + 16);
+    }
+};
+
+/* QuantizeUniform(x, n_bits) for x >= 0 as vq_quantize_emit evaluates it: the code's two words */
+__device__ __forceinline__ void vq_quantize_code(double x, int n_bits, unsigned long long &hi, unsigned long long &lo)
+{
+    hi = 0;
+    lo = 0;
+    if (x >= 1.0) {
+        const int ones = n_bits - 1;
+        if (ones >= 64) {
+            lo = ~0ull;
+            hi = (ones - 64 >= 64) ? ~0ull : ((1ull << (ones - 64)) - 1ull);
+        } else {
+            lo = (ones == 0) ? 0ull : ((~0ull) >> (64 - ones));
+        }
+    } else {
+        const double factor = (n_bits <= 53) ? (double)((1ull << n_bits) - 1ull) : ldexp(1.0, n_bits);
+        const double code = floor((factor * x + 1.0) * 0.5);
+        if (n_bits <= 64) {
+            lo = (unsigned long long)code;
+        } else {
+            const double top = floor(ldexp(code, -64));
+            hi = (unsigned long long)top;
+            lo = (unsigned long long)(code - ldexp(top, 64));
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqView V, VqArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *words = (unsigned *)smem;                               /* VQ_WORDS        */
+    double *gain_s = (double *)(smem + VQ_WORDS * 4);                 /* 32              */
+    int *ba_s = (int *)(gain_s + PACX_MAX_BANDS);                     /* 32              */
+    int *start_s = ba_s + PACX_MAX_BANDS;                             /* 33              */
+    int *misc = start_s + PACX_MAX_BANDS + 1;                         /* 3: node count, overflow, flags */
+    int *bg_s = misc + 3;                                             /* 32 gain bits before the shape's slack */
+    unsigned short *root_s = (unsigned short *)(bg_s + PACX_MAX_BANDS);   /* 32 root node of a band, 0xFFFF none */
+    int *bs_s = (int *)(root_s + PACX_MAX_BANDS);                     /* 32 shape bits  (16 spare ints follow) */
+    double *buf0 = (double *)(smem + VQF_FIXED);                      /* two level buffers of VQF_BUF doubles */
+    VqfStore N;
+    N.bind(smem + VQF_FIXED + 2 * VQF_BUF * 8);
+    static_assert(VQ_WORDS * 4 + PACX_MAX_BANDS * 8 + PACX_MAX_BANDS * 4 + (PACX_MAX_BANDS + 1) * 4 + 3 * 4 +
+                  PACX_MAX_BANDS * 4 + PACX_MAX_BANDS * 2 + PACX_MAX_BANDS * 4 <= VQF_FIXED && VQF_FIXED % 16 == 0,
+                  "fixed part of k_vq_frame's LDS");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const long long unit = blockIdx.x;
+    const long long cf = A.mixed ? unit / PACX_SUB : unit;
+    const int sb = A.mixed ? (int)(unit % PACX_SUB) : 0;
+    if (cf >= A.n_cf)
+        return;
+    const long long frame = cf / A.n_ch;
+    const unsigned fl = A.flags ? A.flags[frame] : 0u;
+    const bool is_short = A.mixed && (fl & 2u);
+    if (!is_short && sb != 0)
+        return;
+    if (is_short && A.status_in) {             /* hop dropped: nothing to code */
+        unsigned st = 0;
+        for (int c = 0; c < A.n_ch; ++c)
+            st |= A.status_in[frame * A.n_ch + c];
+        if (st & PACX_ST_ZERO_SUBBLOCK)
+            return;
+    }
+    const int nb = is_short ? T.nb_short : T.nb_long;
+    const int32_t *__restrict__ lower = is_short ? T.band_lower_short : T.band_lower_long;
+    const int32_t *__restrict__ count = is_short ? T.band_lines_short : T.band_lines_long;
+    const int first_omit = (!is_short && T.use_sbr) ? T.first_omitted : nb;
+    const long long boff = cf * T.band_stride + (is_short ? sb * T.nb_short : 0);
+    const double *__restrict__ lin = A.lines + cf * PACX_M_LONG + (is_short ? sb * PACX_M_SHORT : 0);
+    const int ov = A.overall[cf * PACX_SUB + sb];
+    const double up = (double)(1 << ov);
+    const int lead = is_short ? 0 : 3;
+    const double half_pi = 1.5707963267948966;
+
+    for (int i = tid; i < VQ_WORDS; i += 64 * VQ_WAVES)
+        words[i] = 0u;
+    for (int i = tid; i <= min(V.l_max, VQ_LMAX); i += 64 * VQ_WAVES)
+        vq_row_off_s[i] = V.row_off[i];
+    if (tid < 3)
+        misc[tid] = 0;
+    /* phase A: gains; the unit shapes x / gain are level 0 of the walk (bufs[0], at the band's lines) */
+    double *xs = buf0;
+    for (int b = wave; b < nb; b += VQ_WAVES) {
+        double g;
+        if (b >= first_omit) {
+            const double v = A.sbr_mean[cf * PACX_SUB + (b - first_omit)] * up;
+            g = sqrt(v * v);
+        } else {
+            const int lo = ldc(&lower[b]), cnt = ldc(&count[b]);
+            double acc = 0.0;
+            for (int i = lane; i < cnt; i += 64) {
+                const double x = lin[lo + i] * up;
+                xs[lo + i] = x;
+                acc = fma(x, x, acc);
+            }
+            g = sqrt(wave_sum_f64(acc));
+            for (int i = lane; i < cnt; i += 64)
+                xs[lo + i] = xs[lo + i] / g;
+        }
+        if (lane == 0)
+            gain_s[b] = g;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        /* final allocations, band positions, header fields, the roots of the trees */
+        int ba = 0, r_bits = 0, cnt = 1;
+        if (lane < nb) {
+            ba = A.bit_alloc[boff + lane];
+            if (ba && gain_s[lane] == 0.0)
+                ba = 0;                                   /* coder/codec.py:352-353 */
+            cnt = (lane >= first_omit) ? 1 : count[lane];
+            r_bits = ba * cnt;
+            A.bit_alloc[boff + lane] = ba;
+            ba_s[lane] = ba;
+        }
+        int incl = r_bits;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += t;
+        }
+        const int head = lead + T.n_scale_bits + T.n_mant_size_bits * nb;
+        if (lane < nb)
+            start_s[lane] = head + incl - r_bits;
+        if (lane == nb - 1)
+            start_s[nb] = head + incl;
+        if (lane == 0) {
+            if (!is_short) {
+                vq_put32(words, 0, fl & 1u, 1);
+                vq_put32(words, 1, (fl >> 1) & 1u, 1);
+                vq_put32(words, 2, (fl >> 2) & 1u, 1);
+            }
+            vq_put32(words, lead, (unsigned)ov, T.n_scale_bits);
+        }
+        if (lane < nb)
+            vq_put32(words, lead + T.n_scale_bits + T.n_mant_size_bits * lane, (unsigned)(ba ? ba - 1 : 0),
+                     T.n_mant_size_bits);
+        /* gain_shape_alloc of the band; an omitted band is one number: every bit to its gain */
+        int bits_gain = ba, bits_shape = 0;
+        if (lane < nb && lane < first_omit && ba) {
+            bits_gain = (int)floor((double)r_bits / (double)cnt + V.half_log2[cnt]);
+            bits_shape = r_bits - bits_gain;
+            if (bits_shape < 0)
+                bits_shape = 0;
+        }
+        const bool rooted = lane < nb && bits_shape != 0;
+        const unsigned long long mr = __builtin_amdgcn_ballot_w64(rooted);
+        const int id = __popcll(mr & below);
+        if (lane < nb) {
+            bg_s[lane] = bits_gain;
+            bs_s[lane] = bits_shape;
+            root_s[lane] = rooted ? (unsigned short)id : 0xFFFF;
+        }
+        if (rooted) {
+            N.nn[id] = (unsigned short)cnt;
+            N.bb[id] = (unsigned short)bits_shape;
+            N.off[id] = (unsigned short)lower[lane];
+            N.kind[id] = bits_shape > PACX_VQ_SPLIT_BITS ? 0 : 1;
+            N.wid[id] = 0;
+            N.band[id] = (unsigned char)lane;
+            N.has[id] = 0;
+            N.kid[id] = 0;
+            N.val[id] = 0ull;
+        }
+        if (lane == 0) {
+            misc[0] = __popcll(mr);
+            N.lvl[0] = 0;
+        }
+    }
+    __syncthreads();
+
+    bool undefined = false;
+    int lev_b = 0, lev_e = misc[0], depth = 0;
+    for (;;) {
+        const double *cur = buf0 + (depth & 1) * VQF_BUF;
+        double *nxt = buf0 + ((depth + 1) & 1) * VQF_BUF;
+        /* ---- wave 0: the level's nodes grouped by class, room for what they write to the next buffer */
+        if (wave == 0) {
+            int cnt_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (lev_e - lev_b > VQF_NLV && lane == 0)
+                misc[1] = 1;
+            for (int base = lev_b; base < lev_e && lev_e - lev_b <= VQF_NLV; base += 64) {
+                const int j = base + lane;
+                int c = 8;
+                if (j < lev_e) {
+                    const int n = N.nn[j], half = n - n / 2;
+                    if (N.kind[j] == 1)
+                        c = n <= 16 ? 0 : (n <= 32 ? 1 : 2);
+                    else
+                        c = half <= 8 ? 3 : (half <= 16 ? 4 : (half <= 32 ? 5 : (half <= 64 ? 6 : 7)));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    cnt_c[k] += __popcll(__builtin_amdgcn_ballot_w64(c == k));
+            }
+            int start_c[9];
+            start_c[0] = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                start_c[k + 1] = start_c[k] + cnt_c[k];
+            if (lane < 9) {
+                int v = 0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    v = (lane == k) ? start_c[k] : v;
+                N.cls[lane] = v;
+            }
+            int run_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int carry = 0;
+            for (int base = lev_b; base < lev_e && lev_e - lev_b <= VQF_NLV; base += 64) {
+                const int j = base + lane;
+                int c = 8, need = 0;
+                if (j < lev_e) {
+                    const int n = N.nn[j], half = n - n / 2;
+                    if (N.kind[j] == 1) {
+                        c = n <= 16 ? 0 : (n <= 32 ? 1 : 2);
+                        need = c == 2 ? 2 * n : 0;           /* scratch of a single big leaf */
+                    } else {
+                        c = half <= 8 ? 3 : (half <= 16 ? 4 : (half <= 32 ? 5 : (half <= 64 ? 6 : 7)));
+                        need = 2 * half;                    /* its children's vectors */
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(c == k);
+                    if (c == k)
+                        N.ord[start_c[k] + run_c[k] + __popcll(m & below)] = (unsigned short)j;
+                    run_c[k] += __popcll(m);
+                }
+                int room;
+                const int at = carry + wave_excl_scan_i32(need, lane, room);
+                if (j < lev_e)
+                    N.tot[j] = (unsigned short)at;
+                carry += room;
+            }
+            if (carry > VQF_BUF && lane == 0)
+                misc[1] = 1;
+        }
+        __syncthreads();
+        if (misc[1])
+            break;
+        /* ---- all waves: the level's passes, dealt round-robin */
+        {
+            int items_before = 0, t_next = wave;
+#pragma unroll 1
+            for (int c = 0; c < 8; ++c) {
+                const int c_b = N.cls[c], c_n = N.cls[c + 1] - c_b;
+                const int lg = (c == 0) ? 2 : (c == 1) ? 1 : (c == 2) ? 0 : (c == 3) ? 3 : (c == 4) ? 2 : (c == 5) ? 1 : 0;
+                const int G = 1 << lg;                     /* nodes per pass */
+                const int items = (c_n + G - 1) >> lg;
+                for (; t_next < items_before + items; t_next += VQ_WAVES) {
+                    const int p0 = c_b + ((t_next - items_before) << lg);
+                    const int p_n = min(G, c_b + c_n - p0);
+                    if (c <= 1) {
+                        /* leaves, four or two per pass */
+                        const int lw = (c == 0) ? 4 : 5, W = 1 << lw;
+                        const int g = lane >> lw, l = lane & (W - 1);
+                        const bool valid = g < p_n;
+                        const int node = valid ? N.ord[p0 + g] : 0;
+                        const int n = valid ? N.nn[node] : 0;
+                        int bits = valid ? N.bb[node] : 0;
+                        bits = bits > 32 ? 32 : bits;
+                        const int K = valid ? V.k_of[n * 33 + bits] : 0;
+                        const int width = valid ? V.w_of[n * 33 + bits] : 0;
+                        const double x = (valid && l < n) ? cur[N.off[node] + l] : 0.0;
+                        bool ok = false;
+                        unsigned long long term;
+                        if (c == 0)
+                            term = vq_leaf_group<16>(V, x, n, K < 0 ? 0 : K, l, ok);
+                        else
+                            term = vq_leaf_group<32>(V, x, n, K < 0 ? 0 : K, l, ok);
+                        if (valid && l == 0) {
+                            if (K < 0) {                   /* a 1-dimensional leaf: the reference never returns */
+                                N.kind[node] = 3;
+                                N.wid[node] = 0;
+                                N.val[node] = 0ull;
+                            } else {
+                                N.val[node] = ok ? term : 0ull;
+                                N.wid[node] = (unsigned char)width;
+                            }
+                        }
+                        if (valid && (K < 0 || !ok))
+                            undefined = true;
+                    } else if (c == 2) {
+                        const int node = N.ord[p0];
+                        const int n = N.nn[node];
+                        int bits = N.bb[node];
+                        bits = bits > 32 ? 32 : bits;
+                        const int K = ldc(&V.k_of[n * 33 + bits]);
+                        const int width = ldc(&V.w_of[n * 33 + bits]);
+                        bool ok = true;
+                        double *t1 = nxt + N.tot[node];
+                        const unsigned long long idx = vq_leaf_idx(V, cur + N.off[node], n, K, t1, t1 + n, lane, ok);
+                        if (!ok)
+                            undefined = true;
+                        if (lane == 0) {
+                            N.val[node] = ok ? idx : 0ull;
+                            N.wid[node] = (unsigned char)width;
+                        }
+                    } else if (c < 7) {
+                        /* splits packed: one node per aligned block of P lanes */
+                        const int lp = c + 0;              /* classes 3..6 = blocks of 8, 16, 32, 64 lanes */
+                        const int P = 1 << lp;
+                        const int g = lane >> lp, i = lane & (P - 1);
+                        const bool valid = g < p_n;
+                        const int node = valid ? N.ord[p0 + g] : 0;
+                        const int n = valid ? N.nn[node] : 0;
+                        const int cut = n / 2, half = n - cut;
+                        const double *src = cur + (valid ? N.off[node] : 0);
+                        const bool mine = i < half;
+                        const double left = (mine && i < cut) ? src[i] : 0.0;
+                        const double right = mine ? src[cut + i] : 0.0;
+                        double mid = mine ? (left + right) / 2.0 : 0.0;
+                        double sd = mine ? (left - right) / 2.0 : 0.0;
+                        double mm = fma(mid, mid, 0.0), ss = fma(sd, sd, 0.0);
+                        for (int off = P >> 1; off > 0; off >>= 1) {
+                            mm = mm + __shfl_xor(mm, off, 64);
+                            ss = ss + __shfl_xor(ss, off, 64);
+                        }
+                        const double m_l2 = sqrt(mm), s_l2 = sqrt(ss);
+                        if (m_l2 != 0.0)
+                            mid = mid / m_l2;
+                        if (s_l2 != 0.0)
+                            sd = sd / s_l2;
+                        if (mine) {
+                            double *mv = nxt + N.tot[node];
+                            mv[i] = mid;
+                            mv[half + i] = sd;
+                        }
+                        if (valid && i == 0)
+                            N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
+                    } else {
+                        /* a split of more than 128 components: lanes strided over the half */
+                        const int node = N.ord[p0];
+                        const int n = N.nn[node];
+                        const double *src = cur + N.off[node];
+                        const int cut = n / 2, half = n - cut;
+                        double *mv = nxt + N.tot[node], *sv = mv + half;
+                        double mm = 0.0, ss = 0.0;
+                        for (int i = lane; i < half; i += 64) {
+                            const double left = (i < cut) ? src[i] : 0.0;
+                            const double right = src[cut + i];
+                            const double mid = (left + right) / 2.0;
+                            const double sd = (left - right) / 2.0;
+                            mv[i] = mid;
+                            sv[i] = sd;
+                            mm = fma(mid, mid, mm);
+                            ss = fma(sd, sd, ss);
+                        }
+                        const double m_l2 = sqrt(wave_sum_f64(mm));
+                        const double s_l2 = sqrt(wave_sum_f64(ss));
+                        for (int i = lane; i < half; i += 64) {
+                            if (m_l2 != 0.0)
+                                mv[i] = mv[i] / m_l2;
+                            if (s_l2 != 0.0)
+                                sv[i] = sv[i] / s_l2;
+                        }
+                        if (lane == 0)
+                            N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
+                    }
+                }
+                items_before += items;
+            }
+        }
+        __syncthreads();
+        /* ---- the level's splits, one per lane: angle, bit split, children */
+        const int s_b = N.cls[3], s_n = N.cls[8] - s_b;
+        for (int k0 = 64 * wave; k0 < s_n; k0 += 64 * VQ_WAVES) {
+            const bool has = k0 + lane < s_n;
+            const int snode = has ? N.ord[s_b + k0 + lane] : 0;
+            const int sn = has ? N.nn[snode] : 2;
+            const int half = sn - sn / 2;
+            const int bits = has ? N.bb[snode] : 0;
+            const double q = has ? __longlong_as_double((long long)N.val[snode]) : -1.0;
+            const double theta = (q < 0.0) ? 0.0 : vq_atan(q);
+            const int a_theta = (int)floor((double)bits / (double)half + V.half_log2[half]);
+            int a_rest = bits - a_theta;
+            if (a_rest < 0)
+                a_rest = 0;
+            const double tn = theta / half_pi;
+            double theta_q = 0.0;
+            unsigned long long code = 0ull;
+            int w_theta = 0;
+            if (a_theta > 62) {
+                if (has)
+                    undefined = true;
+            } else if (a_theta > 0) {
+                if (tn >= 1.0) {
+                    code = (1ull << (a_theta - 1)) - 1ull;
+                } else {
+                    const double factor = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+                    code = (unsigned long long)floor((factor * tn + 1.0) * 0.5);
+                }
+                w_theta = a_theta;
+                const unsigned long long mag = code & ((1ull << (a_theta - 1)) - 1ull);
+                const double den = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+                double dq = (double)(2ull * mag) / den;
+                if (code >> (a_theta - 1))
+                    dq = -dq;
+                theta_q = dq * half_pi;
+            }
+            int a_mid = 0;
+            if (theta_q != 0.0) {
+                double lt;
+                if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta_q > 0.0)
+                    lt = V.log2_tan[((1 << (a_theta - 1)) - 1) + (int)code];
+                else
+                    lt = vq_log2_tan(theta_q);
+                const double v = ((double)a_rest - (double)(half - 1) * lt) / 2.0;
+                const double f = floor(v);
+                a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
+            }
+            const int a_side = a_rest - a_mid;
+            const int c_mid = (has && a_mid > 0) ? 1 : 0, c_side = (has && a_side > 0) ? 1 : 0;
+            int born;
+            const int rel = wave_excl_scan_i32(c_mid + c_side, lane, born);
+            int base = 0;
+            if (lane == 0 && born)
+                base = atomicAdd(&misc[0], born);
+            base = __shfl(base, 0, 64);
+            if (base + born > VQF_NCAP) {
+                if (lane == 0)
+                    misc[1] = 1;
+                continue;
+            }
+            if (has) {
+                const int first = base + rel;
+                N.val[snode] = code;
+                N.wid[snode] = (unsigned char)w_theta;
+                N.kid[snode] = (unsigned short)first;
+                N.has[snode] = (unsigned char)(c_mid | (c_side << 1));
+                const int at = N.tot[snode];
+                const int bd = N.band[snode];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int a = c ? a_side : a_mid;
+                    if (a <= 0)
+                        continue;
+                    const int id = c ? first + c_mid : first;
+                    const bool splits = a > PACX_VQ_SPLIT_BITS && depth + 1 < VQ_DEPTH;
+                    if (a > PACX_VQ_SPLIT_BITS && !splits)
+                        undefined = true;                  /* deeper than any real tree */
+                    N.nn[id] = (unsigned short)half;
+                    N.bb[id] = (unsigned short)(a > 65535 ? 65535 : a);
+                    N.off[id] = (unsigned short)(at + (c ? half : 0));
+                    N.kind[id] = splits ? 0 : 1;
+                    N.wid[id] = 0;
+                    N.band[id] = (unsigned char)bd;
+                    N.has[id] = 0;
+                    N.kid[id] = 0;
+                    N.val[id] = 0ull;
+                }
+            }
+        }
+        __syncthreads();
+        if (misc[1])
+            break;
+        const int n_nodes = misc[0];
+        depth += 1;
+        if (tid == 0)
+            N.lvl[depth] = (unsigned short)lev_e;
+        if (n_nodes == lev_e) {                              /* no children: the walk is over */
+            depth -= 1;
+            break;
+        }
+        lev_b = lev_e;
+        lev_e = n_nodes;
+        if (depth > VQ_DEPTH) {                            /* cannot happen: splits stop at VQ_DEPTH - 1 */
+            if (tid == 0)
+                misc[1] = 1;
+            __syncthreads();
+            break;
+        }
+    }
+    if (misc[1]) {
+        /* does not fit the store: k_vq codes this unit */
+        if (tid == 0) {
+            if (!is_short)
+                A.n_bytes[cf] = -1;
+            else
+                A.unit_bits[unit * 2] = -1;
+        }
+        return;
+    }
+    const int n_nodes = misc[0];
+    if (tid == 0)
+        N.lvl[depth + 1] = (unsigned short)n_nodes;
+    __syncthreads();
+    /* ---- subtree widths and field counts bottom-up (counts ride in nn[], field numbers in off[]) */
+    for (int d = depth; d >= 0; --d) {
+        const int b = N.lvl[d], e = N.lvl[d + 1];
+        for (int j = b + tid; j < e; j += 64 * VQ_WAVES) {
+            const int k0 = N.kid[j], hs = N.has[j];
+            int t = N.wid[j], f = (N.kind[j] == 3) ? 0 : 1;
+            if (hs & 1) { t += N.tot[k0]; f += N.nn[k0]; }
+            if (hs & 2) { const int k1 = k0 + (hs & 1); t += N.tot[k1]; f += N.nn[k1]; }
+            N.tot[j] = (unsigned short)t;
+            N.nn[j] = (unsigned short)f;
+        }
+        __syncthreads();
+    }
+    if (tid < nb && root_s[tid] != 0xFFFF) {
+        N.pos[root_s[tid]] = (unsigned short)start_s[tid];
+        N.off[root_s[tid]] = 0;
+    }
+    __syncthreads();
+    for (int d = 0; d <= depth; ++d) {
+        const int b = N.lvl[d], e = N.lvl[d + 1];
+        for (int j = b + tid; j < e; j += 64 * VQ_WAVES) {
+            const int k0 = N.kid[j], hs = N.has[j];
+            int p = N.pos[j] + N.wid[j], r = N.off[j] + ((N.kind[j] == 3) ? 0 : 1);
+            if (hs & 1) {
+                N.pos[k0] = (unsigned short)p;
+                N.off[k0] = (unsigned short)r;
+                p += N.tot[k0];
+                r += N.nn[k0];
+            }
+            if (hs & 2) {
+                const int k1 = k0 + (hs & 1);
+                N.pos[k1] = (unsigned short)p;
+                N.off[k1] = (unsigned short)r;
+            }
+        }
+        __syncthreads();
+    }
+    /* ---- every field by its own lane */
+    for (int j = tid; j < n_nodes; j += 64 * VQ_WAVES) {
+        const int w = N.wid[j];
+        unsigned long long v = N.val[j];
+        if (w > 0 && w < 64)
+            v &= (1ull << w) - 1ull;
+        if (w > 0)
+            vq_put_field(words, N.pos[j], v, w);
+        if (A.log && N.kind[j] != 3 && N.off[j] < A.log_cap) {
+            const long long slot = (cf * PACX_SUB + sb) * PACX_MAX_BANDS + N.band[j];
+            pacx_vq_entry e;
+            e.value = v;
+            e.width = w;
+            e.band = N.band[j];
+            A.log[slot * A.log_cap + N.off[j]] = e;
+        }
+    }
+    /* ---- the gains of all bands side by side (mu-law, QuantizeUniform; the index soaks up the slack) */
+    if (tid < 64) {
+        const int b = lane;
+        const int ba = (b < nb) ? ba_s[b] : 0;
+        const long long slot = (cf * PACX_SUB + sb) * PACX_MAX_BANDS + b;
+        if (b < nb && !ba && A.log_count)
+            A.log_count[slot] = 0;
+        const int cnt = (b < nb && b < first_omit) ? count[b] : 1;
+        const double gain = (b < nb) ? gain_s[b] : 0.0;
+        const double g = vq_log(1.0 + 255.0 * fabs(gain / (double)cnt)) / V.log_mu1;
+        if (ba) {
+            const int rt = root_s[b];
+            const int used = (rt != 0xFFFF) ? N.tot[rt] : 0;
+            const int fields = (rt != 0xFFFF) ? N.nn[rt] : 0;
+            int bits_gain = bg_s[b] + bs_s[b] - used;
+            if (bits_gain < 0)
+                bits_gain = 0;
+            int width = bits_gain;
+            unsigned long long hi = 0, lo = 0;
+            if (bits_gain > 128) {                         /* beyond what the entry format carries */
+                undefined = true;
+                width = 0;
+            } else if (bits_gain > 0) {
+                vq_quantize_code(g, bits_gain, hi, lo);
+            }
+            const int at = start_s[b] + used;
+            if (width > 64) {
+                vq_put_field(words, at, hi, width - 64);
+                vq_put_field(words, at + width - 64, lo, 64);
+            } else if (width > 0) {
+                vq_put_field(words, at, lo, width);
+            }
+            if (at + width != start_s[b + 1])
+                undefined = true;                          /* a band must fill its slot exactly */
+            if (A.log && fields < A.log_cap) {
+                pacx_vq_entry e;
+                e.value = lo;
+                e.width = width;
+                e.band = b;
+                A.log[slot * A.log_cap + fields] = e;
+            }
+            if (A.log_count)
+                A.log_count[slot] = fields + 1;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(undefined) && lane == 0 && A.status)
+        atomicOr(&A.status[cf], PACX_ST_VQ_UNDEFINED);
+    __syncthreads();
+
+    /* hand the string over */
+    const int written = start_s[nb];                       /* includes `lead` */
+    int size_rule = T.n_scale_bits;                        /* getNumBytesNeeded */
+    for (int b = 0; b < nb; ++b)
+        size_rule += T.n_mant_size_bits + T.n_scale_bits;
+    size_rule += written - (lead + T.n_scale_bits + T.n_mant_size_bits * nb);
+    if (!is_short) {
+        const int nbytes = (size_rule + 4 + 7) >> 3;
+        unsigned *dst = (unsigned *)(A.payload + cf * (long long)A.payload_stride);
+        for (int i = tid; i < (nbytes + 3) / 4; i += 64 * VQ_WAVES)
+            dst[i] = __builtin_bswap32(words[i]);
+        if (tid == 0)
+            A.n_bytes[cf] = nbytes;
+    } else {
+        unsigned *dst = A.unit_words + unit * VQ_WORDS;
+        for (int i = tid; i < (written + 31) / 32; i += 64 * VQ_WAVES)
+            dst[i] = words[i];
+        if (tid == 0) {
+            A.unit_bits[unit * 2] = written;
+            A.unit_bits[unit * 2 + 1] = size_rule;
+        }
+    }
+}
+
 /* short frames: flags + the 8 sub-block strings, back to back */
 __global__ __launch_bounds__(64) void k_vq_join(PacxTables T, const uint8_t *__restrict__ flags, int n_ch,
                                                long long n_cf, const uint32_t *__restrict__ status,
@@ -1521,6 +2190,11 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
     static_assert(fixed % 8 == 0, "the shapes behind the fixed part are doubles");
     const size_t smem = fixed + PACX_M_LONG * 8 + (size_t)V.scr_off[VQ_WAVES] * 8 + (size_t)VQ_WAVES * VQ_NODE_BYTES;
     const long long units = A.mixed ? n_cf * PACX_SUB : n_cf;
+    /* the frame-level walk first; k_vq then takes the units it left (PACX_VQ_FRAME=0: k_vq alone) */
+    const char *fe = getenv("PACX_VQ_FRAME");
+    A.redo = (fe && atoi(fe) == 0) ? 0 : 1;
+    if (A.redo)
+        hipLaunchKernelGGL(k_vq_frame, dim3((unsigned)units), dim3(64 * VQ_WAVES), (size_t)VQF_SMEM, st, T, V, A);
     hipLaunchKernelGGL(k_vq, dim3((unsigned)units), dim3(64 * VQ_WAVES), smem, st, T, V, A);
     if (A.mixed)
         hipLaunchKernelGGL(k_vq_join, dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch, n_cf, status,
