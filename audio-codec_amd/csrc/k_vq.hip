@@ -1448,7 +1448,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
 #define VQF_NCAP 448                   /* nodes per (sub-)block */
 #define VQF_NLV 256                    /* nodes per level */
 #define VQF_BUF (PACX_M_LONG + 160)    /* doubles per level buffer */
-#define VQF_FIXED 3056                 /* words, gains, allocations, starts, ticket, gain bits, roots, counters */
+#define VQF_FIXED 3072                 /* words, gains, allocations, starts, ticket, gain bits, roots, counters */
 #define VQF_SMEM (VQF_FIXED + 2 * VQF_BUF * 8 + VQF_NCAP * 8 + 6 * VQF_NCAP * 2 + 4 * VQF_NCAP + VQF_NLV * 2 + 64 + 64)
 
 struct VqfStore {
@@ -1505,19 +1505,27 @@ __device__ __forceinline__ void vq_quantize_code(double x, int n_bits, unsigned 
 
 __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqView V, VqArgs A)
 {
+#ifdef PACX_VQ_DEBUG
+    long long vqf_last = 0;
+#define VQF_T(k) do { long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                      if (threadIdx.x == 0 && vqf_last) atomicAdd((unsigned long long *)&g_vq_dbg[k], (unsigned long long)(t_ - vqf_last)); \
+                      vqf_last = t_; } while (0)
+#else
+#define VQF_T(k) do { } while (0)
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *words = (unsigned *)smem;                               /* VQ_WORDS        */
     double *gain_s = (double *)(smem + VQ_WORDS * 4);                 /* 32              */
     int *ba_s = (int *)(gain_s + PACX_MAX_BANDS);                     /* 32              */
     int *start_s = ba_s + PACX_MAX_BANDS;                             /* 33              */
-    int *misc = start_s + PACX_MAX_BANDS + 1;                         /* 3: node count, overflow, flags */
-    int *bg_s = misc + 3;                                             /* 32 gain bits before the shape's slack */
+    int *misc = start_s + PACX_MAX_BANDS + 1;                         /* node count, overflow, spare, two pass tickets, 2 spare */
+    int *bg_s = misc + 7;                                             /* 32 gain bits before the shape's slack */
     unsigned short *root_s = (unsigned short *)(bg_s + PACX_MAX_BANDS);   /* 32 root node of a band, 0xFFFF none */
     int *bs_s = (int *)(root_s + PACX_MAX_BANDS);                     /* 32 shape bits  (16 spare ints follow) */
     double *buf0 = (double *)(smem + VQF_FIXED);                      /* two level buffers of VQF_BUF doubles */
     VqfStore N;
     N.bind(smem + VQF_FIXED + 2 * VQF_BUF * 8);
-    static_assert(VQ_WORDS * 4 + PACX_MAX_BANDS * 8 + PACX_MAX_BANDS * 4 + (PACX_MAX_BANDS + 1) * 4 + 3 * 4 +
+    static_assert(VQ_WORDS * 4 + PACX_MAX_BANDS * 8 + PACX_MAX_BANDS * 4 + (PACX_MAX_BANDS + 1) * 4 + 7 * 4 +
                   PACX_MAX_BANDS * 4 + PACX_MAX_BANDS * 2 + PACX_MAX_BANDS * 4 <= VQF_FIXED && VQF_FIXED % 16 == 0,
                   "fixed part of k_vq_frame's LDS");
 
@@ -1558,8 +1566,19 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
         vq_row_off_s[i] = V.row_off[i];
     if (tid < 3)
         misc[tid] = 0;
+    VQF_T(15);
     /* phase A: gains; the unit shapes x / gain are level 0 of the walk (bufs[0], at the band's lines) */
     double *xs = buf0;
+    {
+        /* the unit's lines, scaled, in one coalesced sweep: the bands' norms then read LDS, not memory */
+        const int n_lines = is_short ? PACX_M_SHORT : PACX_M_LONG;
+        for (int i = 2 * tid; i < n_lines; i += 2 * 64 * VQ_WAVES) {
+            const double2 v = *(const double2 *)(lin + i);
+            xs[i] = v.x * up;
+            xs[i + 1] = v.y * up;
+        }
+    }
+    __syncthreads();
     for (int b = wave; b < nb; b += VQ_WAVES) {
         double g;
         if (b >= first_omit) {
@@ -1569,8 +1588,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
             const int lo = ldc(&lower[b]), cnt = ldc(&count[b]);
             double acc = 0.0;
             for (int i = lane; i < cnt; i += 64) {
-                const double x = lin[lo + i] * up;
-                xs[lo + i] = x;
+                const double x = xs[lo + i];
                 acc = fma(x, x, acc);
             }
             g = sqrt(wave_sum_f64(acc));
@@ -1650,6 +1668,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
     }
     __syncthreads();
 
+    VQF_T(0);
     bool undefined = false;
     int lev_b = 0, lev_e = misc[0], depth = 0;
     for (;;) {
@@ -1658,8 +1677,12 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
         /* ---- wave 0: the level's nodes grouped by class, room for what they write to the next buffer */
         if (wave == 0) {
             int cnt_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (lev_e - lev_b > VQF_NLV && lane == 0)
-                misc[1] = 1;
+            if (lane == 0) {
+                misc[3] = 0;
+                misc[4] = 0;
+                if (lev_e - lev_b > VQF_NLV)
+                    misc[1] = 1;
+            }
             for (int base = lev_b; base < lev_e && lev_e - lev_b <= VQF_NLV; base += 64) {
                 const int j = base + lane;
                 int c = 8;
@@ -1718,132 +1741,138 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
                 misc[1] = 1;
         }
         __syncthreads();
+        VQF_T(1);
         if (misc[1])
             break;
-        /* ---- all waves: the level's passes, dealt round-robin */
+        /* ---- one pass: `p_n` nodes of class c, ord[p0 ..) */
+        auto do_item = [&](int c, int p0, int p_n) {
+            if (c <= 1) {
+                /* leaves, four or two per pass */
+                const int lw = (c == 0) ? 4 : 5, W = 1 << lw;
+                const int g = lane >> lw, l = lane & (W - 1);
+                const bool valid = g < p_n;
+                const int node = valid ? N.ord[p0 + g] : 0;
+                const int n = valid ? N.nn[node] : 0;
+                int bits = valid ? N.bb[node] : 0;
+                bits = bits > 32 ? 32 : bits;
+                const int K = valid ? V.k_of[n * 33 + bits] : 0;
+                const int width = valid ? V.w_of[n * 33 + bits] : 0;
+                const double x = (valid && l < n) ? cur[N.off[node] + l] : 0.0;
+                bool ok = false;
+                unsigned long long term;
+                if (c == 0)
+                    term = vq_leaf_group<16>(V, x, n, K < 0 ? 0 : K, l, ok);
+                else
+                    term = vq_leaf_group<32>(V, x, n, K < 0 ? 0 : K, l, ok);
+                if (valid && l == 0) {
+                    if (K < 0) {                   /* a 1-dimensional leaf: the reference never returns */
+                        N.kind[node] = 3;
+                        N.wid[node] = 0;
+                        N.val[node] = 0ull;
+                    } else {
+                        N.val[node] = ok ? term : 0ull;
+                        N.wid[node] = (unsigned char)width;
+                    }
+                }
+                if (valid && (K < 0 || !ok))
+                    undefined = true;
+            } else if (c == 2) {
+                const int node = N.ord[p0];
+                const int n = N.nn[node];
+                int bits = N.bb[node];
+                bits = bits > 32 ? 32 : bits;
+                const int K = ldc(&V.k_of[n * 33 + bits]);
+                const int width = ldc(&V.w_of[n * 33 + bits]);
+                bool ok = true;
+                double *t1 = nxt + N.tot[node];
+                const unsigned long long idx = vq_leaf_idx(V, cur + N.off[node], n, K, t1, t1 + n, lane, ok);
+                if (!ok)
+                    undefined = true;
+                if (lane == 0) {
+                    N.val[node] = ok ? idx : 0ull;
+                    N.wid[node] = (unsigned char)width;
+                }
+            } else if (c < 7) {
+                /* splits packed: one node per aligned block of P lanes */
+                const int lp = c + 0;              /* classes 3..6 = blocks of 8, 16, 32, 64 lanes */
+                const int P = 1 << lp;
+                const int g = lane >> lp, i = lane & (P - 1);
+                const bool valid = g < p_n;
+                const int node = valid ? N.ord[p0 + g] : 0;
+                const int n = valid ? N.nn[node] : 0;
+                const int cut = n / 2, half = n - cut;
+                const double *src = cur + (valid ? N.off[node] : 0);
+                const bool mine = i < half;
+                const double left = (mine && i < cut) ? src[i] : 0.0;
+                const double right = mine ? src[cut + i] : 0.0;
+                double mid = mine ? (left + right) / 2.0 : 0.0;
+                double sd = mine ? (left - right) / 2.0 : 0.0;
+                double mm = fma(mid, mid, 0.0), ss = fma(sd, sd, 0.0);
+                for (int off = P >> 1; off > 0; off >>= 1) {
+                    mm = mm + __shfl_xor(mm, off, 64);
+                    ss = ss + __shfl_xor(ss, off, 64);
+                }
+                const double m_l2 = sqrt(mm), s_l2 = sqrt(ss);
+                if (m_l2 != 0.0)
+                    mid = mid / m_l2;
+                if (s_l2 != 0.0)
+                    sd = sd / s_l2;
+                if (mine) {
+                    double *mv = nxt + N.tot[node];
+                    mv[i] = mid;
+                    mv[half + i] = sd;
+                }
+                if (valid && i == 0)
+                    N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
+            } else {
+                /* a split of more than 128 components: lanes strided over the half */
+                const int node = N.ord[p0];
+                const int n = N.nn[node];
+                const double *src = cur + N.off[node];
+                const int cut = n / 2, half = n - cut;
+                double *mv = nxt + N.tot[node], *sv = mv + half;
+                double mm = 0.0, ss = 0.0;
+                for (int i = lane; i < half; i += 64) {
+                    const double left = (i < cut) ? src[i] : 0.0;
+                    const double right = src[cut + i];
+                    const double mid = (left + right) / 2.0;
+                    const double sd = (left - right) / 2.0;
+                    mv[i] = mid;
+                    sv[i] = sd;
+                    mm = fma(mid, mid, mm);
+                    ss = fma(sd, sd, ss);
+                }
+                const double m_l2 = sqrt(wave_sum_f64(mm));
+                const double s_l2 = sqrt(wave_sum_f64(ss));
+                for (int i = lane; i < half; i += 64) {
+                    if (m_l2 != 0.0)
+                        mv[i] = mv[i] / m_l2;
+                    if (s_l2 != 0.0)
+                        sv[i] = sv[i] / s_l2;
+                }
+                if (lane == 0)
+                    N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
+            }
+        };
+        /* passes are dealt round-robin, the expensive classes first (a wave's last pass is a cheap one) */
         {
+            const int order[8] = {7, 2, 6, 5, 1, 4, 0, 3};
             int items_before = 0, t_next = wave;
 #pragma unroll 1
-            for (int c = 0; c < 8; ++c) {
+            for (int k = 0; k < 8; ++k) {
+                const int c = order[k];
                 const int c_b = N.cls[c], c_n = N.cls[c + 1] - c_b;
                 const int lg = (c == 0) ? 2 : (c == 1) ? 1 : (c == 2) ? 0 : (c == 3) ? 3 : (c == 4) ? 2 : (c == 5) ? 1 : 0;
-                const int G = 1 << lg;                     /* nodes per pass */
-                const int items = (c_n + G - 1) >> lg;
+                const int items = (c_n + (1 << lg) - 1) >> lg;
                 for (; t_next < items_before + items; t_next += VQ_WAVES) {
                     const int p0 = c_b + ((t_next - items_before) << lg);
-                    const int p_n = min(G, c_b + c_n - p0);
-                    if (c <= 1) {
-                        /* leaves, four or two per pass */
-                        const int lw = (c == 0) ? 4 : 5, W = 1 << lw;
-                        const int g = lane >> lw, l = lane & (W - 1);
-                        const bool valid = g < p_n;
-                        const int node = valid ? N.ord[p0 + g] : 0;
-                        const int n = valid ? N.nn[node] : 0;
-                        int bits = valid ? N.bb[node] : 0;
-                        bits = bits > 32 ? 32 : bits;
-                        const int K = valid ? V.k_of[n * 33 + bits] : 0;
-                        const int width = valid ? V.w_of[n * 33 + bits] : 0;
-                        const double x = (valid && l < n) ? cur[N.off[node] + l] : 0.0;
-                        bool ok = false;
-                        unsigned long long term;
-                        if (c == 0)
-                            term = vq_leaf_group<16>(V, x, n, K < 0 ? 0 : K, l, ok);
-                        else
-                            term = vq_leaf_group<32>(V, x, n, K < 0 ? 0 : K, l, ok);
-                        if (valid && l == 0) {
-                            if (K < 0) {                   /* a 1-dimensional leaf: the reference never returns */
-                                N.kind[node] = 3;
-                                N.wid[node] = 0;
-                                N.val[node] = 0ull;
-                            } else {
-                                N.val[node] = ok ? term : 0ull;
-                                N.wid[node] = (unsigned char)width;
-                            }
-                        }
-                        if (valid && (K < 0 || !ok))
-                            undefined = true;
-                    } else if (c == 2) {
-                        const int node = N.ord[p0];
-                        const int n = N.nn[node];
-                        int bits = N.bb[node];
-                        bits = bits > 32 ? 32 : bits;
-                        const int K = ldc(&V.k_of[n * 33 + bits]);
-                        const int width = ldc(&V.w_of[n * 33 + bits]);
-                        bool ok = true;
-                        double *t1 = nxt + N.tot[node];
-                        const unsigned long long idx = vq_leaf_idx(V, cur + N.off[node], n, K, t1, t1 + n, lane, ok);
-                        if (!ok)
-                            undefined = true;
-                        if (lane == 0) {
-                            N.val[node] = ok ? idx : 0ull;
-                            N.wid[node] = (unsigned char)width;
-                        }
-                    } else if (c < 7) {
-                        /* splits packed: one node per aligned block of P lanes */
-                        const int lp = c + 0;              /* classes 3..6 = blocks of 8, 16, 32, 64 lanes */
-                        const int P = 1 << lp;
-                        const int g = lane >> lp, i = lane & (P - 1);
-                        const bool valid = g < p_n;
-                        const int node = valid ? N.ord[p0 + g] : 0;
-                        const int n = valid ? N.nn[node] : 0;
-                        const int cut = n / 2, half = n - cut;
-                        const double *src = cur + (valid ? N.off[node] : 0);
-                        const bool mine = i < half;
-                        const double left = (mine && i < cut) ? src[i] : 0.0;
-                        const double right = mine ? src[cut + i] : 0.0;
-                        double mid = mine ? (left + right) / 2.0 : 0.0;
-                        double sd = mine ? (left - right) / 2.0 : 0.0;
-                        double mm = fma(mid, mid, 0.0), ss = fma(sd, sd, 0.0);
-                        for (int off = P >> 1; off > 0; off >>= 1) {
-                            mm = mm + __shfl_xor(mm, off, 64);
-                            ss = ss + __shfl_xor(ss, off, 64);
-                        }
-                        const double m_l2 = sqrt(mm), s_l2 = sqrt(ss);
-                        if (m_l2 != 0.0)
-                            mid = mid / m_l2;
-                        if (s_l2 != 0.0)
-                            sd = sd / s_l2;
-                        if (mine) {
-                            double *mv = nxt + N.tot[node];
-                            mv[i] = mid;
-                            mv[half + i] = sd;
-                        }
-                        if (valid && i == 0)
-                            N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
-                    } else {
-                        /* a split of more than 128 components: lanes strided over the half */
-                        const int node = N.ord[p0];
-                        const int n = N.nn[node];
-                        const double *src = cur + N.off[node];
-                        const int cut = n / 2, half = n - cut;
-                        double *mv = nxt + N.tot[node], *sv = mv + half;
-                        double mm = 0.0, ss = 0.0;
-                        for (int i = lane; i < half; i += 64) {
-                            const double left = (i < cut) ? src[i] : 0.0;
-                            const double right = src[cut + i];
-                            const double mid = (left + right) / 2.0;
-                            const double sd = (left - right) / 2.0;
-                            mv[i] = mid;
-                            sv[i] = sd;
-                            mm = fma(mid, mid, mm);
-                            ss = fma(sd, sd, ss);
-                        }
-                        const double m_l2 = sqrt(wave_sum_f64(mm));
-                        const double s_l2 = sqrt(wave_sum_f64(ss));
-                        for (int i = lane; i < half; i += 64) {
-                            if (m_l2 != 0.0)
-                                mv[i] = mv[i] / m_l2;
-                            if (s_l2 != 0.0)
-                                sv[i] = sv[i] / s_l2;
-                        }
-                        if (lane == 0)
-                            N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
-                    }
+                    do_item(c, p0, min(1 << lg, c_b + c_n - p0));
                 }
                 items_before += items;
             }
         }
         __syncthreads();
+        VQF_T(2);
         /* ---- the level's splits, one per lane: angle, bit split, children */
         const int s_b = N.cls[3], s_n = N.cls[8] - s_b;
         for (int k0 = 64 * wave; k0 < s_n; k0 += 64 * VQ_WAVES) {
@@ -1934,6 +1963,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
             }
         }
         __syncthreads();
+        VQF_T(3);
         if (misc[1])
             break;
         const int n_nodes = misc[0];
@@ -2004,6 +2034,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
         }
         __syncthreads();
     }
+    VQF_T(4);
     /* ---- every field by its own lane */
     for (int j = tid; j < n_nodes; j += 64 * VQ_WAVES) {
         const int w = N.wid[j];
@@ -2070,6 +2101,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
         atomicOr(&A.status[cf], PACX_ST_VQ_UNDEFINED);
     __syncthreads();
 
+    VQF_T(5);
     /* hand the string over */
     const int written = start_s[nb];                       /* includes `lead` */
     int size_rule = T.n_scale_bits;                        /* getNumBytesNeeded */
@@ -2092,6 +2124,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
             A.unit_bits[unit * 2 + 1] = size_rule;
         }
     }
+    VQF_T(6);
 }
 
 /* short frames: flags + the 8 sub-block strings, back to back */

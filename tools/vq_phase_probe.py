@@ -31,3 +31,12 @@ inames = ["split arithmetic (fold, norms, angle, bit split)", "sibling bottom sp
 print("inside the band walk (share of phase B's stamped time):")
 for n, v in zip(inames, inner):
     print("  %-58s %.1f %%" % (n, 100.0 * v / max(inner.sum(), 1.0)))
+
+if os.environ.get("PACX_VQ_FRAME", "1") != "0":
+    fn = ["phase A gains + header + roots", "level: classify (wave 0) + barrier", "level: packed passes + barrier",
+          "level: scalar arithmetic + children + barrier", "widths / positions (barrier per level)", "fields + gains",
+          "hand-over"]
+    tf = np.array(out[:7], dtype=np.float64)
+    print("k_vq_frame, thread 0 of every workgroup, share of its time:")
+    for n, v in zip(fn, tf):
+        print("  %-48s %.1f %%" % (n, 100.0 * v / tf.sum()))
