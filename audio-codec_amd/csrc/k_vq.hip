@@ -1445,9 +1445,14 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
  *   ORed in by its own lane, and the gains of all bands are quantised side by side.
  * Arithmetic per node is that of vq_shape / vq_leaf / vq_leaf_group.  A unit whose trees do not fit
  * the store (bit rates far above the shipped ones) is left to k_vq: n_bytes / unit_bits = -1. */
-#define VQF_NCAP 448                   /* nodes per (sub-)block */
+#ifndef VQF_NCAP
+#define VQF_NCAP 256                   /* nodes per (sub-)block: 31 KB of LDS with the rest, five workgroups per CU
+                                          (448 nodes and 1184-double buffers: four, 571 against 487 us) */
+#endif
 #define VQF_NLV 256                    /* nodes per level */
-#define VQF_BUF (PACX_M_LONG + 160)    /* doubles per level buffer */
+#ifndef VQF_BUF
+#define VQF_BUF (PACX_M_LONG + 64)     /* doubles per level buffer */
+#endif
 #define VQF_FIXED 3072                 /* words, gains, allocations, starts, ticket, gain bits, roots, counters */
 #define VQF_SMEM (VQF_FIXED + 2 * VQF_BUF * 8 + VQF_NCAP * 8 + 6 * VQF_NCAP * 2 + 4 * VQF_NCAP + VQF_NLV * 2 + 64 + 64)
 
@@ -1503,7 +1508,7 @@ __device__ __forceinline__ void vq_quantize_code(double x, int n_bits, unsigned 
     }
 }
 
-__global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqView V, VqArgs A)
+__global__ __launch_bounds__(64 * VQ_WAVES, 5) void k_vq_frame(PacxTables T, VqView V, VqArgs A)
 {
 #ifdef PACX_VQ_DEBUG
     long long vqf_last = 0;
@@ -1655,7 +1660,13 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
             N.bb[id] = (unsigned short)bits_shape;
             N.off[id] = (unsigned short)lower[lane];
             N.kind[id] = bits_shape > PACX_VQ_SPLIT_BITS ? 0 : 1;
-            N.wid[id] = 0;
+            int w_leaf = 0;
+            if (bits_shape <= PACX_VQ_SPLIT_BITS) {
+                const int k_leaf = V.k_of[cnt * 33 + bits_shape];
+                w_leaf = V.w_of[cnt * 33 + bits_shape];
+                N.tot[id] = (unsigned short)(k_leaf < 0 ? 0xFFFF : k_leaf);
+            }
+            N.wid[id] = (unsigned char)w_leaf;
             N.band[id] = (unsigned char)lane;
             N.has[id] = 0;
             N.kid[id] = 0;
@@ -1733,7 +1744,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
                 }
                 int room;
                 const int at = carry + wave_excl_scan_i32(need, lane, room);
-                if (j < lev_e)
+                if (j < lev_e && need)                     /* (a small leaf keeps its pulse count there) */
                     N.tot[j] = (unsigned short)at;
                 carry += room;
             }
@@ -1753,10 +1764,12 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
                 const bool valid = g < p_n;
                 const int node = valid ? N.ord[p0 + g] : 0;
                 const int n = valid ? N.nn[node] : 0;
+                /* pulse count and index width were looked up when the leaf was created */
+                const int kraw = valid ? N.tot[node] : 0;
                 int bits = valid ? N.bb[node] : 0;
                 bits = bits > 32 ? 32 : bits;
-                const int K = valid ? V.k_of[n * 33 + bits] : 0;
-                const int width = valid ? V.w_of[n * 33 + bits] : 0;
+                const int K = (kraw == 0xFFFF) ? -1 : (n == 2 ? (bits >= 2 ? 1 << (bits - 2) : 0) : kraw);
+                const int width = valid ? N.wid[node] : 0;
                 const double x = (valid && l < n) ? cur[N.off[node] + l] : 0.0;
                 bool ok = false;
                 unsigned long long term;
@@ -1954,7 +1967,14 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 4) void k_vq_frame(PacxTables T, VqV
                     N.bb[id] = (unsigned short)(a > 65535 ? 65535 : a);
                     N.off[id] = (unsigned short)(at + (c ? half : 0));
                     N.kind[id] = splits ? 0 : 1;
-                    N.wid[id] = 0;
+                    int w_leaf = 0;
+                    if (!splits) {                         /* table lookups off the leaf pass's critical path */
+                        const int b32 = a > 32 ? 32 : a;
+                        const int k_leaf = V.k_of[half * 33 + b32];
+                        w_leaf = V.w_of[half * 33 + b32];
+                        N.tot[id] = (unsigned short)(k_leaf < 0 ? 0xFFFF : k_leaf);
+                    }
+                    N.wid[id] = (unsigned char)w_leaf;
                     N.band[id] = (unsigned char)bd;
                     N.has[id] = 0;
                     N.kid[id] = 0;
