@@ -115,13 +115,19 @@ __shared__ int vq_row_off_s[VQ_LMAX + 1];
 
 /* index term of a component of magnitude a >= 1 with k >= a pulses left and l1 dimensions
    after it: N(l1,k) + 2 (P(l1,k-1) - P(l1,k-a)) (+ N(l1,k-a) if negative) */
+/* ROWS64: only the first 64 row offsets sit in LDS (k_vq_frame: a quarter of a kilobyte instead of four --
+   the workgroups per CU of that kernel are bound by LDS); longer vectors read theirs from the table itself */
+#define VQ_ROWS_SMALL 64
+__shared__ int vq_row_off_small[VQ_ROWS_SMALL];
+template <bool ROWS64 = false>
 __device__ __forceinline__ unsigned long long vq_term(const VqView &V, int l1, long long k, long long a, bool neg)
 {
 #ifdef VQ_STUB_TERM        /* timing experiment only (wrong indices): what the table lookups cost */
     return (unsigned long long)(k + a + (neg ? 1 : 0) + l1);
 #endif
     if (l1 >= 3) {
-        const long long base = vq_row_off_s[l1], ka = k - a;
+        const long long base = ROWS64 ? (l1 < VQ_ROWS_SMALL ? vq_row_off_small[l1] : V.row_off[l1]) : vq_row_off_s[l1];
+        const long long ka = k - a;
         const uint64_t nk = V.n_tab[base + k], pk1 = V.p_tab[base + k - 1];
         const uint64_t pka = V.p_tab[base + ka], nka = V.n_tab[base + ka];
         return nk + 2ull * (pk1 - pka) + (neg ? nka : 0ull);
@@ -282,6 +288,7 @@ __device__ __forceinline__ void vq_quantize_emit(VqOut &o, double x, int n_bits,
 /* ---- one PVQ leaf --------------------------------------------------------- */
 /* xs[0..n): unit vector in LDS; t1, t2: n doubles of LDS scratch each.  Returns the enumeration
    index of the K-pulse vector (ok = false for an all-zero vector: NaN pulses in the reference). */
+template <bool ROWS64 = false>
 __device__ __forceinline__ unsigned long long vq_leaf_idx(const VqView &V, const double *xs, int n, int K,
                                                           double *t1, double *t2, int lane, bool &ok)
 {
@@ -369,7 +376,7 @@ __device__ __forceinline__ unsigned long long vq_leaf_idx(const VqView &V, const
         }
         const long long k = k_left - (incl - a);
         if (a >= 1)
-            acc += vq_term(V, n - i - 1, k, a, neg);
+            acc += vq_term<ROWS64>(V, n - i - 1, k, a, neg);
         k_left -= __shfl(incl, 63, 64);
     }
     return wave_sum_u64(acc);
@@ -399,7 +406,7 @@ __device__ __forceinline__ void vq_leaf(const VqView &V, VqOut &o, const double 
  * xor butterfly over W lanes with zeros in the unused ones adds in the order of
  * the 64-lane one).  Returns the enumeration index in every lane of the group;
  * ok = false for an all-zero vector (NaN pulses in the reference). */
-template <int W>
+template <int W, bool ROWS64 = false>
 __device__ __forceinline__ unsigned long long vq_leaf_group(const VqView &V, double x, int n, int K, int l,
                                                             bool &ok)
 {
@@ -460,7 +467,7 @@ __device__ __forceinline__ unsigned long long vq_leaf_group(const VqView &V, dou
     const long long k = (long long)K - (incl - a);
     unsigned long long term = 0;
     if (a >= 1)
-        term = vq_term(V, n - l - 1, k, a, x < 0.0);
+        term = vq_term<ROWS64>(V, n - l - 1, k, a, x < 0.0);
 #pragma unroll
     for (int off = W / 2; off > 0; off >>= 1)
         term = term + (unsigned long long)__shfl_xor((long long)term, off, W);
@@ -1446,8 +1453,10 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
  * Arithmetic per node is that of vq_shape / vq_leaf / vq_leaf_group.  A unit whose trees do not fit
  * the store (bit rates far above the shipped ones) is left to k_vq: n_bytes / unit_bits = -1. */
 #ifndef VQF_NCAP
-#define VQF_NCAP 256                   /* nodes per (sub-)block: 31 KB of LDS with the rest, five workgroups per CU
-                                          (448 nodes and 1184-double buffers: four, 571 against 487 us) */
+#define VQF_NCAP 416                   /* nodes per (sub-)block.  With the 1088-double level buffers and the small
+                                          row-offset table that is 31 KB of LDS: five workgroups per CU (448 nodes: four,
+                                          571 against 487 us on one box; a sixth, at 80 VGPRs with three spilled,
+                                          gave nothing: 494 us) */
 #endif
 #define VQF_NLV 256                    /* nodes per level */
 #ifndef VQF_BUF
@@ -1508,7 +1517,10 @@ __device__ __forceinline__ void vq_quantize_code(double x, int n_bits, unsigned 
     }
 }
 
-__global__ __launch_bounds__(64 * VQ_WAVES, 5) void k_vq_frame(PacxTables T, VqView V, VqArgs A)
+#ifndef VQF_OCC
+#define VQF_OCC 5
+#endif
+__global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables T, VqView V, VqArgs A)
 {
 #ifdef PACX_VQ_DEBUG
     long long vqf_last = 0;
@@ -1567,8 +1579,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 5) void k_vq_frame(PacxTables T, VqV
 
     for (int i = tid; i < VQ_WORDS; i += 64 * VQ_WAVES)
         words[i] = 0u;
-    for (int i = tid; i <= min(V.l_max, VQ_LMAX); i += 64 * VQ_WAVES)
-        vq_row_off_s[i] = V.row_off[i];
+    if (tid < VQ_ROWS_SMALL && tid <= V.l_max)
+        vq_row_off_small[tid] = V.row_off[tid];
     if (tid < 3)
         misc[tid] = 0;
     VQF_T(15);
@@ -1774,9 +1786,9 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 5) void k_vq_frame(PacxTables T, VqV
                 bool ok = false;
                 unsigned long long term;
                 if (c == 0)
-                    term = vq_leaf_group<16>(V, x, n, K < 0 ? 0 : K, l, ok);
+                    term = vq_leaf_group<16, true>(V, x, n, K < 0 ? 0 : K, l, ok);
                 else
-                    term = vq_leaf_group<32>(V, x, n, K < 0 ? 0 : K, l, ok);
+                    term = vq_leaf_group<32, true>(V, x, n, K < 0 ? 0 : K, l, ok);
                 if (valid && l == 0) {
                     if (K < 0) {                   /* a 1-dimensional leaf: the reference never returns */
                         N.kind[node] = 3;
@@ -1798,7 +1810,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, 5) void k_vq_frame(PacxTables T, VqV
                 const int width = ldc(&V.w_of[n * 33 + bits]);
                 bool ok = true;
                 double *t1 = nxt + N.tot[node];
-                const unsigned long long idx = vq_leaf_idx(V, cur + N.off[node], n, K, t1, t1 + n, lane, ok);
+                const unsigned long long idx = vq_leaf_idx<true>(V, cur + N.off[node], n, K, t1, t1 + n, lane, ok);
                 if (!ok)
                     undefined = true;
                 if (lane == 0) {
