@@ -1879,27 +1879,43 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                     N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
             }
         };
-        /* passes are dealt round-robin, the expensive classes first (a wave's last pass is a cheap one) */
-        {
-            const int order[8] = {7, 2, 6, 5, 1, 4, 0, 3};
-            int items_before = 0, t_next = wave;
+        /* passes are dealt round-robin, the expensive classes first (a wave's last pass is a cheap one).
+           First the splits on all four waves; the leaves of the level do not depend on its scalar stage,
+           so they run NEXT to it: the waves without a share of the scalar stage take them */
+        auto deal = [&](const int *order, int n_classes, int first_wave, int n_waves) {
+            int items_before = 0, t_next = wave - first_wave;
+            if (t_next < 0)
+                return;
 #pragma unroll 1
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < n_classes; ++k) {
                 const int c = order[k];
                 const int c_b = N.cls[c], c_n = N.cls[c + 1] - c_b;
                 const int lg = (c == 0) ? 2 : (c == 1) ? 1 : (c == 2) ? 0 : (c == 3) ? 3 : (c == 4) ? 2 : (c == 5) ? 1 : 0;
                 const int items = (c_n + (1 << lg) - 1) >> lg;
-                for (; t_next < items_before + items; t_next += VQ_WAVES) {
+                for (; t_next < items_before + items; t_next += n_waves) {
                     const int p0 = c_b + ((t_next - items_before) << lg);
                     do_item(c, p0, min(1 << lg, c_b + c_n - p0));
                 }
                 items_before += items;
             }
+        };
+        {
+            const int split_order[5] = {7, 6, 5, 4, 3};
+            deal(split_order, 5, 0, VQ_WAVES);
         }
         __syncthreads();
         VQF_T(2);
         /* ---- the level's splits, one per lane: angle, bit split, children */
         const int s_b = N.cls[3], s_n = N.cls[8] - s_b;
+        {
+            /* leaves: on the waves the scalar stage leaves free (all four when it takes none or all of them) */
+            const int busy = (s_n + 63) >> 6;
+            const int leaf_order[3] = {2, 1, 0};
+            if (busy == 0 || busy >= VQ_WAVES)
+                deal(leaf_order, 3, 0, VQ_WAVES);
+            else
+                deal(leaf_order, 3, busy, VQ_WAVES - busy);
+        }
         for (int k0 = 64 * wave; k0 < s_n; k0 += 64 * VQ_WAVES) {
             const bool has = k0 + lane < s_n;
             const int snode = has ? N.ord[s_b + k0 + lane] : 0;
