@@ -203,7 +203,7 @@ struct VqOut {
 };
 
 #ifdef PACX_VQ_DEBUG
-__device__ long long g_vq_dbg[16];
+__device__ long long g_vq_dbg[32];
 /* inside the band walk: slots 8.. = split arithmetic, quad attempt, leaf pair, single leaf, climb, band set-up, gain */
 #define VQ_S(o, k) do { long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
                         if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_vq_dbg[k], (unsigned long long)(t_ - (o).t_last)); \
@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
  * Arithmetic per node is that of vq_shape / vq_leaf / vq_leaf_group.  A unit whose trees do not fit
  * the store (bit rates far above the shipped ones) is left to k_vq: n_bytes / unit_bits = -1. */
 #ifndef VQF_NCAP
-#define VQF_NCAP 416                   /* nodes per (sub-)block.  With the 1088-double level buffers and the small
+#define VQF_NCAP 352                   /* nodes per (sub-)block.  With the 1088-double level buffers and the small
                                           row-offset table that is 31 KB of LDS: five workgroups per CU (448 nodes: four,
                                           571 against 487 us on one box; a sixth, at 80 VGPRs with three spilled,
                                           gave nothing: 494 us) */
@@ -1517,6 +1517,16 @@ __device__ __forceinline__ void vq_quantize_code(double x, int n_bits, unsigned 
     }
 }
 
+#ifdef PACX_VQ_DEBUG
+#define VQF_SUB(k) do { long long t3_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3_) :: "memory"); \
+                        if (lane == 0) atomicAdd((unsigned long long *)&g_vq_dbg[k], (unsigned long long)(t3_ - t_sub)); t_sub = t3_; } while (0)
+#else
+#define VQF_SUB(k) do { } while (0)
+#endif
+#define VQF_HL 64                      /* 0.5 log2(L), L < 64, in LDS */
+#define VQF_LT 127                     /* log2(tan) of the angle codes of 1..7 bits in LDS */
+__shared__ double vqf_half_log2[VQF_HL];
+__shared__ double vqf_log2_tan[VQF_LT + 1];
 #ifndef VQF_OCC
 #define VQF_OCC 5
 #endif
@@ -1581,6 +1591,12 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         words[i] = 0u;
     if (tid < VQ_ROWS_SMALL && tid <= V.l_max)
         vq_row_off_small[tid] = V.row_off[tid];
+    /* the scalar stage of a level is one dependency chain, and it is what the kernel waits for: the two
+       tables it reads sit in LDS as far as they are commonly needed (halves below 64, angles of up to 7 bits) */
+    if (tid < VQF_HL && tid <= V.l_max)
+        vqf_half_log2[tid] = V.half_log2[tid];
+    if (tid < VQF_LT)
+        vqf_log2_tan[tid] = V.log2_tan[tid];
     if (tid < 3)
         misc[tid] = 0;
     VQF_T(15);
@@ -1672,13 +1688,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             N.bb[id] = (unsigned short)bits_shape;
             N.off[id] = (unsigned short)lower[lane];
             N.kind[id] = bits_shape > PACX_VQ_SPLIT_BITS ? 0 : 1;
-            int w_leaf = 0;
-            if (bits_shape <= PACX_VQ_SPLIT_BITS) {
-                const int k_leaf = V.k_of[cnt * 33 + bits_shape];
-                w_leaf = V.w_of[cnt * 33 + bits_shape];
-                N.tot[id] = (unsigned short)(k_leaf < 0 ? 0xFFFF : k_leaf);
-            }
-            N.wid[id] = (unsigned char)w_leaf;
+            N.wid[id] = 0;
             N.band[id] = (unsigned char)lane;
             N.has[id] = 0;
             N.kid[id] = 0;
@@ -1756,7 +1766,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 }
                 int room;
                 const int at = carry + wave_excl_scan_i32(need, lane, room);
-                if (j < lev_e && need)                     /* (a small leaf keeps its pulse count there) */
+                if (j < lev_e && need)
                     N.tot[j] = (unsigned short)at;
                 carry += room;
             }
@@ -1769,6 +1779,10 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             break;
         /* ---- one pass: `p_n` nodes of class c, ord[p0 ..) */
         auto do_item = [&](int c, int p0, int p_n) {
+#ifdef PACX_VQ_DEBUG
+            long long t_in;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_in) :: "memory");
+#endif
             if (c <= 1) {
                 /* leaves, four or two per pass */
                 const int lw = (c == 0) ? 4 : 5, W = 1 << lw;
@@ -1776,12 +1790,11 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 const bool valid = g < p_n;
                 const int node = valid ? N.ord[p0 + g] : 0;
                 const int n = valid ? N.nn[node] : 0;
-                /* pulse count and index width were looked up when the leaf was created */
-                const int kraw = valid ? N.tot[node] : 0;
+                /* pulse count and index width: looked up here, beside the scalar stage, not in it */
                 int bits = valid ? N.bb[node] : 0;
                 bits = bits > 32 ? 32 : bits;
-                const int K = (kraw == 0xFFFF) ? -1 : (n == 2 ? (bits >= 2 ? 1 << (bits - 2) : 0) : kraw);
-                const int width = valid ? N.wid[node] : 0;
+                const int K = valid ? V.k_of[n * 33 + bits] : 0;
+                const int width = valid ? V.w_of[n * 33 + bits] : 0;
                 const double x = (valid && l < n) ? cur[N.off[node] + l] : 0.0;
                 bool ok = false;
                 unsigned long long term;
@@ -1878,45 +1891,52 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 if (lane == 0)
                     N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
             }
+#ifdef PACX_VQ_DEBUG
+            {
+                long long t_out;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_out) :: "memory");
+                if (lane == 0) {
+                    atomicAdd((unsigned long long *)&g_vq_dbg[8 + c], (unsigned long long)(t_out - t_in));
+                    atomicAdd((unsigned long long *)&g_vq_dbg[16 + c], 1ull);
+                }
+            }
+#endif
         };
         /* passes are dealt round-robin, the expensive classes first (a wave's last pass is a cheap one).
            First the splits on all four waves; the leaves of the level do not depend on its scalar stage,
            so they run NEXT to it: the waves without a share of the scalar stage take them */
-        auto deal = [&](const int *order, int n_classes, int first_wave, int n_waves) {
-            int items_before = 0, t_next = wave - first_wave;
-            if (t_next < 0)
-                return;
+        /* pass t of a stage goes to wave (pattern >> 2 (t mod period)) & 3 */
+        auto deal = [&](const int *order, int n_classes, unsigned pattern, int period) {
+            int ph = 0;
 #pragma unroll 1
             for (int k = 0; k < n_classes; ++k) {
                 const int c = order[k];
                 const int c_b = N.cls[c], c_n = N.cls[c + 1] - c_b;
                 const int lg = (c == 0) ? 2 : (c == 1) ? 1 : (c == 2) ? 0 : (c == 3) ? 3 : (c == 4) ? 2 : (c == 5) ? 1 : 0;
-                const int items = (c_n + (1 << lg) - 1) >> lg;
-                for (; t_next < items_before + items; t_next += n_waves) {
-                    const int p0 = c_b + ((t_next - items_before) << lg);
-                    do_item(c, p0, min(1 << lg, c_b + c_n - p0));
+                for (int p0 = c_b; p0 < c_b + c_n; p0 += 1 << lg) {
+                    if ((int)((pattern >> (2 * ph)) & 3u) == wave)
+                        do_item(c, p0, min(1 << lg, c_b + c_n - p0));
+                    ph = (ph + 1 == period) ? 0 : ph + 1;
                 }
-                items_before += items;
             }
         };
+        const unsigned EVEN = 0xE4u;                       /* 0, 1, 2, 3 */
         {
             const int split_order[5] = {7, 6, 5, 4, 3};
-            deal(split_order, 5, 0, VQ_WAVES);
+            deal(split_order, 5, EVEN, 4);
         }
         __syncthreads();
         VQF_T(2);
         /* ---- the level's splits, one per lane: angle, bit split, children */
         const int s_b = N.cls[3], s_n = N.cls[8] - s_b;
-        {
-            /* leaves: on the waves the scalar stage leaves free (all four when it takes none or all of them) */
-            const int busy = (s_n + 63) >> 6;
-            const int leaf_order[3] = {2, 1, 0};
-            if (busy == 0 || busy >= VQ_WAVES)
-                deal(leaf_order, 3, 0, VQ_WAVES);
-            else
-                deal(leaf_order, 3, busy, VQ_WAVES - busy);
-        }
         for (int k0 = 64 * wave; k0 < s_n; k0 += 64 * VQ_WAVES) {
+#ifdef PACX_VQ_DEBUG
+            long long t_sc;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_sc) :: "memory");
+#endif
+#ifdef PACX_VQ_DEBUG
+            long long t_sub = t_sc;
+#endif
             const bool has = k0 + lane < s_n;
             const int snode = has ? N.ord[s_b + k0 + lane] : 0;
             const int sn = has ? N.nn[snode] : 2;
@@ -1924,7 +1944,9 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             const int bits = has ? N.bb[snode] : 0;
             const double q = has ? __longlong_as_double((long long)N.val[snode]) : -1.0;
             const double theta = (q < 0.0) ? 0.0 : vq_atan(q);
-            const int a_theta = (int)floor((double)bits / (double)half + V.half_log2[half]);
+            VQF_SUB(26);
+            const double hl = (half < VQF_HL) ? vqf_half_log2[half] : V.half_log2[half];
+            const int a_theta = (int)floor((double)bits / (double)half + hl);
             int a_rest = bits - a_theta;
             if (a_rest < 0)
                 a_rest = 0;
@@ -1950,17 +1972,21 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                     dq = -dq;
                 theta_q = dq * half_pi;
             }
+            VQF_SUB(27);
             int a_mid = 0;
             if (theta_q != 0.0) {
                 double lt;
-                if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta_q > 0.0)
-                    lt = V.log2_tan[((1 << (a_theta - 1)) - 1) + (int)code];
+                if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta_q > 0.0) {
+                    const int at_lt = ((1 << (a_theta - 1)) - 1) + (int)code;
+                    lt = (at_lt < VQF_LT) ? vqf_log2_tan[at_lt] : V.log2_tan[at_lt];
+                }
                 else
                     lt = vq_log2_tan(theta_q);
                 const double v = ((double)a_rest - (double)(half - 1) * lt) / 2.0;
                 const double f = floor(v);
                 a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
             }
+            VQF_SUB(28);
             const int a_side = a_rest - a_mid;
             const int c_mid = (has && a_mid > 0) ? 1 : 0, c_side = (has && a_side > 0) ? 1 : 0;
             int born;
@@ -1974,6 +2000,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                     misc[1] = 1;
                 continue;
             }
+            VQF_SUB(29);
             if (has) {
                 const int first = base + rel;
                 N.val[snode] = code;
@@ -1995,20 +2022,33 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                     N.bb[id] = (unsigned short)(a > 65535 ? 65535 : a);
                     N.off[id] = (unsigned short)(at + (c ? half : 0));
                     N.kind[id] = splits ? 0 : 1;
-                    int w_leaf = 0;
-                    if (!splits) {                         /* table lookups off the leaf pass's critical path */
-                        const int b32 = a > 32 ? 32 : a;
-                        const int k_leaf = V.k_of[half * 33 + b32];
-                        w_leaf = V.w_of[half * 33 + b32];
-                        N.tot[id] = (unsigned short)(k_leaf < 0 ? 0xFFFF : k_leaf);
-                    }
-                    N.wid[id] = (unsigned char)w_leaf;
+                    N.wid[id] = 0;
                     N.band[id] = (unsigned char)bd;
                     N.has[id] = 0;
                     N.kid[id] = 0;
                     N.val[id] = 0ull;
                 }
             }
+#ifdef PACX_VQ_DEBUG
+            {
+                long long t2_;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory");
+                if (lane == 0) {
+                    atomicAdd((unsigned long long *)&g_vq_dbg[24], (unsigned long long)(t2_ - t_sc));
+                    atomicAdd((unsigned long long *)&g_vq_dbg[25], 1ull);
+                }
+            }
+#endif
+        }
+        {
+            /* the leaves of the level, beside its scalar stage: a wave with a share of that stage (64 splits
+               each) takes a seventh of what the others take */
+            const int busy = (s_n + 63) >> 6;
+            const int leaf_order[3] = {2, 1, 0};
+            /* owners of passes 0.. : busy = 1: 1 2 3 1 2 3 0;  2: 2 3 2 3 2 3 0 1;  3: 3 0 3 1 3 2 3 */
+            const unsigned pat = busy == 1 ? 0x0E79u : busy == 2 ? 0x4EEEu : busy == 3 ? 0x3B73u : EVEN;
+            const int per = busy == 1 ? 7 : busy == 2 ? 8 : busy == 3 ? 7 : 4;
+            deal(leaf_order, 3, pat, per);
         }
         __syncthreads();
         VQF_T(3);

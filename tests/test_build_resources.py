@@ -39,7 +39,8 @@ HOT = [
     (r"^k_tail_long\(", 128, 4),
     (r"^k_tail_short\(", 72, 7),
     (r"^k_gather_small\(", None, None),
-    (r"^k_vq\(", 128, 3),
+    (r"^k_vq_frame\(", 102, 5),                          # gain-shape coder: five workgroups per CU is what it runs on
+    (r"^k_vq\(", 128, 4),                                # ... its fallback for trees beyond the node store
     (r"^k_vq_join\(", None, None),
     (r"^k_vq_dec\(", 168, 3),
     (r"^k_unpack\(", None, None),
@@ -75,3 +76,20 @@ def test_only_listed_kernels_use_scratch(res):
     for name, r in res.items():
         if r["scratch"] or r["vgpr_spill"]:
             assert any(a in name for a in allowed), f"{name}: scratch {r['scratch']}, spilled {r['vgpr_spill']}"
+
+
+def test_vq_frame_lds_allows_five_workgroups(res):
+    """k_vq_frame is bound by dependency chains, so workgroups per CU are its throughput: its dynamic LDS (the
+    launcher's VQF_SMEM) plus its static arrays must fit five times into a CU's 160 KB."""
+    import os
+    src = open(os.path.join(os.path.dirname(__file__), "..", "audio-codec_amd", "csrc", "k_vq.hip")).read()
+    def macro(name):
+        m = re.search(r"#define\s+%s\s+\(?([^/\n]+?)\)?\s*(/\*|\n)" % name, src)
+        assert m, name
+        return m.group(1).strip()
+    ncap, nlv = int(macro("VQF_NCAP")), int(macro("VQF_NLV"))
+    fixed = int(macro("VQF_FIXED"))
+    buf = eval(macro("VQF_BUF").replace("PACX_M_LONG", "1024"))
+    smem = fixed + 2 * buf * 8 + ncap * 8 + 6 * ncap * 2 + 4 * ncap + nlv * 2 + 64 + 64
+    static_lds = max(v["lds"] for k, v in res.items() if k.startswith("k_vq_frame("))   # its static arrays
+    assert 5 * (smem + static_lds) <= 160 * 1024 - 5 * 512, (smem, static_lds)
