@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
  * Arithmetic per node is that of vq_shape / vq_leaf / vq_leaf_group.  A unit whose trees do not fit
  * the store (bit rates far above the shipped ones) is left to k_vq: n_bytes / unit_bits = -1. */
 #ifndef VQF_NCAP
-#define VQF_NCAP 352                   /* nodes per (sub-)block.  With the 1088-double level buffers and the small
+#define VQF_NCAP 320                   /* nodes per (sub-)block.  With the 1088-double level buffers and the small
                                           row-offset table that is 31 KB of LDS: five workgroups per CU (448 nodes: four,
                                           571 against 487 us on one box; a sixth, at 80 VGPRs with three spilled,
                                           gave nothing: 494 us) */
@@ -1463,14 +1463,14 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
 #define VQF_BUF (PACX_M_LONG + 64)     /* doubles per level buffer */
 #endif
 #define VQF_FIXED 3072                 /* words, gains, allocations, starts, ticket, gain bits, roots, counters */
-#define VQF_SMEM (VQF_FIXED + 2 * VQF_BUF * 8 + VQF_NCAP * 8 + 6 * VQF_NCAP * 2 + 4 * VQF_NCAP + VQF_NLV * 2 + 64 + 64)
+#define VQF_SMEM (VQF_FIXED + 2 * VQF_BUF * 8 + VQF_NCAP * 8 + 6 * VQF_NCAP * 2 + 4 * VQF_NCAP + 2 * VQF_NLV * 2 + 128 + 64)
 
 struct VqfStore {
     unsigned long long *val;
     unsigned short *nn, *bb, *off, *tot, *pos, *kid;
     unsigned char *kind, *wid, *band, *has;
-    unsigned short *ord;               /* [NLV] the open level's nodes grouped by class */
-    int *cls;                          /* [9] class starts in ord, [9..15] spare */
+    unsigned short *ord;               /* [2][NLV] a level's nodes grouped by class (two levels' lists alternate) */
+    int *cls;                          /* [2][16] class starts in ord ([9] used) */
     unsigned short *lvl;               /* [VQ_DEPTH + 2] first node of every depth */
     __device__ __forceinline__ void bind(unsigned char *p)
     {
@@ -1486,8 +1486,8 @@ struct VqfStore {
         band = wid + VQF_NCAP;
         has = band + VQF_NCAP;
         ord = (unsigned short *)(has + VQF_NCAP);
-        cls = (int *)(ord + VQF_NLV);
-        lvl = (unsigned short *)(cls + 16);
+        cls = (int *)(ord + 2 * VQF_NLV);
+        lvl = (unsigned short *)(cls + 32);
     }
 };
 
@@ -1701,79 +1701,87 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
     }
     __syncthreads();
 
+    /* ---- a level's nodes grouped by class (ord / cls of that level's parity), room for what they write to the
+       next buffer.  One wave.  Level d + 1 is classified while level d's leaves are still being coded from
+       level d's lists: the lists alternate between two copies */
+    auto classify = [&](int lev_b, int lev_e, int par) {
+        unsigned short *ord_w = N.ord + par * VQF_NLV;
+        int *cls_w = N.cls + par * 16;
+        int cnt_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (lane == 0) {
+            misc[3] = 0;
+            misc[4] = 0;
+            if (lev_e - lev_b > VQF_NLV)
+                misc[1] = 1;
+        }
+        for (int base = lev_b; base < lev_e && lev_e - lev_b <= VQF_NLV; base += 64) {
+            const int j = base + lane;
+            int c = 8;
+            if (j < lev_e) {
+                const int n = N.nn[j], half = n - n / 2;
+                if (N.kind[j] == 1)
+                    c = n <= 16 ? 0 : (n <= 32 ? 1 : 2);
+                else
+                    c = half <= 8 ? 3 : (half <= 16 ? 4 : (half <= 32 ? 5 : (half <= 64 ? 6 : 7)));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                cnt_c[k] += __popcll(__builtin_amdgcn_ballot_w64(c == k));
+        }
+        int start_c[9];
+        start_c[0] = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            start_c[k + 1] = start_c[k] + cnt_c[k];
+        if (lane < 9) {
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                v = (lane == k) ? start_c[k] : v;
+            cls_w[lane] = v;
+        }
+        int run_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int carry = 0;
+        for (int base = lev_b; base < lev_e && lev_e - lev_b <= VQF_NLV; base += 64) {
+            const int j = base + lane;
+            int c = 8, need = 0;
+            if (j < lev_e) {
+                const int n = N.nn[j], half = n - n / 2;
+                if (N.kind[j] == 1) {
+                    c = n <= 16 ? 0 : (n <= 32 ? 1 : 2);
+                    need = c == 2 ? 2 * n : 0;           /* scratch of a single big leaf */
+                } else {
+                    c = half <= 8 ? 3 : (half <= 16 ? 4 : (half <= 32 ? 5 : (half <= 64 ? 6 : 7)));
+                    need = 2 * half;                    /* its children's vectors */
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(c == k);
+                if (c == k)
+                    ord_w[start_c[k] + run_c[k] + __popcll(m & below)] = (unsigned short)j;
+                run_c[k] += __popcll(m);
+            }
+            int room;
+            const int at = carry + wave_excl_scan_i32(need, lane, room);
+            if (j < lev_e && need)
+                N.tot[j] = (unsigned short)at;
+            carry += room;
+        }
+        if (carry > VQF_BUF && lane == 0)
+            misc[1] = 1;
+    };
     VQF_T(0);
     bool undefined = false;
     int lev_b = 0, lev_e = misc[0], depth = 0;
+    if (wave == 0)
+        classify(0, lev_e, 0);
+    __syncthreads();
     for (;;) {
         const double *cur = buf0 + (depth & 1) * VQF_BUF;
         double *nxt = buf0 + ((depth + 1) & 1) * VQF_BUF;
-        /* ---- wave 0: the level's nodes grouped by class, room for what they write to the next buffer */
-        if (wave == 0) {
-            int cnt_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (lane == 0) {
-                misc[3] = 0;
-                misc[4] = 0;
-                if (lev_e - lev_b > VQF_NLV)
-                    misc[1] = 1;
-            }
-            for (int base = lev_b; base < lev_e && lev_e - lev_b <= VQF_NLV; base += 64) {
-                const int j = base + lane;
-                int c = 8;
-                if (j < lev_e) {
-                    const int n = N.nn[j], half = n - n / 2;
-                    if (N.kind[j] == 1)
-                        c = n <= 16 ? 0 : (n <= 32 ? 1 : 2);
-                    else
-                        c = half <= 8 ? 3 : (half <= 16 ? 4 : (half <= 32 ? 5 : (half <= 64 ? 6 : 7)));
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    cnt_c[k] += __popcll(__builtin_amdgcn_ballot_w64(c == k));
-            }
-            int start_c[9];
-            start_c[0] = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                start_c[k + 1] = start_c[k] + cnt_c[k];
-            if (lane < 9) {
-                int v = 0;
-#pragma unroll
-                for (int k = 0; k < 9; ++k)
-                    v = (lane == k) ? start_c[k] : v;
-                N.cls[lane] = v;
-            }
-            int run_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            int carry = 0;
-            for (int base = lev_b; base < lev_e && lev_e - lev_b <= VQF_NLV; base += 64) {
-                const int j = base + lane;
-                int c = 8, need = 0;
-                if (j < lev_e) {
-                    const int n = N.nn[j], half = n - n / 2;
-                    if (N.kind[j] == 1) {
-                        c = n <= 16 ? 0 : (n <= 32 ? 1 : 2);
-                        need = c == 2 ? 2 * n : 0;           /* scratch of a single big leaf */
-                    } else {
-                        c = half <= 8 ? 3 : (half <= 16 ? 4 : (half <= 32 ? 5 : (half <= 64 ? 6 : 7)));
-                        need = 2 * half;                    /* its children's vectors */
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(c == k);
-                    if (c == k)
-                        N.ord[start_c[k] + run_c[k] + __popcll(m & below)] = (unsigned short)j;
-                    run_c[k] += __popcll(m);
-                }
-                int room;
-                const int at = carry + wave_excl_scan_i32(need, lane, room);
-                if (j < lev_e && need)
-                    N.tot[j] = (unsigned short)at;
-                carry += room;
-            }
-            if (carry > VQF_BUF && lane == 0)
-                misc[1] = 1;
-        }
-        __syncthreads();
+        const unsigned short *ord_c = N.ord + (depth & 1) * VQF_NLV;
+        const int *cls_c = N.cls + (depth & 1) * 16;
         VQF_T(1);
         if (misc[1])
             break;
@@ -1788,7 +1796,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 const int lw = (c == 0) ? 4 : 5, W = 1 << lw;
                 const int g = lane >> lw, l = lane & (W - 1);
                 const bool valid = g < p_n;
-                const int node = valid ? N.ord[p0 + g] : 0;
+                const int node = valid ? ord_c[p0 + g] : 0;
                 const int n = valid ? N.nn[node] : 0;
                 /* pulse count and index width: looked up here, beside the scalar stage, not in it */
                 int bits = valid ? N.bb[node] : 0;
@@ -1815,7 +1823,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 if (valid && (K < 0 || !ok))
                     undefined = true;
             } else if (c == 2) {
-                const int node = N.ord[p0];
+                const int node = ord_c[p0];
                 const int n = N.nn[node];
                 int bits = N.bb[node];
                 bits = bits > 32 ? 32 : bits;
@@ -1836,7 +1844,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 const int P = 1 << lp;
                 const int g = lane >> lp, i = lane & (P - 1);
                 const bool valid = g < p_n;
-                const int node = valid ? N.ord[p0 + g] : 0;
+                const int node = valid ? ord_c[p0 + g] : 0;
                 const int n = valid ? N.nn[node] : 0;
                 const int cut = n / 2, half = n - cut;
                 const double *src = cur + (valid ? N.off[node] : 0);
@@ -1864,7 +1872,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                     N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
             } else {
                 /* a split of more than 128 components: lanes strided over the half */
-                const int node = N.ord[p0];
+                const int node = ord_c[p0];
                 const int n = N.nn[node];
                 const double *src = cur + N.off[node];
                 const int cut = n / 2, half = n - cut;
@@ -1911,7 +1919,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
 #pragma unroll 1
             for (int k = 0; k < n_classes; ++k) {
                 const int c = order[k];
-                const int c_b = N.cls[c], c_n = N.cls[c + 1] - c_b;
+                const int c_b = cls_c[c], c_n = cls_c[c + 1] - c_b;
                 const int lg = (c == 0) ? 2 : (c == 1) ? 1 : (c == 2) ? 0 : (c == 3) ? 3 : (c == 4) ? 2 : (c == 5) ? 1 : 0;
                 for (int p0 = c_b; p0 < c_b + c_n; p0 += 1 << lg) {
                     if ((int)((pattern >> (2 * ph)) & 3u) == wave)
@@ -1928,7 +1936,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         __syncthreads();
         VQF_T(2);
         /* ---- the level's splits, one per lane: angle, bit split, children */
-        const int s_b = N.cls[3], s_n = N.cls[8] - s_b;
+        const int s_b = cls_c[3], s_n = cls_c[8] - s_b;
+        const bool early = s_n <= 64;
         for (int k0 = 64 * wave; k0 < s_n; k0 += 64 * VQ_WAVES) {
 #ifdef PACX_VQ_DEBUG
             long long t_sc;
@@ -1938,7 +1947,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             long long t_sub = t_sc;
 #endif
             const bool has = k0 + lane < s_n;
-            const int snode = has ? N.ord[s_b + k0 + lane] : 0;
+            const int snode = has ? ord_c[s_b + k0 + lane] : 0;
             const int sn = has ? N.nn[snode] : 2;
             const int half = sn - sn / 2;
             const int bits = has ? N.bb[snode] : 0;
@@ -2045,9 +2054,15 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                each) takes a seventh of what the others take */
             const int busy = (s_n + 63) >> 6;
             const int leaf_order[3] = {2, 1, 0};
-            /* owners of passes 0.. : busy = 1: 1 2 3 1 2 3 0;  2: 2 3 2 3 2 3 0 1;  3: 3 0 3 1 3 2 3 */
-            const unsigned pat = busy == 1 ? 0x0E79u : busy == 2 ? 0x4EEEu : busy == 3 ? 0x3B73u : EVEN;
-            const int per = busy == 1 ? 7 : busy == 2 ? 8 : busy == 3 ? 7 : 4;
+            /* owners of passes 0.. : busy = 1: 1 2 3 (wave 0 sorts the next level);  2: 2 3 2 3 2 3 0 1;  3: 3 0 3 1 3 2 3 */
+            const unsigned pat = busy == 1 ? 0x39u : busy == 2 ? 0x4EEEu : busy == 3 ? 0x3B73u : EVEN;
+            const int per = busy == 1 ? 3 : busy == 2 ? 8 : busy == 3 ? 7 : 4;
+            /* one chunk of splits: wave 0 made all the children itself and sorts the next level at once */
+            if (early && wave == 0) {
+                vq_fence();
+                if (!misc[1])
+                    classify(lev_e, misc[0], (depth + 1) & 1);
+            }
             deal(leaf_order, 3, pat, per);
         }
         __syncthreads();
@@ -2064,6 +2079,11 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         }
         lev_b = lev_e;
         lev_e = n_nodes;
+        if (!early) {
+            if (wave == 0)
+                classify(lev_b, lev_e, depth & 1);
+            __syncthreads();
+        }
         if (depth > VQ_DEPTH) {                            /* cannot happen: splits stop at VQ_DEPTH - 1 */
             if (tid == 0)
                 misc[1] = 1;

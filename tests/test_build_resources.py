@@ -90,6 +90,6 @@ def test_vq_frame_lds_allows_five_workgroups(res):
     ncap, nlv = int(macro("VQF_NCAP")), int(macro("VQF_NLV"))
     fixed = int(macro("VQF_FIXED"))
     buf = eval(macro("VQF_BUF").replace("PACX_M_LONG", "1024"))
-    smem = fixed + 2 * buf * 8 + ncap * 8 + 6 * ncap * 2 + 4 * ncap + nlv * 2 + 64 + 64
+    smem = fixed + 2 * buf * 8 + ncap * 8 + 6 * ncap * 2 + 4 * ncap + 2 * nlv * 2 + 128 + 64
     static_lds = max(v["lds"] for k, v in res.items() if k.startswith("k_vq_frame("))   # its static arrays
     assert 5 * (smem + static_lds) <= 160 * 1024 - 5 * 512, (smem, static_lds)
