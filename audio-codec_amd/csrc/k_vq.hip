@@ -1963,7 +1963,25 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             double theta_q = 0.0;
             unsigned long long code = 0ull;
             int w_theta = 0;
-            if (a_theta > 62) {
+            if (!__builtin_amdgcn_ballot_w64(a_theta > 31)) {
+                /* every angle of this chunk has at most 31 bits (all but freak allocations): the same values
+                   in 32-bit integers -- one conversion instruction where the 64-bit ones take a dozen */
+                if (a_theta > 0) {
+                    const double factor = (double)((1u << a_theta) - 1u);
+                    unsigned c32;
+                    if (tn >= 1.0)
+                        c32 = (1u << (a_theta - 1)) - 1u;
+                    else
+                        c32 = (unsigned)floor((factor * tn + 1.0) * 0.5);
+                    code = c32;
+                    w_theta = a_theta;
+                    const unsigned mag = c32 & ((1u << (a_theta - 1)) - 1u);
+                    double dq = (double)(2u * mag) / factor;
+                    if (c32 >> (a_theta - 1))
+                        dq = -dq;
+                    theta_q = dq * half_pi;
+                }
+            } else if (a_theta > 62) {
                 if (has)
                     undefined = true;
             } else if (a_theta > 0) {
