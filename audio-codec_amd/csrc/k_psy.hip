@@ -99,8 +99,9 @@ __device__ __forceinline__ PacxPeak make_peak(double left, double centre, int f,
  *       Bark values and SPLs overwrite one round of 64 at a time (masker p comes from bins
  *       i_p - 1, i_p with i_p >= 2 p + 1, so slots 2p, 2p + 1 are never read again)
  *     region A (1 KB): peak bin numbers
- *   with SBR (inten is needed to the end): 17.5 KB -> 9 waves per CU
- *     region A (9 KB): the tile, later bin numbers, Bark values, SPLs;  region B: raw, inten
+ *   (COMPACT false, 17.5 KB, region A holding the tile: the layout of the time when the maskers'
+ *    Bark values and SPLs were kept in LDS; no launcher uses it any more -- SBR handles, whose epilogue
+ *    needs the intensities to the end, run the compact kernel too)
  * The packed spectrum Z never goes to LDS: the real-FFT split needs Z[k] with
  * Z[N/2-k], and with natural-order FFT output (wave_fft.h fft512n) that
  * partner sits in the mirrored lane's mirrored register, one ds_bpermute away. */
@@ -444,7 +445,7 @@ __device__ __forceinline__ void side_long_one(const PacxTables &T, const PacxPcm
        ScaleFactor is monotone, so min(sf(max MDCT), sf(max FFT)) is
        sf(max of both); magnitudes come back from the intensities
        (|X| = sqrt(I/norm), two roundings away from np.abs). */
-    if (!COMPACT && sbr_mean) {
+    if (sbr_mean) {
         wave_lds_fence();
         double mx = 0.0;
         for (int i = lane; i <= 1024; i += 64)
@@ -1099,10 +1100,10 @@ static void launch_side(const PacxTables &T, const PacxPcmView &in, const uint8_
     const int part = mixed >> 4;
     mixed &= 15;
     const bool do_long = (!short_blocks || mixed) && part != 2, do_short = (short_blocks || mixed) && part != 1;
-    if (do_long && sbr_mean)
-        hipLaunchKernelGGL((k_side_long<DT, FAST, false>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks,
-                           n_peaks, n_kept, sbr_mean, sbr_overall);
-    else if (do_long)
+    /* SBR handles run the same compact kernel: the maskers no longer pass through LDS, so the intensities
+       are intact when the SBR epilogue wants them (the 17.5 KB layout it used to need cost a quarter of
+       the occupancy: 88 against 53 us) */
+    if (do_long)
         hipLaunchKernelGGL((k_side_long<DT, FAST, true>), grid, block, 0, st, T, in, flags, n_cf, mixed, peaks,
                            n_peaks, n_kept, sbr_mean, sbr_overall);
     if (do_short)

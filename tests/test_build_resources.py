@@ -30,8 +30,7 @@ HOT = [
     (r"^void k_mdct_long_v2<true>\(", 256, 2),           # batches with block-switching flags
     (r"^void k_mdct_long_v2<false>\(", 256, 2),
     (r"^void k_mdct_short<0, true>\(", 128, 3),
-    (r"^void k_side_long<0, true, true>\(", 168, 3),     # int16 fast path, compact LDS
-    (r"^void k_side_long<0, true, false>\(", 168, 3),    # ... SBR handles
+    (r"^void k_side_long<0, true, true>\(", 168, 3),     # int16 fast path, compact LDS (SBR handles too)
     (r"^void k_side_short<0, true>\(", 168, 3),
     (r"^void k_mask<1024, true>\(", 168, 3),            # mask + BitAlloc + quantise + pack, long frames
     (r"^void k_mask<1024, false>\(", 168, 3),
