@@ -403,9 +403,10 @@ def _decode_blocks_of(A, name, kbps, seen):
 
 
 def test_level_walk_equals_depth_first_walk(A, monkeypatch):
-    """k_vq codes a band's split tree depth first (vq_shape) or level by level (vq_shape_bfs, default from
-    112 shape bits; PACX_VQ_BFS selects): same bytes either way, at bit rates that give one-level trees,
-    deep trees and trees beyond the level walk's node store (which then falls back to the depth-first walk)."""
+    """Three coders for the split trees, same bytes: k_vq_frame (all bands of a block level by level, the
+    default; trees beyond its node store fall back to k_vq), k_vq walking a band level by level
+    (vq_shape_bfs, PACX_VQ_FRAME=0 PACX_VQ_BFS=1) and k_vq depth first (PACX_VQ_BFS=0) -- at bit rates that
+    give one-level trees, deep trees and trees beyond either node store."""
     rng = np.random.default_rng(11)
     t = np.arange(20 * 1024)
     tone = 0.4 * np.sin(2 * np.pi * 440 * t / 48000) + 0.2 * np.sin(2 * np.pi * 5200 * t / 48000)
@@ -413,11 +414,13 @@ def test_level_walk_equals_depth_first_walk(A, monkeypatch):
     pcm = np.clip(np.round(pcm * 20000), -32767, 32767).astype(np.int16)
     for kbps in (64, 128, 256, 448):
         outs = []
-        for mode in ("0", "1", None):
-            if mode is None:
+        for frame, bfs in (("1", None), ("0", "0"), ("0", "1"), ("0", None)):
+            monkeypatch.setenv("PACX_VQ_FRAME", frame)
+            if bfs is None:
                 monkeypatch.delenv("PACX_VQ_BFS", raising=False)
             else:
-                monkeypatch.setenv("PACX_VQ_BFS", mode)
+                monkeypatch.setenv("PACX_VQ_BFS", bfs)
             outs.append(A.pacfile.encode_stream(pcm, 48000, kbps, block_switching=True, use_vq=True,
                                                 use_sbr=kbps < 128))
-        assert outs[0] == outs[1] == outs[2], kbps
+        monkeypatch.delenv("PACX_VQ_FRAME", raising=False)
+        assert outs[0] == outs[1] == outs[2] == outs[3], kbps
