@@ -510,14 +510,19 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 {
     typedef typename PcmStage<DT>::elem E;
     const int SPAN = PACX_N_SHORT + (PACX_SUB - 1) * PACX_M_SHORT;
-    /* LDS: the FFT exchange tile, and one region that holds the raw samples and
-       then the intensities.  As in the long kernel the packed spectra never go to
-       LDS: sub-block g lives in lanes 8g..8g+7, lane r holds bins r + 8 k3, and
-       the partner bin 64 - k of the real-FFT split sits in lane 8g + (8-r)%8. */
+    /* LDS: ONE region that holds the raw samples, then the FFT exchange tile, then the
+       intensities -- the three follow one another in time (the samples are in registers before
+       the first exchange, the spectra are in registers before the first intensity is written;
+       the DS instructions of the one wave execute in order).  With a tile of its own the kernel
+       took 18 KB and eight waves fitted a CU; at 9.8 KB its registers are the limit (twelve).
+       As in the long kernel the packed spectra never go to LDS: sub-block g lives in lanes
+       8g..8g+7, lane r holds bins r + 8 k3, and the partner bin 64 - k of the real-FFT split
+       sits in lane 8g + (8-r)%8. */
     constexpr int RAW_BYTES = (int)sizeof(E) * SPAN;
-    constexpr int B_BYTES = RAW_BYTES > PACX_SUB * 130 * 8 ? RAW_BYTES : PACX_SUB * 130 * 8;
-    __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
+    constexpr int I_BYTES = RAW_BYTES > PACX_SUB * 130 * 8 ? RAW_BYTES : PACX_SUB * 130 * 8;
+    constexpr int B_BYTES = I_BYTES > (int)sizeof(cplx) * WFFT_TILE ? I_BYTES : (int)sizeof(cplx) * WFFT_TILE;
     __shared__ __attribute__((aligned(16))) char regB[B_BYTES];
+    cplx *tile = (cplx *)regB;
     __shared__ unsigned char pk_idx[PACX_SUB][64];
     __shared__ int pk_cnt[PACX_SUB];
     double *inten = (double *)regB;
@@ -546,6 +551,7 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
     __syncthreads();                  /* raw consumed: region B becomes inten */
     fft64x8(ev, tile, T.w512, lane);
     fft64x8(od, tile, T.w512, lane);
+    __syncthreads();                  /* the tile is done with: region B becomes inten */
     /* ev[k3] = E[k], od[k3] = O[k], k = r + 8 k3 (64-point spectra of the even / odd
        samples).  Z[k] = E[k] + W128^k O[k], Z[k+64] = E[k] - W128^k O[k]; bins k and
        k + 64 pair with Z[128-k] and Z[64-k], both made of E[m], O[m], m = 64 - k */
