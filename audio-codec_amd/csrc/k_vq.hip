@@ -1194,7 +1194,7 @@ struct VqArgs {
     pacx_vq_entry *log;
     int32_t *log_count;
     int log_cap;               /* entries per band                          */
-    int redo;                  /* 1: code only the units k_vq_frame left (n_bytes / unit_bits = -1) */
+    int redo;                  /* 1: code only the channel-frames k_vq_frame left (n_bytes = -1) */
     int bfs;                   /* shape bits from which a band's tree is walked level by level (vq_shape_bfs); 0: never */
 };
 
@@ -1247,8 +1247,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
         if (st & PACX_ST_ZERO_SUBBLOCK)
             return;
     }
-    if (A.redo && (is_short ? A.unit_bits[unit * 2] : A.n_bytes[cf]) != -1)
-        return;                                /* k_vq_frame coded this unit */
+    if (A.redo && A.n_bytes[cf] != -1)
+        return;                                /* k_vq_frame coded this channel-frame */
     const int nb = is_short ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = is_short ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = is_short ? T.band_lines_short : T.band_lines_long;
@@ -1451,9 +1451,11 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
  *   top-down (depth-first order inside a band, bands at their static positions), every field is
  *   ORed in by its own lane, and the gains of all bands are quantised side by side.
  * Arithmetic per node is that of vq_shape / vq_leaf / vq_leaf_group.  A unit whose trees do not fit
- * the store (bit rates far above the shipped ones) is left to k_vq: n_bytes / unit_bits = -1. */
+ * the store (bit rates far above the shipped ones) is left to k_vq (and k_vq_join): n_bytes = -1.
+ * A short-coded frame is ONE unit too: its 8 x nb_short bands are the unit's bands, its eight strings are
+ * written back to back by the same workgroup (no per-sub-block launch geometry, no join pass). */
 #ifndef VQF_NCAP
-#define VQF_NCAP 320                   /* nodes per (sub-)block.  With the 1088-double level buffers and the small
+#define VQF_NCAP 272                   /* nodes per (sub-)block.  With the 1088-double level buffers and the small
                                           row-offset table that is 31 KB of LDS: five workgroups per CU (448 nodes: four,
                                           571 against 487 us on one box; a sixth, at 80 VGPRs with three spilled,
                                           gave nothing: 494 us) */
@@ -1462,7 +1464,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
 #ifndef VQF_BUF
 #define VQF_BUF (PACX_M_LONG + 64)     /* doubles per level buffer */
 #endif
-#define VQF_FIXED 3072                 /* words, gains, allocations, starts, ticket, gain bits, roots, counters */
+#define VQF_VB 64                      /* bands of a unit: a long block's, or the 8 x nb_short of a short frame */
+#define VQF_FIXED 4160                 /* words, gains, allocations, starts, ticket, gain bits, roots, counters */
 #define VQF_SMEM (VQF_FIXED + 2 * VQF_BUF * 8 + VQF_NCAP * 8 + 6 * VQF_NCAP * 2 + 4 * VQF_NCAP + 2 * VQF_NLV * 2 + 128 + 64)
 
 struct VqfStore {
@@ -1542,50 +1545,49 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *words = (unsigned *)smem;                               /* VQ_WORDS        */
-    double *gain_s = (double *)(smem + VQ_WORDS * 4);                 /* 32              */
-    int *ba_s = (int *)(gain_s + PACX_MAX_BANDS);                     /* 32              */
-    int *start_s = ba_s + PACX_MAX_BANDS;                             /* 33              */
-    int *misc = start_s + PACX_MAX_BANDS + 1;                         /* node count, overflow, spare, two pass tickets, 2 spare */
-    int *bg_s = misc + 7;                                             /* 32 gain bits before the shape's slack */
-    unsigned short *root_s = (unsigned short *)(bg_s + PACX_MAX_BANDS);   /* 32 root node of a band, 0xFFFF none */
-    int *bs_s = (int *)(root_s + PACX_MAX_BANDS);                     /* 32 shape bits  (16 spare ints follow) */
+    /* a short-coded frame is ONE unit: its 8 x nb_short bands are the unit's (virtual) bands, band
+       vb = 8 j + ... = j nb + b of sub-block j -- at most VQF_VB of them */
+    double *gain_s = (double *)(smem + VQ_WORDS * 4);                 /* VB              */
+    int *ba_s = (int *)(gain_s + VQF_VB);                             /* VB              */
+    int *start_s = ba_s + VQF_VB;                                     /* VB: first stream bit of the band's fields */
+    int *end_s = start_s + VQF_VB;                                    /* VB: where they must end */
+    int *misc = end_s + VQF_VB;                                       /* node count, overflow, total bits, 5 spare */
+    int *bg_s = misc + 8;                                             /* VB gain bits before the shape's slack */
+    int *bs_s = bg_s + VQF_VB;                                        /* VB shape bits */
+    unsigned short *root_s = (unsigned short *)(bs_s + VQF_VB);       /* VB root node of a band, 0xFFFF none */
     double *buf0 = (double *)(smem + VQF_FIXED);                      /* two level buffers of VQF_BUF doubles */
     VqfStore N;
     N.bind(smem + VQF_FIXED + 2 * VQF_BUF * 8);
-    static_assert(VQ_WORDS * 4 + PACX_MAX_BANDS * 8 + PACX_MAX_BANDS * 4 + (PACX_MAX_BANDS + 1) * 4 + 7 * 4 +
-                  PACX_MAX_BANDS * 4 + PACX_MAX_BANDS * 2 + PACX_MAX_BANDS * 4 <= VQF_FIXED && VQF_FIXED % 16 == 0,
+    static_assert(VQ_WORDS * 4 + VQF_VB * 8 + 5 * VQF_VB * 4 + 8 * 4 + VQF_VB * 2 <= VQF_FIXED && VQF_FIXED % 16 == 0,
                   "fixed part of k_vq_frame's LDS");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned long long below = (1ull << lane) - 1ull;
-    const long long unit = blockIdx.x;
-    const long long cf = A.mixed ? unit / PACX_SUB : unit;
-    const int sb = A.mixed ? (int)(unit % PACX_SUB) : 0;
+    const long long cf = blockIdx.x;
     if (cf >= A.n_cf)
         return;
     const long long frame = cf / A.n_ch;
     const unsigned fl = A.flags ? A.flags[frame] : 0u;
     const bool is_short = A.mixed && (fl & 2u);
-    if (!is_short && sb != 0)
-        return;
-    if (is_short && A.status_in) {             /* hop dropped: nothing to code */
+    if (is_short && A.status_in) {             /* hop dropped: nothing to code (n_bytes stays 0) */
         unsigned st = 0;
         for (int c = 0; c < A.n_ch; ++c)
             st |= A.status_in[frame * A.n_ch + c];
         if (st & PACX_ST_ZERO_SUBBLOCK)
             return;
     }
-    const int nb = is_short ? T.nb_short : T.nb_long;
+    const int nb = is_short ? T.nb_short : T.nb_long;                /* bands per (sub-)block */
+    const int n_sub = is_short ? PACX_SUB : 1;
+    const int n_vb = n_sub * nb;                                      /* the unit's bands (<= VQF_VB, the launcher checks) */
     const int32_t *__restrict__ lower = is_short ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = is_short ? T.band_lines_short : T.band_lines_long;
     const int first_omit = (!is_short && T.use_sbr) ? T.first_omitted : nb;
-    const long long boff = cf * T.band_stride + (is_short ? sb * T.nb_short : 0);
-    const double *__restrict__ lin = A.lines + cf * PACX_M_LONG + (is_short ? sb * PACX_M_SHORT : 0);
-    const int ov = A.overall[cf * PACX_SUB + sb];
-    const double up = (double)(1 << ov);
-    const int lead = is_short ? 0 : 3;
+    const long long boff = cf * T.band_stride;
+    const double *__restrict__ lin = A.lines + cf * PACX_M_LONG;
     const double half_pi = 1.5707963267948966;
+    /* band vb = j nb + b */
+    auto sub_of = [&](int vb) { return is_short ? vb / nb : 0; };
 
     for (int i = tid; i < VQ_WORDS; i += 64 * VQ_WAVES)
         words[i] = 0u;
@@ -1603,22 +1605,26 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
     /* phase A: gains; the unit shapes x / gain are level 0 of the walk (bufs[0], at the band's lines) */
     double *xs = buf0;
     {
-        /* the unit's lines, scaled, in one coalesced sweep: the bands' norms then read LDS, not memory */
-        const int n_lines = is_short ? PACX_M_SHORT : PACX_M_LONG;
-        for (int i = 2 * tid; i < n_lines; i += 2 * 64 * VQ_WAVES) {
+        /* the unit's lines, scaled (a short frame: each sub-block by its own overall scale), in one
+           coalesced sweep: the bands' norms then read LDS, not memory */
+        for (int i = 2 * tid; i < PACX_M_LONG; i += 2 * 64 * VQ_WAVES) {
+            const int ov = A.overall[cf * PACX_SUB + (is_short ? i / PACX_M_SHORT : 0)];
+            const double up = (double)(1 << ov);
             const double2 v = *(const double2 *)(lin + i);
             xs[i] = v.x * up;
             xs[i + 1] = v.y * up;
         }
     }
     __syncthreads();
-    for (int b = wave; b < nb; b += VQ_WAVES) {
+    for (int vb = wave; vb < n_vb; vb += VQ_WAVES) {
+        const int j = sub_of(vb), b = vb - j * nb;
         double g;
         if (b >= first_omit) {
+            const double up = (double)(1 << A.overall[cf * PACX_SUB]);
             const double v = A.sbr_mean[cf * PACX_SUB + (b - first_omit)] * up;
             g = sqrt(v * v);
         } else {
-            const int lo = ldc(&lower[b]), cnt = ldc(&count[b]);
+            const int lo = j * PACX_M_SHORT + ldc(&lower[b]), cnt = ldc(&count[b]);
             double acc = 0.0;
             for (int i = lane; i < cnt; i += 64) {
                 const double x = xs[lo + i];
@@ -1629,67 +1635,69 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 xs[lo + i] = xs[lo + i] / g;
         }
         if (lane == 0)
-            gain_s[b] = g;
+            gain_s[vb] = g;
     }
     __syncthreads();
     if (tid < 64) {
-        /* final allocations, band positions, header fields, the roots of the trees */
+        /* final allocations, band positions, header fields, the roots of the trees: one band per lane.
+           The stream: 3 flag bits, then per (sub-)block its head (overall scale, nb allocation fields)
+           and the fields of its bands back to back (coder/pacfile.py:552-592; eight of those for a short
+           frame): band vb starts at 3 + (j + 1) head + the bits of all bands before it */
+        const int vb = lane, j = sub_of(vb < n_vb ? vb : 0), b = vb - j * nb;
         int ba = 0, r_bits = 0, cnt = 1;
-        if (lane < nb) {
-            ba = A.bit_alloc[boff + lane];
-            if (ba && gain_s[lane] == 0.0)
+        if (vb < n_vb) {
+            ba = A.bit_alloc[boff + vb];
+            if (ba && gain_s[vb] == 0.0)
                 ba = 0;                                   /* coder/codec.py:352-353 */
-            cnt = (lane >= first_omit) ? 1 : count[lane];
+            cnt = (b >= first_omit) ? 1 : count[b];
             r_bits = ba * cnt;
-            A.bit_alloc[boff + lane] = ba;
-            ba_s[lane] = ba;
+            A.bit_alloc[boff + vb] = ba;
+            ba_s[vb] = ba;
         }
-        int incl = r_bits;
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const int t = __shfl_up(incl, off, 64);
-            if (lane >= off)
-                incl += t;
+        int total_bits;
+        const int before = wave_excl_scan_i32(r_bits, lane, total_bits);
+        const int head = T.n_scale_bits + T.n_mant_size_bits * nb;
+        const int start = 3 + (j + 1) * head + before;
+        if (vb < n_vb) {
+            start_s[vb] = start;
+            end_s[vb] = start + r_bits;
         }
-        const int head = lead + T.n_scale_bits + T.n_mant_size_bits * nb;
-        if (lane < nb)
-            start_s[lane] = head + incl - r_bits;
-        if (lane == nb - 1)
-            start_s[nb] = head + incl;
         if (lane == 0) {
-            if (!is_short) {
-                vq_put32(words, 0, fl & 1u, 1);
-                vq_put32(words, 1, (fl >> 1) & 1u, 1);
-                vq_put32(words, 2, (fl >> 2) & 1u, 1);
-            }
-            vq_put32(words, lead, (unsigned)ov, T.n_scale_bits);
+            vq_put32(words, 0, fl & 1u, 1);
+            vq_put32(words, 1, (fl >> 1) & 1u, 1);
+            vq_put32(words, 2, (fl >> 2) & 1u, 1);
+            misc[2] = 3 + n_sub * head + total_bits;      /* bits written */
         }
-        if (lane < nb)
-            vq_put32(words, lead + T.n_scale_bits + T.n_mant_size_bits * lane, (unsigned)(ba ? ba - 1 : 0),
+        if (vb < n_vb) {
+            const int sub_base = 3 + j * head + __shfl(before, vb - b, 64);
+            if (b == 0)
+                vq_put32(words, sub_base, (unsigned)A.overall[cf * PACX_SUB + j], T.n_scale_bits);
+            vq_put32(words, sub_base + T.n_scale_bits + T.n_mant_size_bits * b, (unsigned)(ba ? ba - 1 : 0),
                      T.n_mant_size_bits);
+        }
         /* gain_shape_alloc of the band; an omitted band is one number: every bit to its gain */
         int bits_gain = ba, bits_shape = 0;
-        if (lane < nb && lane < first_omit && ba) {
+        if (vb < n_vb && b < first_omit && ba) {
             bits_gain = (int)floor((double)r_bits / (double)cnt + V.half_log2[cnt]);
             bits_shape = r_bits - bits_gain;
             if (bits_shape < 0)
                 bits_shape = 0;
         }
-        const bool rooted = lane < nb && bits_shape != 0;
+        const bool rooted = vb < n_vb && bits_shape != 0;
         const unsigned long long mr = __builtin_amdgcn_ballot_w64(rooted);
         const int id = __popcll(mr & below);
-        if (lane < nb) {
-            bg_s[lane] = bits_gain;
-            bs_s[lane] = bits_shape;
-            root_s[lane] = rooted ? (unsigned short)id : 0xFFFF;
+        if (vb < n_vb) {
+            bg_s[vb] = bits_gain;
+            bs_s[vb] = bits_shape;
+            root_s[vb] = rooted ? (unsigned short)id : 0xFFFF;
         }
         if (rooted) {
             N.nn[id] = (unsigned short)cnt;
             N.bb[id] = (unsigned short)bits_shape;
-            N.off[id] = (unsigned short)lower[lane];
+            N.off[id] = (unsigned short)(j * PACX_M_SHORT + lower[b]);
             N.kind[id] = bits_shape > PACX_VQ_SPLIT_BITS ? 0 : 1;
             N.wid[id] = 0;
-            N.band[id] = (unsigned char)lane;
+            N.band[id] = (unsigned char)vb;
             N.has[id] = 0;
             N.kid[id] = 0;
             N.val[id] = 0ull;
@@ -2110,13 +2118,9 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         }
     }
     if (misc[1]) {
-        /* does not fit the store: k_vq codes this unit */
-        if (tid == 0) {
-            if (!is_short)
-                A.n_bytes[cf] = -1;
-            else
-                A.unit_bits[unit * 2] = -1;
-        }
+        /* does not fit the store: k_vq (and, for a short frame, k_vq_join) code this channel-frame */
+        if (tid == 0)
+            A.n_bytes[cf] = -1;
         return;
     }
     const int n_nodes = misc[0];
@@ -2136,7 +2140,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         }
         __syncthreads();
     }
-    if (tid < nb && root_s[tid] != 0xFFFF) {
+    if (tid < n_vb && root_s[tid] != 0xFFFF) {
         N.pos[root_s[tid]] = (unsigned short)start_s[tid];
         N.off[root_s[tid]] = 0;
     }
@@ -2170,29 +2174,30 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         if (w > 0)
             vq_put_field(words, N.pos[j], v, w);
         if (A.log && N.kind[j] != 3 && N.off[j] < A.log_cap) {
-            const long long slot = (cf * PACX_SUB + sb) * PACX_MAX_BANDS + N.band[j];
+            const int vb = N.band[j], sj = sub_of(vb);
+            const long long slot = (cf * PACX_SUB + sj) * PACX_MAX_BANDS + (vb - sj * nb);
             pacx_vq_entry e;
             e.value = v;
             e.width = w;
-            e.band = N.band[j];
+            e.band = vb - sj * nb;
             A.log[slot * A.log_cap + N.off[j]] = e;
         }
     }
     /* ---- the gains of all bands side by side (mu-law, QuantizeUniform; the index soaks up the slack) */
     if (tid < 64) {
-        const int b = lane;
-        const int ba = (b < nb) ? ba_s[b] : 0;
-        const long long slot = (cf * PACX_SUB + sb) * PACX_MAX_BANDS + b;
-        if (b < nb && !ba && A.log_count)
+        const int vb = lane, sj = sub_of(vb < n_vb ? vb : 0), b = vb - sj * nb;
+        const int ba = (vb < n_vb) ? ba_s[vb] : 0;
+        const long long slot = (cf * PACX_SUB + sj) * PACX_MAX_BANDS + b;
+        if (vb < n_vb && !ba && A.log_count)
             A.log_count[slot] = 0;
-        const int cnt = (b < nb && b < first_omit) ? count[b] : 1;
-        const double gain = (b < nb) ? gain_s[b] : 0.0;
+        const int cnt = (vb < n_vb && b < first_omit) ? count[b] : 1;
+        const double gain = (vb < n_vb) ? gain_s[vb] : 0.0;
         const double g = vq_log(1.0 + 255.0 * fabs(gain / (double)cnt)) / V.log_mu1;
         if (ba) {
-            const int rt = root_s[b];
+            const int rt = root_s[vb];
             const int used = (rt != 0xFFFF) ? N.tot[rt] : 0;
             const int fields = (rt != 0xFFFF) ? N.nn[rt] : 0;
-            int bits_gain = bg_s[b] + bs_s[b] - used;
+            int bits_gain = bg_s[vb] + bs_s[vb] - used;
             if (bits_gain < 0)
                 bits_gain = 0;
             int width = bits_gain;
@@ -2203,14 +2208,14 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             } else if (bits_gain > 0) {
                 vq_quantize_code(g, bits_gain, hi, lo);
             }
-            const int at = start_s[b] + used;
+            const int at = start_s[vb] + used;
             if (width > 64) {
                 vq_put_field(words, at, hi, width - 64);
                 vq_put_field(words, at + width - 64, lo, 64);
             } else if (width > 0) {
                 vq_put_field(words, at, lo, width);
             }
-            if (at + width != start_s[b + 1])
+            if (at + width != end_s[vb])
                 undefined = true;                          /* a band must fill its slot exactly */
             if (A.log && fields < A.log_cap) {
                 pacx_vq_entry e;
@@ -2228,28 +2233,16 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
     __syncthreads();
 
     VQF_T(5);
-    /* hand the string over */
-    const int written = start_s[nb];                       /* includes `lead` */
-    int size_rule = T.n_scale_bits;                        /* getNumBytesNeeded */
-    for (int b = 0; b < nb; ++b)
-        size_rule += T.n_mant_size_bits + T.n_scale_bits;
-    size_rule += written - (lead + T.n_scale_bits + T.n_mant_size_bits * nb);
-    if (!is_short) {
-        const int nbytes = (size_rule + 4 + 7) >> 3;
-        unsigned *dst = (unsigned *)(A.payload + cf * (long long)A.payload_stride);
-        for (int i = tid; i < (nbytes + 3) / 4; i += 64 * VQ_WAVES)
-            dst[i] = __builtin_bswap32(words[i]);
-        if (tid == 0)
-            A.n_bytes[cf] = nbytes;
-    } else {
-        unsigned *dst = A.unit_words + unit * VQ_WORDS;
-        for (int i = tid; i < (written + 31) / 32; i += 64 * VQ_WAVES)
-            dst[i] = words[i];
-        if (tid == 0) {
-            A.unit_bits[unit * 2] = written;
-            A.unit_bits[unit * 2 + 1] = size_rule;
-        }
-    }
+    /* hand the string over.  getNumBytesNeeded (coder/pacfile.py:342-361) also charges a scale factor per band
+       that the gain-shape writer does not send */
+    const int written = misc[2];                           /* with the 3 flag bits */
+    const int size_rule = written - 3 + n_sub * nb * T.n_scale_bits;
+    const int nbytes = (size_rule + 4 + 7) >> 3;
+    unsigned *dst = (unsigned *)(A.payload + cf * (long long)A.payload_stride);
+    for (int i = tid; i < (nbytes + 3) / 4; i += 64 * VQ_WAVES)
+        dst[i] = __builtin_bswap32(words[i]);
+    if (tid == 0)
+        A.n_bytes[cf] = nbytes;
     VQF_T(6);
 }
 
@@ -2259,7 +2252,7 @@ __global__ __launch_bounds__(64) void k_vq_join(PacxTables T, const uint8_t *__r
                                                const unsigned *__restrict__ unit_words,
                                                const int32_t *__restrict__ unit_bits,
                                                uint8_t *__restrict__ payload, int payload_stride,
-                                               int32_t *__restrict__ n_bytes)
+                                               int32_t *__restrict__ n_bytes, int redo)
 {
     __shared__ unsigned words[VQ_WORDS];
     const int lane = threadIdx.x;
@@ -2270,6 +2263,8 @@ __global__ __launch_bounds__(64) void k_vq_join(PacxTables T, const uint8_t *__r
     const unsigned fl = flags[frame];
     if (!(fl & 2u))
         return;
+    if (redo && n_bytes[cf] != -1)
+        return;                                /* k_vq_frame wrote this frame's string itself */
     unsigned st = 0;
     if (status)
         for (int c = 0; c < n_ch; ++c)
@@ -2352,12 +2347,14 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
     /* the frame-level walk first; k_vq then takes the units it left (PACX_VQ_FRAME=0: k_vq alone) */
     const char *fe = getenv("PACX_VQ_FRAME");
     A.redo = (fe && atoi(fe) == 0) ? 0 : 1;
-    if (A.redo)
-        hipLaunchKernelGGL(k_vq_frame, dim3((unsigned)units), dim3(64 * VQ_WAVES), (size_t)VQF_SMEM, st, T, V, A);
+    if (PACX_SUB * T.nb_short > VQF_VB || T.nb_long > VQF_VB)
+        A.redo = 0;                             /* more bands than k_vq_frame's per-band arrays hold */
+    if (A.redo)                                 /* one workgroup per channel-frame, long or short */
+        hipLaunchKernelGGL(k_vq_frame, dim3((unsigned)n_cf), dim3(64 * VQ_WAVES), (size_t)VQF_SMEM, st, T, V, A);
     hipLaunchKernelGGL(k_vq, dim3((unsigned)units), dim3(64 * VQ_WAVES), smem, st, T, V, A);
     if (A.mixed)
         hipLaunchKernelGGL(k_vq_join, dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch, n_cf, status,
-                           unit_words, unit_bits, payload, payload_stride, n_bytes);
+                           unit_words, unit_bits, payload, payload_stride, n_bytes, A.redo);
 }
 
 size_t pacx_vq_view_size(void) { return sizeof(VqView); }
