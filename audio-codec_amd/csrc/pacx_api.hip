@@ -1038,36 +1038,70 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
     /* every long-coded frame gets its n_bytes from the coder; only dropped short hops keep the zero */
     if (mixed)
         HIP_TRY(h, hipMemsetAsync(n_bytes, 0, (size_t)n_cf * sizeof(int32_t), st));
-    if (mixed)
-        pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,
-                                h->ws_lists + 2 * n_cf, st);
-    if (fast) {
-        pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
-                            h->n_cu, mixed ? h->ws_lists : nullptr, mixed ? h->ws_lists + 2 * n_cf : nullptr, st);
-        if (mixed)
-            pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale,
-                             PACX_SUB, status, st);
-    } else {
-        pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
-                         PACX_SUB, status, st);
-    }
-    /* the side chain follows the MDCT on the same stream: with SBR it folds max|FFT| into the overall scale
-       the MDCT wrote, and without SBR a fork to a second stream costs more than it hides here (0.677 against
-       0.661 ms per step, A/B on one box) */
-    pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
-                     T.use_sbr ? h->ws_sbr_mean : nullptr, T.use_sbr ? overall_scale : nullptr, st);
     MaskTail mt;
     memset(&mt, 0, sizeof(mt));
     mt.bit_alloc = bit_alloc;
     mt.status = status;
-    /* BitAlloc of the long frames inside the mask kernel or in k_bitalloc behind it: as with the scalar
-       coder's tail, all-long batches are a little faster unfused (0.637 against 0.642 ms per step, A/B on one
-       box); PACX_VQ_FUSE_ALLOC=0/1 forces either */
-    const char *vf_env = getenv("PACX_VQ_FUSE_ALLOC");
-    const int vq_fuse = vf_env ? (atoi(vf_env) != 0) : mixed;
-    pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
-                     nullptr, h->n_cu, h->ws_lists, h->ws_lists + n_cf, h->ws_lists + 2 * n_cf, vq_fuse ? &mt : nullptr, st);
-    pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, vq_fuse, h->ws_smr, bit_alloc, status, st);
+    const char *split_env = getenv("PACX_SPLIT_SHORT");       /* 0: short frames on the long frames' stream */
+    if (mixed && fast && !(split_env && atoi(split_env) == 0)) {
+        /* a block-switched batch: the long-coded and the short-coded frames are two independent chains up
+           to the gain-shape coder (which takes all frames), as in the scalar entry point:
+             long :  k_mdct_long_v2 -> k_side_long (folds max|FFT| into the overall scale of SBR blocks) ->
+                     k_mask<1024> with BitAlloc
+             short:  k_mdct_short -> k_side_short -> k_mask<128> -> k_bitalloc
+           side by side on two streams; the side chains and the short MDCT go by the flags alone and start
+           while the frame lists are made */
+        int32_t *const list_long = h->ws_lists, *const list_short = h->ws_lists + n_cf, *const counts = h->ws_lists + 2 * n_cf;
+        HIP_TRY(h, hipEventRecord(h->ev_fork, st));
+        HIP_TRY(h, hipStreamWaitEvent(h->short_stream, h->ev_fork, 0));
+        pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, list_long, list_short, counts, st);
+        HIP_TRY(h, hipEventRecord(h->ev_lists, st));
+        /* short chain */
+        pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale, PACX_SUB, status,
+                         h->short_stream);
+        pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_npeaks,
+                         h->ws_nkept, nullptr, nullptr, h->short_stream);
+        HIP_TRY(h, hipStreamWaitEvent(h->short_stream, h->ev_lists, 0));
+        pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_nkept, h->ws_lines,
+                         h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, nullptr, h->short_stream);
+        pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, 1, h->ws_smr, bit_alloc, status, h->short_stream);
+        HIP_TRY(h, hipEventRecord(h->ev_short_done, h->short_stream));
+        /* long chain */
+        pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status, h->n_cu,
+                            list_long, counts, st);
+        pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed | PACX_PART_LONG, h->ws_peaks, h->ws_npeaks,
+                         h->ws_nkept, T.use_sbr ? h->ws_sbr_mean : nullptr, T.use_sbr ? overall_scale : nullptr, st);
+        pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_LONG, h->ws_peaks, h->ws_nkept, h->ws_lines,
+                         h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, &mt, st);
+        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_short_done, 0));       /* both chains done */
+    } else {
+        if (mixed)
+            pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,
+                                    h->ws_lists + 2 * n_cf, st);
+        if (fast) {
+            pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
+                                h->n_cu, mixed ? h->ws_lists : nullptr, mixed ? h->ws_lists + 2 * n_cf : nullptr, st);
+            if (mixed)
+                pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale,
+                                 PACX_SUB, status, st);
+        } else {
+            pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
+                             PACX_SUB, status, st);
+        }
+        /* the side chain follows the MDCT on the same stream: with SBR it folds max|FFT| into the overall scale
+           the MDCT wrote, and without SBR a fork to a second stream costs more than it hides here (0.677 against
+           0.661 ms per step, A/B on one box) */
+        pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
+                         T.use_sbr ? h->ws_sbr_mean : nullptr, T.use_sbr ? overall_scale : nullptr, st);
+        /* BitAlloc of the long frames inside the mask kernel or in k_bitalloc behind it: as with the scalar
+           coder's tail, all-long batches are a little faster unfused (0.637 against 0.642 ms per step, A/B on one
+           box); PACX_VQ_FUSE_ALLOC=0/1 forces either */
+        const char *vf_env = getenv("PACX_VQ_FUSE_ALLOC");
+        const int vq_fuse = vf_env ? (atoi(vf_env) != 0) : mixed;
+        pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
+                         nullptr, h->n_cu, h->ws_lists, h->ws_lists + n_cf, h->ws_lists + 2 * n_cf, vq_fuse ? &mt : nullptr, st);
+        pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, vq_fuse, h->ws_smr, bit_alloc, status, st);
+    }
     pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
                    h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
                    h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, st);
