@@ -1211,7 +1211,8 @@ extern "C" int pacx_debug_read_vq(long long *out, int n)
 #define VQ_T(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqView V, VqArgs A)
+/* one (sub-)block: the body of k_vq (one workgroup per unit) and of k_vq_redo (the units k_vq_frame left) */
+__device__ __forceinline__ void vq_unit_body(const PacxTables &T, const VqView &V, const VqArgs &A, const long long unit)
 {
 #ifdef PACX_VQ_DEBUG
     long long vq_last = 0;
@@ -1230,7 +1231,6 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          /* uniform: the per-wave LDS pointers stay scalar */
     VqNodes N;
     N.bind((unsigned char *)(scr_all + V.scr_off[VQ_WAVES]) + wave * VQ_NODE_BYTES);
-    const long long unit = blockIdx.x;
     const long long cf = A.mixed ? unit / PACX_SUB : unit;
     const int sb = A.mixed ? (int)(unit % PACX_SUB) : 0;
     if (cf >= A.n_cf)
@@ -1433,6 +1433,28 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqVi
         }
     }
     VQ_T(5);
+}
+
+__global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq(PacxTables T, VqView V, VqArgs A)
+{
+    vq_unit_body(T, V, A, blockIdx.x);
+}
+
+/* behind k_vq_frame: the channel-frames it flagged (n_bytes = -1), their 1 or 8 units one after the other.
+   A grid-stride walk over the frames: a launch of one workgroup per unit, nearly all of which have nothing
+   to do, cost 49 us on a block-switched batch (65 536 workgroups) */
+__global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq_redo(PacxTables T, VqView V, VqArgs A)
+{
+    for (long long cf = blockIdx.x; cf < A.n_cf; cf += gridDim.x) {
+        if (A.n_bytes[cf] != -1)
+            continue;
+        const unsigned fl = A.flags ? A.flags[cf / A.n_ch] : 0u;
+        const int n_sub = (A.mixed && (fl & 2u)) ? PACX_SUB : 1;
+        for (int sb = 0; sb < n_sub; ++sb) {
+            __syncthreads();                               /* the previous unit's LDS is done with */
+            vq_unit_body(T, V, A, A.mixed ? cf * PACX_SUB + sb : cf);
+        }
+    }
 }
 
 /* ------------------------------------------------ frame-level walk (k_vq_frame) */
@@ -2351,7 +2373,10 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
         A.redo = 0;                             /* more bands than k_vq_frame's per-band arrays hold */
     if (A.redo)                                 /* one workgroup per channel-frame, long or short */
         hipLaunchKernelGGL(k_vq_frame, dim3((unsigned)n_cf), dim3(64 * VQ_WAVES), (size_t)VQF_SMEM, st, T, V, A);
-    hipLaunchKernelGGL(k_vq, dim3((unsigned)units), dim3(64 * VQ_WAVES), smem, st, T, V, A);
+    if (A.redo)
+        hipLaunchKernelGGL(k_vq_redo, dim3((unsigned)(n_cf < 1024 ? n_cf : 1024)), dim3(64 * VQ_WAVES), smem, st, T, V, A);
+    else
+        hipLaunchKernelGGL(k_vq, dim3((unsigned)units), dim3(64 * VQ_WAVES), smem, st, T, V, A);
     if (A.mixed)
         hipLaunchKernelGGL(k_vq_join, dim3((unsigned)n_cf), dim3(64), 0, st, T, flags, n_ch, n_cf, status,
                            unit_words, unit_bits, payload, payload_stride, n_bytes, A.redo);
