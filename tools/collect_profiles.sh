@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for w in scalar128 vq128 vq96 bs128; do
+for w in scalar128 vq128 vq96 bs128 shipped128 shipped96; do
   python3 $R/bench.py --workload $w > $OUT/bench_$w.log 2>&1
   tail -1 $OUT/bench_$w.log > $OUT/bench_$w.json
   rocprofv3 --kernel-trace --stats -d $OUT/stats_$w -o s --output-format csv -- python3 $R/bench.py --workload $w --no-cpu-baseline --no-verify > /dev/null 2>&1
