@@ -1195,6 +1195,8 @@ struct VqArgs {
     int32_t *log_count;
     int log_cap;               /* entries per band                          */
     int redo;                  /* 1: code only the channel-frames k_vq_frame left (n_bytes = -1) */
+    const int32_t *cf_list;    /* k_vq_frame: the channel-frames of this launch (NULL: all n_cf) ... */
+    const int32_t *cf_count;   /* ... and how many (device side) */
     int bfs;                   /* shape bits from which a band's tree is walked level by level (vq_shape_bfs); 0: never */
 };
 
@@ -1586,7 +1588,12 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned long long below = (1ull << lane) - 1ull;
-    const long long cf = blockIdx.x;
+    long long cf = blockIdx.x;
+    if (A.cf_list) {                           /* a launch over one of the frame lists of a block-switched batch */
+        if (cf >= (long long)*A.cf_count)
+            return;
+        cf = A.cf_list[cf];
+    }
     if (cf >= A.n_cf)
         return;
     const long long frame = cf / A.n_ch;
@@ -2330,12 +2337,17 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
                     const double *lines, const int32_t *overall, int32_t *bit_alloc, const double *sbr_mean,
                     uint32_t *status, uint8_t *payload, int payload_stride, int32_t *n_bytes,
                     unsigned *unit_words, int32_t *unit_bits, pacx_vq_entry *log, int32_t *log_count,
-                    int log_cap, hipStream_t st)
+                    int log_cap, int stage, const int32_t *cf_list, const int32_t *cf_count, hipStream_t st)
 {
+    /* stage 0: everything.  1: only k_vq_frame, over cf_list (a block-switched batch codes its long and its
+       short frames behind their own front-end chains, on two streams).  2: what follows it (the frames it
+       left, the join pass of the old coder) */
     if (n_cf <= 0)
         return;
     const VqView &V = *(const VqView *)vq_view;
     VqArgs A;
+    A.cf_list = cf_list;
+    A.cf_count = cf_count;
     A.flags = flags;
     A.n_ch = n_ch;
     A.n_cf = n_cf;
@@ -2371,8 +2383,10 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
     A.redo = (fe && atoi(fe) == 0) ? 0 : 1;
     if (PACX_SUB * T.nb_short > VQF_VB || T.nb_long > VQF_VB)
         A.redo = 0;                             /* more bands than k_vq_frame's per-band arrays hold */
-    if (A.redo)                                 /* one workgroup per channel-frame, long or short */
+    if (A.redo && stage != 2)                   /* one workgroup per channel-frame, long or short */
         hipLaunchKernelGGL(k_vq_frame, dim3((unsigned)n_cf), dim3(64 * VQ_WAVES), (size_t)VQF_SMEM, st, T, V, A);
+    if (stage == 1)
+        return;
     if (A.redo)
         hipLaunchKernelGGL(k_vq_redo, dim3((unsigned)(n_cf < 1024 ? n_cf : 1024)), dim3(64 * VQ_WAVES), smem, st, T, V, A);
     else

@@ -90,7 +90,7 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
                     const double *lines, const int32_t *overall, int32_t *bit_alloc, const double *sbr_mean,
                     uint32_t *status, uint8_t *payload, int payload_stride, int32_t *n_bytes,
                     unsigned *unit_words, int32_t *unit_bits, pacx_vq_entry *log, int32_t *log_count,
-                    int log_cap, hipStream_t st);
+                    int log_cap, int stage, const int32_t *cf_list, const int32_t *cf_count, hipStream_t st);
 size_t pacx_vq_view_size(void);
 void pacx_vq_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
                        const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
@@ -1042,6 +1042,7 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
     memset(&mt, 0, sizeof(mt));
     mt.bit_alloc = bit_alloc;
     mt.status = status;
+    int vq_stage = 0;
     const char *split_env = getenv("PACX_SPLIT_SHORT");       /* 0: short frames on the long frames' stream */
     if (mixed && fast && !(split_env && atoi(split_env) == 0)) {
         /* a block-switched batch: the long-coded and the short-coded frames are two independent chains up
@@ -1065,6 +1066,11 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
         pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_nkept, h->ws_lines,
                          h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, nullptr, h->short_stream);
         pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, 1, h->ws_smr, bit_alloc, status, h->short_stream);
+        /* each chain goes on into the gain-shape coder with its own frames */
+        pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
+                       h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
+                       h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, 1, list_short, counts + 1,
+                       h->short_stream);
         HIP_TRY(h, hipEventRecord(h->ev_short_done, h->short_stream));
         /* long chain */
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status, h->n_cu,
@@ -1073,7 +1079,11 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
                          h->ws_nkept, T.use_sbr ? h->ws_sbr_mean : nullptr, T.use_sbr ? overall_scale : nullptr, st);
         pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_LONG, h->ws_peaks, h->ws_nkept, h->ws_lines,
                          h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, &mt, st);
+        pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
+                       h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
+                       h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, 1, list_long, counts, st);
         HIP_TRY(h, hipStreamWaitEvent(st, h->ev_short_done, 0));       /* both chains done */
+        vq_stage = 2;
     } else {
         if (mixed)
             pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,
@@ -1104,7 +1114,7 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
     }
     pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
                    h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
-                   h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, st);
+                   h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, vq_stage, nullptr, nullptr, st);
     return post_launch(h, "pacx_encode_vq_batch");
 }
 
