@@ -118,15 +118,22 @@ def cpu_baseline(vq_kbps=None, frames_per_core=None):
     return out
 
 
-def cpu_baseline_bs(pcm, sample_rate, n_hops_cpu=192):
-    """block-switched workload: the oracle's whole file loop on the first hops of the same stream"""
-    from oracle import pac_oracle as po
+def cpu_baseline_bs(pcm, sample_rate, n_hops_cpu=192, vq_kbps=None):
+    """block-switched workloads: the oracle's whole file loop on the first hops of the same stream (scalar
+    mantissas, or with vq_kbps the reference driver's own settings: gain-shape coder, SBR below 128 kb/s)"""
     t0 = time.perf_counter()
-    po.encode_stream(pcm[:n_hops_cpu * 1024], sample_rate, KBPS, block_switching=True)
+    if vq_kbps:
+        from oracle import pac_oracle_vq as pv
+        n_hops_cpu = 96
+        pv.encode_stream_vq(pcm[:n_hops_cpu * 1024], sample_rate, vq_kbps)
+        what = "oracle/pac_oracle_vq.py encode_stream_vq (gain-shape coder, block switching on)"
+    else:
+        from oracle import pac_oracle as po
+        po.encode_stream(pcm[:n_hops_cpu * 1024], sample_rate, KBPS, block_switching=True)
+        what = "oracle/pac_oracle.py encode_stream (block switching on)"
     dtc = time.perf_counter() - t0
     return {"value": (n_hops_cpu + 2) * N_CH / dtc, "unit": "channel-frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_hops_cpu} hops of the same tiled stream through oracle/pac_oracle.py "
-                      f"encode_stream (block switching on), {dtc:.1f} s"}
+            "sample": f"first {n_hops_cpu} hops of the same tiled stream through {what}, {dtc:.1f} s"}
 
 
 # ------------------------------------------------------------------ verification
@@ -492,7 +499,7 @@ def main():
             res["config"]["ms_per_step_without_gather"] = d2 / args.steps * 1e3
         if not args.no_cpu_baseline and not multi:
             if block_switched:
-                res["cpu_baseline"] = cpu_baseline_bs(pcm, sample_rate)
+                res["cpu_baseline"] = cpu_baseline_bs(pcm, sample_rate, vq_kbps=vq_kbps)
             else:
                 res["cpu_baseline"] = cpu_baseline(vq_kbps)
         print(json.dumps(res), flush=True)
