@@ -44,6 +44,9 @@ struct VqDecView {
     const double *gauss;          /* [2r+1] normalised weights, centre at r   */
     int gauss_r;
     const double *line_freq;      /* [1024] (k + 1/2) * sampleRate / 2048      */
+    /* scratch of wave w = [scr_off[w], scr_off[w+1]) doubles: the first VQD_WAVES tickets are static (wave w
+       takes the (w+1)-th band from the top), so only those waves need room for the biggest bands */
+    int scr_off[VQD_WAVES + 1];
 };
 
 __device__ __forceinline__ uint64_t vqd_N(const VqDecView &V, int l, long long k)
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
             for (int s = 1; s < PACX_SUB; ++s)
                 A.overall[cf * PACX_SUB + s] = 0;
         }
-        misc[0] = 0;
+        misc[0] = VQD_WAVES;                               /* tickets 0 .. VQD_WAVES-1 are the waves' own */
         misc[1] = bad ? 0 : (shrt ? PACX_SUB : 1) * nb;
         misc[2] = shrt;
         misc[3] = sbr;
@@ -542,14 +545,15 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
     const int nb = shrt ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = shrt ? T.band_lower_short : T.band_lower_long;
     const int32_t *__restrict__ count = shrt ? T.band_lines_short : T.band_lines_long;
-    double *scr = scr_all + (size_t)wave * A.scr_len;
+    double *scr = scr_all + V.scr_off[wave];
     VqdFrame *fr = frames + wave * VQD_DEPTH;
     unsigned raised = 0;
-    for (;;) {
-        int tk = 0;
-        if (lane == 0)
-            tk = atomicAdd(&misc[0], 1);
-        tk = __builtin_amdgcn_readfirstlane(tk);
+    for (int tk = wave;; tk = -1) {
+        if (tk < 0) {
+            if (lane == 0)
+                tk = atomicAdd(&misc[0], 1);
+            tk = __builtin_amdgcn_readfirstlane(tk);
+        }
         if (tk >= n_items)
             break;
         const int s = tk / nb, b = nb - 1 - (tk % nb);           /* large bands first */
@@ -725,9 +729,25 @@ size_t pacx_vqdec_view_size(void) { return sizeof(VqDecView); }
 
 void pacx_vqdec_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
                           const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
-                          const double *log2_tan, const double *gauss, int gauss_r, const double *line_freq)
+                          const double *log2_tan, const double *gauss, int gauss_r, const double *line_freq,
+                          const int32_t *sizes_long, int nb_long, const int32_t *sizes_short, int nb_short)
 {
     VqDecView *v = (VqDecView *)dst;
+    /* ticket t codes band nb - 1 - t (mod nb; short frames: of sub-block t / nb).  Wave w owns ticket w; later
+       tickets go to whichever wave is free */
+    v->scr_off[0] = 0;
+    for (int w = 0; w < VQD_WAVES; ++w) {
+        int n = 1;
+        if (w < nb_long)
+            n = sizes_long[nb_long - 1 - w];
+        if (w < nb_short && sizes_short[nb_short - 1 - w] > n)
+            n = sizes_short[nb_short - 1 - w];
+        for (int b = 0; b < nb_long - VQD_WAVES; ++b)
+            n = sizes_long[b] > n ? sizes_long[b] : n;
+        for (int b = 0; b < nb_short; ++b)                 /* a short frame's later tickets start over at the top band */
+            n = sizes_short[b] > n ? sizes_short[b] : n;
+        v->scr_off[w + 1] = v->scr_off[w] + ((3 * n + 4 * VQD_DEPTH + 1) & ~1);
+    }
     v->log2_tan = log2_tan;
     v->n_tab = n_tab;
     v->p_tab = p_tab;
@@ -761,10 +781,10 @@ void pacx_launch_vq_dec(const PacxTables &T, const void *view, long long n_cf, c
     A.lines = lines;
     A.sbr_flag = sbr_flag;
     A.status = status;
-    A.scr_len = (3 * V.l_max + 4 * VQD_DEPTH + 1) & ~1;
+    A.scr_len = 0;
     const size_t fixed = VQD_WORDS * 4 + PACX_M_LONG * 8 + (2 * PACX_SUB * PACX_MAX_BANDS + 4) * 4 +
                          VQD_WAVES * VQD_DEPTH * sizeof(VqdFrame);
-    const size_t smem = fixed + (size_t)VQD_WAVES * A.scr_len * 8;
+    const size_t smem = fixed + (size_t)V.scr_off[VQD_WAVES] * 8;
     hipLaunchKernelGGL(k_vq_dec, dim3((unsigned)n_cf), dim3(64 * VQD_WAVES), smem, st, T, V, A);
     if (T.use_sbr) {
         /* LDS sized for the worst case (every line above the cut): lines, mirrored

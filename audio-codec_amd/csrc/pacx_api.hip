@@ -79,7 +79,8 @@ void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const
 size_t pacx_vqdec_view_size(void);
 void pacx_vqdec_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
                           const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
-                          const double *log2_tan, const double *gauss, int gauss_r, const double *line_freq);
+                          const double *log2_tan, const double *gauss, int gauss_r, const double *line_freq,
+                          const int32_t *sizes_long, int nb_long, const int32_t *sizes_short, int nb_short);
 void pacx_launch_vq_dec(const PacxTables &T, const void *view, long long n_cf, const uint8_t *payload,
                         int payload_stride, const long long *offsets, const int32_t *n_bytes,
                         uint8_t *cf_flags, int32_t *overall, int32_t *bit_alloc, double *lines,
@@ -592,7 +593,8 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         TRY(upload(h, gw.data(), gw.size(), &d_gw));
         TRY(upload(h, lf.data(), lf.size(), &d_lf));
         h->vqdec_view.resize(pacx_vqdec_view_size());
-        pacx_vqdec_view_fill(h->vqdec_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max, d_lt, d_gw, gr, d_lf);
+        pacx_vqdec_view_fill(h->vqdec_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max, d_lt, d_gw, gr, d_lf,
+                             cfg->band_lines_long, T.nb_long, cfg->band_lines_short, T.nb_short);
     }
 #undef TRY
     *out = h;
