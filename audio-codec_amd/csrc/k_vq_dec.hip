@@ -438,6 +438,7 @@ struct VqDecArgs {
     uint8_t *sbr_flag;         /* [cf] 1: Decode_SBR applies                */
     uint32_t *status;
     int scr_len;
+    int redo;                  /* 1: decode only the blocks k_vq_dec_frame left (sbr_flag 0x80) */
 };
 
 __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecView V, VqDecArgs A)
@@ -455,6 +456,8 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
     const long long cf = blockIdx.x;
     if (cf >= A.n_cf)
         return;
+    if (A.redo && A.sbr_flag[cf] != 0x80)
+        return;                                            /* k_vq_dec_frame decoded this block */
     /* as k_unpack (k_decode.hip): a record that is truncated or carries an impossible
        allocation gets PACX_ST_MALFORMED and decodes to zeros; nothing beyond n_bytes is read */
     int nbytes = A.n_bytes[cf];
@@ -608,6 +611,489 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
     double *out = A.lines + cf * PACX_M_LONG;
     for (int i = tid; i < PACX_M_LONG; i += 64 * VQD_WAVES)
         out[i] = lines_s[i];
+}
+
+/* ------------------------------------------------ frame-level decode (k_vq_dec_frame) */
+/* k_vq_dec walks a band's tree depth first with a whole wave per node and decodes the pyramid indices
+ * one component at a time with wave-uniform 64-bit arithmetic: 84 k vector instructions per channel-block,
+ * the vector unit 80 % busy.  Here, as in k_vq_frame of the encoder, one workgroup takes a channel-block
+ * through four stages over ALL its bands:
+ *   1. parse -- one band per LANE: the band's fields are read in the stream's (depth-first) order, but only
+ *      the angles are evaluated; every node of the tree goes into a store in LDS (splits with their angle,
+ *      leaves with the position of their index), its vector gets room in the buffer of its depth;
+ *   2. leaves -- one leaf per LANE (all four waves): index -> pulses -> unit vector;
+ *   3. combine -- level by level from the deepest: left/right from mid/side and the normalisation, several
+ *      nodes per pass (one per aligned block of Q lanes, so that the xor butterfly adds in the order of
+ *      vqd_normalize's 64-lane one);
+ *   4. gains and the lines.
+ * Same arithmetic per node as k_vq_dec.  A block whose trees do not fit is left to k_vq_dec (sbr_flag 0x80). */
+#define VQDF_NCAP 320
+#define VQDF_BUF 1536                  /* doubles: every node's vector lives in a region of pow2ceil(n) of them */
+#define VQDF_VB 64
+#define VQDF_STACK 16
+struct VqdfStore {
+    double *theta;                     /* [NCAP] a split's dequantised angle */
+    unsigned short *nn, *off, *bitpos, *kid0, *kid1, *reg;      /* reg: size of the node's region */
+    unsigned char *kind, *bits, *depth, *band;   /* kind 0 split, 1 leaf, 2 zeros */
+    __device__ __forceinline__ void bind(unsigned char *p)
+    {
+        theta = (double *)p;
+        nn = (unsigned short *)(p + VQDF_NCAP * 8);
+        off = nn + VQDF_NCAP;
+        bitpos = off + VQDF_NCAP;
+        kid0 = bitpos + VQDF_NCAP;
+        kid1 = kid0 + VQDF_NCAP;
+        reg = kid1 + VQDF_NCAP;
+        kind = (unsigned char *)(reg + VQDF_NCAP);
+        bits = kind + VQDF_NCAP;
+        depth = bits + VQDF_NCAP;
+        band = depth + VQDF_NCAP;
+    }
+};
+#define VQDF_STORE_BYTES (VQDF_NCAP * 8 + 6 * VQDF_NCAP * 2 + 4 * VQDF_NCAP)
+#define VQDF_FIXED (VQD_WORDS * 4 + 7 * VQDF_VB * 4 + 32 * 4 + VQDF_VB * VQDF_STACK * 4)
+#define VQDF_SMEM (VQDF_FIXED + VQDF_BUF * 8 + VQDF_STORE_BYTES)
+
+/* decode_pvq_vector for ONE lane: index b -> integer pulses y[0..L) (zeroed here) */
+__device__ __forceinline__ bool vqdf_pvq_lane(const VqDecView &V, unsigned long long b, int L, int K, double *y)
+{
+    for (int i = 0; i < L; ++i)
+        y[i] = 0.0;
+    unsigned long long xb = 0;
+    long long k = K;
+    int l = L;
+    for (int i = 0; i < L && k > 0; ++i, --l) {
+        if (b == xb) {                                  /* the rest is zero, the last component takes k */
+            y[L - 1] = (double)k;
+            k = 0;
+            break;
+        }
+        const unsigned long long n0 = vqd_N(V, l - 1, k);
+        if (b - xb < n0)
+            continue;                                   /* this component is zero */
+        xb += n0;
+        const unsigned long long r = b - xb;
+        const unsigned long long pk1 = vqd_P(V, l - 1, k - 1);
+        long long lo = 1, hi = k;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            const unsigned long long c = 2ull * (pk1 - vqd_P(V, l - 1, k - mid - 1));
+            if (r < c)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const long long j = lo;
+        if (r >= 2ull * (pk1 - vqd_P(V, l - 1, k - j - 1)))
+            return false;                               /* not an index of this codebook */
+        const unsigned long long base = 2ull * (pk1 - vqd_P(V, l - 1, k - j));
+        const unsigned long long group = vqd_N(V, l - 1, k - j);
+        const bool neg = (r - base) >= group;
+        y[i] = neg ? -(double)j : (double)j;
+        xb += base + (neg ? group : 0ull);
+        k -= j;
+    }
+    return k == 0;                                      /* pulses left over: the reference raises */
+}
+
+__global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T, VqDecView V, VqDecArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *words = (unsigned *)smem;                                  /* VQD_WORDS */
+    int *item_pos = (int *)(smem + VQD_WORDS * 4);                       /* VB: first bit of the band's fields */
+    int *item_ba = item_pos + VQDF_VB;                                   /* VB */
+    int *item_end = item_ba + VQDF_VB;                                   /* VB: first bit behind the shape's fields */
+    int *item_bg = item_end + VQDF_VB;                                   /* VB: gain bits before the slack */
+    int *item_bs = item_bg + VQDF_VB;                                    /* VB: shape bits */
+    int *item_root = item_bs + VQDF_VB;                                  /* VB: root node, -1 none */
+    int *item_n = item_root + VQDF_VB;                                   /* VB: vector length */
+    int *misc = item_n + VQDF_VB;                                        /* 0 nodes, 1 redo, 2 n_items, 3 short, 4 sbr, 5 flags, 6 max depth, 8..24 level fill */
+    unsigned *stack = (unsigned *)(misc + 32);                           /* [VB][STACK]: parent | a_side << 16 */
+    double *buf0 = (double *)(smem + VQDF_FIXED);
+    VqdfStore N;
+    N.bind(smem + VQDF_FIXED + VQDF_BUF * 8);
+    static_assert(VQDF_FIXED % 8 == 0, "doubles behind the fixed part");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long cf = blockIdx.x;
+    if (cf >= A.n_cf)
+        return;
+    int nbytes = A.n_bytes[cf];
+    bool bad = nbytes < 1 || nbytes > 4 * (VQD_WORDS - 2);
+    if (bad)
+        nbytes = 0;
+    const uint8_t *src = A.payload + (A.offsets ? A.offsets[cf] : cf * (long long)A.payload_stride);
+    const int n_words = (nbytes + 3) >> 2;
+    for (int i = tid; i < VQD_WORDS; i += 64 * VQD_WAVES) {
+        unsigned v = 0;
+        if (i < n_words) {
+            const int b0 = 4 * i;
+            v = ((unsigned)src[b0] << 24) | ((b0 + 1 < nbytes ? (unsigned)src[b0 + 1] : 0u) << 16) |
+                ((b0 + 2 < nbytes ? (unsigned)src[b0 + 2] : 0u) << 8) | (b0 + 3 < nbytes ? (unsigned)src[b0 + 3] : 0u);
+        }
+        words[i] = v;
+    }
+    double *out = A.lines + cf * PACX_M_LONG;
+    for (int i = tid; i < PACX_M_LONG; i += 64 * VQD_WAVES)
+        out[i] = 0.0;
+    if (tid < 32)
+        misc[tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        /* header: flags, then per (sub-)block the overall scale and the allocations (as k_vq_dec) */
+        const int limit = 8 * nbytes;
+        const unsigned fl = bad ? 0u
+                                : (unsigned)vqd_get(words, 0, 1) | ((unsigned)vqd_get(words, 1, 1) << 1) |
+                                      ((unsigned)vqd_get(words, 2, 1) << 2);
+        A.cf_flags[cf] = (uint8_t)fl;
+        const int shrt = (fl >> 1) & 1;
+        const int nb = shrt ? T.nb_short : T.nb_long;
+        const int32_t *cnt = shrt ? T.band_lines_short : T.band_lines_long;
+        int pos = 3;
+        int sbr = 0;
+        if (3 + T.n_scale_bits + T.n_mant_size_bits * nb > limit)
+            bad = true;
+        if (T.use_sbr && !shrt && !bad) {
+            int p2 = pos + T.n_scale_bits;
+            for (int b = 0; b < nb; ++b) {
+                if (b >= T.first_omitted && vqd_get(words, p2, T.n_mant_size_bits) != 0)
+                    sbr = 1;
+                p2 += T.n_mant_size_bits;
+            }
+        }
+        for (int s = 0; s < (shrt ? PACX_SUB : 1) && !bad; ++s) {
+            if (pos + T.n_scale_bits + T.n_mant_size_bits * nb > limit) {
+                bad = true;
+                break;
+            }
+            A.overall[cf * PACX_SUB + s] = (int)vqd_get(words, pos, T.n_scale_bits);
+            pos += T.n_scale_bits;
+            int body = pos + T.n_mant_size_bits * nb;
+            for (int b = 0; b < nb; ++b) {
+                int a = (int)vqd_get(words, pos, T.n_mant_size_bits);
+                if (a)
+                    a += 1;
+                pos += T.n_mant_size_bits;
+                const int span = a * ((sbr && b >= T.first_omitted) ? 1 : cnt[b]);
+                if (a > 16 || body + span > limit) {
+                    bad = true;
+                    break;
+                }
+                A.bit_alloc[cf * T.band_stride + s * nb + b] = a;
+                item_pos[s * nb + b] = body;
+                item_ba[s * nb + b] = a;
+                body += span;
+            }
+            pos = body;
+        }
+        if (bad) {
+            for (int s = 0; s < PACX_SUB; ++s)
+                A.overall[cf * PACX_SUB + s] = 0;
+            for (int i = 0; i < T.band_stride; ++i)
+                A.bit_alloc[cf * T.band_stride + i] = 0;
+            atomicOr(&A.status[cf], 32u);                          /* PACX_ST_MALFORMED */
+            sbr = 0;
+        } else if (!shrt) {
+            for (int s = 1; s < PACX_SUB; ++s)
+                A.overall[cf * PACX_SUB + s] = 0;
+        }
+        misc[2] = bad ? 0 : (shrt ? PACX_SUB : 1) * nb;
+        misc[3] = shrt;
+        misc[4] = sbr;
+        A.sbr_flag[cf] = (uint8_t)sbr;
+    }
+    __syncthreads();
+    const int shrt = misc[3], sbr = misc[4], n_items = misc[2];
+    const int nb = shrt ? T.nb_short : T.nb_long;
+    const int32_t *__restrict__ lower = shrt ? T.band_lower_short : T.band_lower_long;
+    const int32_t *__restrict__ count = shrt ? T.band_lines_short : T.band_lines_long;
+    const double half_pi = 1.5707963267948966;
+    bool undefined = false;
+
+    /* ---- 1. parse: one band per lane */
+    if (wave == 0) {
+        const int vb = lane;
+        const bool live = vb < n_items && item_ba[vb < n_items ? vb : 0] != 0;
+        const int s = live ? vb / nb : 0, b = vb - s * nb;
+        int n = live ? count[b] : 1;
+        if (live && sbr && b >= T.first_omitted)
+            n = 1;
+        const int r_bits = live ? item_ba[vb] * n : 0;
+        int bits_gain = live ? (int)floor((double)r_bits / (double)n + V.half_log2[n]) : 0;
+        int bits_shape = r_bits - bits_gain;
+        if (bits_shape < 0)
+            bits_shape = 0;
+        int pos = live ? item_pos[vb] : 0;
+        unsigned *stk = stack + vb * VQDF_STACK;
+        int sp = 0;
+        /* the node being entered: length, bits, where it hangs (parent, 0 mid / 1 side; root: parent -1),
+           its region */
+        int c_n = n, c_bits = bits_shape, c_par = -1, c_side = 0, c_depth = 0;
+        bool have = live && bits_shape != 0;
+        int root = -1;
+        bool redo = false;
+        int c_reg = 0;
+        if (have) {
+            c_reg = 1;
+            while (c_reg < n)
+                c_reg <<= 1;
+        }
+        int c_off, room = c_reg;
+        {
+            int incl = room;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o)
+                    incl += t;
+            }
+            c_off = incl - room;
+            if (__shfl(incl, 63, 64) > VQDF_BUF)
+                redo = true;
+        }
+        if (redo)
+            have = false;
+        while (__builtin_amdgcn_ballot_w64(have || sp > 0)) {
+            if (!have && sp > 0) {                          /* the pending side half of the innermost split */
+                const unsigned e = stk[--sp];
+                c_par = (int)(e & 0xFFFFu);
+                c_bits = (int)(e >> 16);
+                c_side = 1;
+                c_depth = N.depth[c_par] + 1;
+                c_n = N.nn[c_par] - N.nn[c_par] / 2;
+                c_reg = N.reg[c_par] >> 1;
+                c_off = N.off[c_par] + c_reg;
+                have = true;
+            }
+            if (!have)
+                continue;
+            /* a node of this lane's tree */
+            const int id = atomicAdd(&misc[0], 1);
+            if (id >= VQDF_NCAP || c_depth > VQD_DEPTH) {
+                redo = true;
+                have = false;
+                sp = 0;
+                continue;
+            }
+            atomicMax(&misc[6], c_depth);
+            N.nn[id] = (unsigned short)c_n;
+            N.off[id] = (unsigned short)c_off;
+            N.reg[id] = (unsigned short)c_reg;
+            N.depth[id] = (unsigned char)c_depth;
+            N.band[id] = (unsigned char)vb;
+            N.kid0[id] = 0xFFFF;
+            N.kid1[id] = 0xFFFF;
+            if (c_par < 0)
+                root = id;
+            else if (c_side)
+                N.kid1[c_par] = (unsigned short)id;
+            else
+                N.kid0[c_par] = (unsigned short)id;
+            if (c_bits <= 0) {
+                N.kind[id] = 2;                             /* a half without bits: zeros */
+                have = false;
+                continue;
+            }
+            if (c_bits <= PACX_VQ_SPLIT_BITS) {
+                const int width = V.w_of[c_n * 33 + c_bits];
+                N.kind[id] = 1;
+                N.bits[id] = (unsigned char)c_bits;
+                N.bitpos[id] = (unsigned short)pos;
+                pos += width;
+                have = false;
+                continue;
+            }
+            if (c_depth >= VQD_DEPTH) {                     /* deeper than any real tree (k_vq_dec stops here too) */
+                undefined = true;
+                N.kind[id] = 2;
+                have = false;
+                continue;
+            }
+            /* split: the angle, the bit split */
+            const int half = c_n - c_n / 2;
+            const int a_theta = (int)floor((double)c_bits / (double)half + V.half_log2[half]);
+            int a_rest = c_bits - a_theta;
+            if (a_rest < 0)
+                a_rest = 0;
+            double theta = 0.0;
+            unsigned long long theta_code = 0;
+            if (a_theta > 0 && a_theta <= 62) {
+                const unsigned long long code = vqd_get(words, pos, a_theta);
+                theta_code = code;
+                const unsigned long long mag = code & ((1ull << (a_theta - 1)) - 1ull);
+                const double den = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+                double dq = (double)(2ull * mag) / den;
+                if (code >> (a_theta - 1))
+                    dq = -dq;
+                theta = dq * half_pi;
+            } else if (a_theta > 62) {
+                undefined = true;
+            }
+            pos += a_theta > 0 ? a_theta : 0;
+            int a_mid = 0;
+            if (theta != 0.0) {
+                double lt;
+                if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta > 0.0)
+                    lt = V.log2_tan[((1 << (a_theta - 1)) - 1) + (int)theta_code];
+                else
+                    lt = log2(tan(fabs(theta)) + PACX_EPS);
+                const double v = ((double)a_rest - (double)(half - 1) * lt) / 2.0;
+                const double f = floor(v);
+                a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
+            }
+            N.kind[id] = 0;
+            N.theta[id] = theta;
+            if (sp >= VQDF_STACK) {
+                redo = true;
+                have = false;
+                sp = 0;
+                continue;
+            }
+            stk[sp++] = (unsigned)id | ((unsigned)(a_rest - a_mid) << 16);
+            c_par = id;
+            c_side = 0;
+            c_bits = a_mid;
+            c_n = half;
+            c_reg >>= 1;                                    /* the mid half of the region; c_off stays */
+            c_depth += 1;
+            have = true;
+        }
+        if (vb < VQDF_VB) {
+            item_end[vb] = pos;
+            item_bg[vb] = bits_gain;
+            item_bs[vb] = bits_shape;
+            item_root[vb] = root;
+            item_n[vb] = n;
+        }
+        if (__builtin_amdgcn_ballot_w64(redo) && lane == 0)
+            misc[1] = 1;
+    }
+    __syncthreads();
+    if (misc[1]) {
+        if (tid == 0)
+            A.sbr_flag[cf] = 0x80;                          /* k_vq_dec decodes this block */
+        return;
+    }
+    const int n_nodes = misc[0], max_depth = misc[6];
+    /* ---- 2. leaves (and the halves without bits): one per lane */
+    for (int j = tid; j < n_nodes; j += 64 * VQD_WAVES) {
+        const int kd = N.kind[j];
+        if (kd == 0)
+            continue;
+        const int n = N.nn[j];
+        double *y = buf0 + N.off[j];
+        if (kd == 2) {
+            for (int i = 0; i < n; ++i)
+                y[i] = 0.0;
+            continue;
+        }
+        const int bits = N.bits[j];
+        const int K = V.k_of[n * 33 + bits];
+        const int width = V.w_of[n * 33 + bits];
+        if (K < 0) {
+            undefined = true;
+            for (int i = 0; i < n; ++i)
+                y[i] = 0.0;
+            continue;
+        }
+        const unsigned long long idx = vqd_get(words, N.bitpos[j], width);
+        if (!vqdf_pvq_lane(V, idx, n, K, y))
+            undefined = true;
+        /* x / ||x|| (sums of squares of integers: exact in any order) */
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i)
+            acc += y[i] * y[i];
+        const double nrm = sqrt(acc);
+        if (nrm != 0.0)
+            for (int i = 0; i < n; ++i)
+                y[i] = y[i] / nrm;
+    }
+    __syncthreads();
+    /* ---- 3. combine, level by level from the deepest split; a root that is a leaf is normalised a second
+       time, as the reference's non-split branch does (coder/gain_shape_quantize.py:468-472) */
+    for (int d = max_depth; d >= 0; --d) {
+        /* every wave walks the node store for its share of the level's work items */
+        int item = 0;
+        for (int j0 = 0; j0 < n_nodes; j0 += 64) {
+            const int j = j0 + lane;
+            const bool mine = j < n_nodes && N.depth[j] == d && (N.kind[j] == 0 || (d == 0 && N.kind[j] == 1));
+            unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+            for (; m; m &= m - 1, ++item) {
+                if ((item & (VQD_WAVES - 1)) != wave)
+                    continue;
+                const int node = j0 + __builtin_ctzll(m);
+                const int n = N.nn[node];
+                double *o = buf0 + N.off[node];
+                if (N.kind[node] == 0) {
+                    /* in place: the output overwrites the children's regions, so a lane reads everything it
+                       needs (up to 8 x 64 components per half) before anybody writes */
+                    const int cut = n / 2, half = n - cut;
+                    const double theta = N.theta[node];
+                    const double ct = vqd_cos(theta), st = vqd_sin(theta);
+                    const double root2 = sqrt(2.0);
+                    const double *mid = buf0 + N.off[N.kid0[node]], *side = buf0 + N.off[N.kid1[node]];
+                    double lft[8], rgt[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = lane + 64 * u;
+                        lft[u] = rgt[u] = 0.0;
+                        if (i < half) {
+                            const double mm = mid[i] * ct, ss = side[i] * st;
+                            lft[u] = (mm + ss) / root2;
+                            rgt[u] = (mm - ss) / root2;
+                        }
+                    }
+                    vqd_fence();
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = lane + 64 * u;
+                        if (i < half) {
+                            if (i < cut)
+                                o[i] = lft[u];              /* an odd band drops the last left value */
+                            o[cut + i] = rgt[u];
+                        }
+                    }
+                    vqd_fence();
+                }
+                vqd_normalize(o, n, lane);
+            }
+        }
+        __syncthreads();
+    }
+    /* ---- 4. gains and the lines */
+    for (int vb = wave; vb < n_items; vb += VQD_WAVES) {
+        const int ba = item_ba[vb];
+        if (!ba)
+            continue;
+        const int s = vb / nb, b = vb - s * nb;
+        const int n = item_n[vb];
+        int at = lower[b];
+        if (sbr && b >= T.first_omitted)
+            at = lower[T.first_omitted] + (b - T.first_omitted);
+        const int pos = item_end[vb];
+        int bits_gain = item_bg[vb] + item_bs[vb] - (pos - item_pos[vb]);
+        double deq = 0.0;
+        if (bits_gain > 64) {
+            undefined = true;
+        } else if (bits_gain > 0) {
+            const unsigned long long code = vqd_get(words, pos, bits_gain);
+            const unsigned long long mag = (bits_gain == 64) ? (code & 0x7FFFFFFFFFFFFFFFull)
+                                                              : (code & ((1ull << (bits_gain - 1)) - 1ull));
+            const double den = (bits_gain <= 53) ? (double)((1ull << bits_gain) - 1ull) : ldexp(1.0, bits_gain);
+            deq = (2.0 * (double)mag) / den;
+            if (code >> (bits_gain - 1))
+                deq = -deq;
+        }
+        const double sgn = (deq > 0.0) ? 1.0 : ((deq < 0.0) ? -1.0 : 0.0);
+        const double gain = (sgn / 255.0 * (vqd_pow256(fabs(deq)) - 1.0)) * (double)n;
+        const int root = item_root[vb];
+        double *dst = out + (shrt ? s * PACX_M_SHORT : 0) + at;
+        for (int i = lane; i < n; i += 64)
+            dst[i] = gain * (root >= 0 ? buf0[N.off[root] + i] : 1.0);
+    }
+    if (__builtin_amdgcn_ballot_w64(undefined) && lane == 0)
+        atomicOr(&A.status[cf], PACX_ST_VQ_UNDEFINED);
 }
 
 /* ------------------------------------------------------- SBR reconstruction */
@@ -785,6 +1271,13 @@ void pacx_launch_vq_dec(const PacxTables &T, const void *view, long long n_cf, c
     const size_t fixed = VQD_WORDS * 4 + PACX_M_LONG * 8 + (2 * PACX_SUB * PACX_MAX_BANDS + 4) * 4 +
                          VQD_WAVES * VQD_DEPTH * sizeof(VqdFrame);
     const size_t smem = fixed + (size_t)V.scr_off[VQD_WAVES] * 8;
+    /* the frame-level decoder first; k_vq_dec then takes the blocks it left (PACX_VQ_DEC_FRAME=0: k_vq_dec alone) */
+    const char *fe = getenv("PACX_VQ_DEC_FRAME");
+    A.redo = (fe && atoi(fe) == 0) ? 0 : 1;
+    if (PACX_SUB * T.nb_short > VQDF_VB || T.nb_long > VQDF_VB)
+        A.redo = 0;
+    if (A.redo)
+        hipLaunchKernelGGL(k_vq_dec_frame, dim3((unsigned)n_cf), dim3(64 * VQD_WAVES), (size_t)VQDF_SMEM, st, T, V, A);
     hipLaunchKernelGGL(k_vq_dec, dim3((unsigned)n_cf), dim3(64 * VQD_WAVES), smem, st, T, V, A);
     if (T.use_sbr) {
         /* LDS sized for the worst case (every line above the cut): lines, mirrored
