@@ -208,7 +208,7 @@ def build_phase_debug():
     tools/mdct_phase_probe.py and tools/psy_phase_probe.py through PACX_LIB).  A
     measuring aid, never loaded by default."""
     build(verbose=False)
-    dbg_srcs = {"k_mdct3.hip": "-DPACX_MDCT_DEBUG", "k_psy.hip": "-DPACX_PSY_DEBUG", "k_quant.hip": "-DPACX_TAIL_DEBUG", "k_vq.hip": "-DPACX_VQ_DEBUG"}
+    dbg_srcs = {"k_mdct3.hip": "-DPACX_MDCT_DEBUG", "k_psy.hip": "-DPACX_PSY_DEBUG", "k_quant.hip": "-DPACX_TAIL_DEBUG", "k_vq.hip": "-DPACX_VQ_DEBUG", "k_vq_dec.hip": "-DPACX_VQD_DEBUG"}
     dbg_objs = []
     for src, flag in dbg_srcs.items():
         obj = os.path.join(OBJ, src.replace(".hip", "_dbg.o"))

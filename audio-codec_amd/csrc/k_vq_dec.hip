@@ -696,8 +696,24 @@ __device__ __forceinline__ bool vqdf_pvq_lane(const VqDecView &V, unsigned long 
     return k == 0;                                      /* pulses left over: the reference raises */
 }
 
+#ifdef PACX_VQD_DEBUG
+/* stage stamps of k_vq_dec_frame (thread 0 of every workgroup), a measuring aid (build.py --phase-debug) */
+__device__ long long g_vqd_dbg[8];
+extern "C" int pacx_debug_read_vqd(long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vqd_dbg), sizeof(long long) * n);
+}
+#define VQD_T(k) do { long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                      if (threadIdx.x == 0 && vqd_last) atomicAdd((unsigned long long *)&g_vqd_dbg[k], (unsigned long long)(t_ - vqd_last)); \
+                      vqd_last = t_; } while (0)
+#else
+#define VQD_T(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T, VqDecView V, VqDecArgs A)
 {
+#ifdef PACX_VQD_DEBUG
+    long long vqd_last = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *words = (unsigned *)smem;                                  /* VQD_WORDS */
     int *item_pos = (int *)(smem + VQD_WORDS * 4);                       /* VB: first bit of the band's fields */
@@ -740,6 +756,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
     if (tid < 32)
         misc[tid] = 0;
     __syncthreads();
+    VQD_T(7);
     if (tid == 0) {
         /* header: flags, then per (sub-)block the overall scale and the allocations (as k_vq_dec) */
         const int limit = 8 * nbytes;
@@ -804,6 +821,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
         A.sbr_flag[cf] = (uint8_t)sbr;
     }
     __syncthreads();
+    VQD_T(0);
     const int shrt = misc[3], sbr = misc[4], n_items = misc[2];
     const int nb = shrt ? T.nb_short : T.nb_long;
     const int32_t *__restrict__ lower = shrt ? T.band_lower_short : T.band_lower_long;
@@ -970,6 +988,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
             misc[1] = 1;
     }
     __syncthreads();
+    VQD_T(1);
     if (misc[1]) {
         if (tid == 0)
             A.sbr_flag[cf] = 0x80;                          /* k_vq_dec decodes this block */
@@ -998,8 +1017,13 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
             continue;
         }
         const unsigned long long idx = vqd_get(words, N.bitpos[j], width);
+#ifdef VQDF_STUB_LEAF          /* timing experiment only: what the index walks cost */
+        for (int i = 0; i < n; ++i)
+            y[i] = (double)((idx >> i) & 1ull);
+#else
         if (!vqdf_pvq_lane(V, idx, n, K, y))
             undefined = true;
+#endif
         /* x / ||x|| (sums of squares of integers: exact in any order) */
         double acc = 0.0;
         for (int i = 0; i < n; ++i)
@@ -1010,6 +1034,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
                 y[i] = y[i] / nrm;
     }
     __syncthreads();
+    VQD_T(2);
     /* ---- 3. combine, level by level from the deepest split; a root that is a leaf is normalised a second
        time, as the reference's non-split branch does (coder/gain_shape_quantize.py:468-472) */
     for (int d = max_depth; d >= 0; --d) {
@@ -1030,7 +1055,11 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
                        needs (up to 8 x 64 components per half) before anybody writes */
                     const int cut = n / 2, half = n - cut;
                     const double theta = N.theta[node];
+#ifdef VQDF_STUB_TRIG
+                    const double ct = 0.7 + theta * 1e-3, st = 0.7 - theta * 1e-3;
+#else
                     const double ct = vqd_cos(theta), st = vqd_sin(theta);
+#endif
                     const double root2 = sqrt(2.0);
                     const double *mid = buf0 + N.off[N.kid0[node]], *side = buf0 + N.off[N.kid1[node]];
                     double lft[8], rgt[8];
@@ -1061,6 +1090,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
         }
         __syncthreads();
     }
+    VQD_T(3);
     /* ---- 4. gains and the lines */
     for (int vb = wave; vb < n_items; vb += VQD_WAVES) {
         const int ba = item_ba[vb];
@@ -1094,6 +1124,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
     }
     if (__builtin_amdgcn_ballot_w64(undefined) && lane == 0)
         atomicOr(&A.status[cf], PACX_ST_VQ_UNDEFINED);
+    VQD_T(4);
 }
 
 /* ------------------------------------------------------- SBR reconstruction */
