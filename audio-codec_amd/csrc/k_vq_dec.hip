@@ -651,7 +651,7 @@ struct VqdfStore {
     }
 };
 #define VQDF_STORE_BYTES (VQDF_NCAP * 8 + 6 * VQDF_NCAP * 2 + 4 * VQDF_NCAP)
-#define VQDF_FIXED (VQD_WORDS * 4 + 7 * VQDF_VB * 4 + 32 * 4 + VQDF_VB * VQDF_STACK * 4)
+#define VQDF_FIXED (VQD_WORDS * 4 + 7 * VQDF_VB * 4 + 32 * 4 + VQDF_VB * VQDF_STACK * 4 + VQDF_NCAP * 2)
 #define VQDF_SMEM (VQDF_FIXED + VQDF_BUF * 8 + VQDF_STORE_BYTES)
 
 /* decode_pvq_vector for ONE lane: index b -> integer pulses y[0..L) (zeroed here) */
@@ -725,6 +725,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
     int *item_n = item_root + VQDF_VB;                                   /* VB: vector length */
     int *misc = item_n + VQDF_VB;                                        /* 0 nodes, 1 redo, 2 n_items, 3 short, 4 sbr, 5 flags, 6 max depth, 8..24 level fill */
     unsigned *stack = (unsigned *)(misc + 32);                           /* [VB][STACK]: parent | a_side << 16 */
+    unsigned short *lst = (unsigned short *)(stack + VQDF_VB * VQDF_STACK);   /* [NCAP] a level's small nodes */
     double *buf0 = (double *)(smem + VQDF_FIXED);
     VqdfStore N;
     N.bind(smem + VQDF_FIXED + VQDF_BUF * 8);
@@ -1038,12 +1039,22 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
     /* ---- 3. combine, level by level from the deepest split; a root that is a leaf is normalised a second
        time, as the reference's non-split branch does (coder/gain_shape_quantize.py:468-472) */
     for (int d = max_depth; d >= 0; --d) {
-        /* every wave walks the node store for its share of the level's work items */
-        int item = 0;
+        /* every wave walks the node store: nodes of more than 64 components are dealt round-robin and take a
+           whole wave each; the others are listed (every wave writes the same list) and combined several per
+           pass, one node per aligned block of Q lanes -- the xor butterfly of the normalisation then adds in the
+           order of vqd_normalize's 64-lane one (plus exact zeros), and cos / sin run once per pass */
+        int item = 0, n_small = 0, my_max = 0;
         for (int j0 = 0; j0 < n_nodes; j0 += 64) {
             const int j = j0 + lane;
             const bool mine = j < n_nodes && N.depth[j] == d && (N.kind[j] == 0 || (d == 0 && N.kind[j] == 1));
-            unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+            const int nj = mine ? N.nn[j] : 0;
+            const unsigned long long ms = __builtin_amdgcn_ballot_w64(mine && nj <= 64);
+            if (mine && nj <= 64) {
+                lst[n_small + __popcll(ms & ((1ull << lane) - 1ull))] = (unsigned short)j;
+                my_max = max(my_max, nj);
+            }
+            n_small += __popcll(ms);
+            unsigned long long m = __builtin_amdgcn_ballot_w64(mine && nj > 64);
             for (; m; m &= m - 1, ++item) {
                 if ((item & (VQD_WAVES - 1)) != wave)
                     continue;
@@ -1086,6 +1097,53 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T
                     vqd_fence();
                 }
                 vqd_normalize(o, n, lane);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            my_max = max(my_max, __shfl_xor(my_max, off, 64));
+        vqd_fence();
+        if (n_small) {
+            int lq = 1;
+            while ((1 << lq) < my_max)
+                ++lq;
+            const int Q = 1 << lq, G = 64 >> lq;
+            const double root2 = sqrt(2.0);
+            for (int p0 = wave * G; p0 < n_small; p0 += VQD_WAVES * G) {
+                const int g = lane >> lq, e = lane & (Q - 1);
+                const bool valid = p0 + g < n_small;
+                const int node = valid ? lst[p0 + g] : lst[p0];
+                const int n = valid ? N.nn[node] : 0;
+                double *o = buf0 + N.off[node];
+                const bool split = N.kind[node] == 0;
+                const int cut = n / 2;
+                const double theta = split ? N.theta[node] : 0.0;
+#ifdef VQDF_STUB_TRIG
+                const double ct = 0.7 + theta * 1e-3, st = 0.7 - theta * 1e-3;
+#else
+                const double ct = vqd_cos(theta), st = vqd_sin(theta);
+#endif
+                double val = 0.0;
+                if (e < n) {
+                    if (split) {
+                        const double *mid = buf0 + N.off[N.kid0[node]], *side = buf0 + N.off[N.kid1[node]];
+                        const int i = e < cut ? e : e - cut;
+                        const double mm = mid[i] * ct, ss = side[i] * st;
+                        val = e < cut ? (mm + ss) / root2 : (mm - ss) / root2;
+                    } else {
+                        val = o[e];                         /* a root that is a leaf: normalised a second time */
+                    }
+                }
+                vqd_fence();                                /* in place: everybody has read */
+                double acc = fma(val, val, 0.0);
+                for (int off = Q >> 1; off > 0; off >>= 1)
+                    acc = acc + __shfl_xor(acc, off, 64);
+                const double nrm = sqrt(acc);
+                if (nrm != 0.0)
+                    val = val / nrm;
+                if (e < n)
+                    o[e] = val;
+                vqd_fence();
             }
         }
         __syncthreads();
