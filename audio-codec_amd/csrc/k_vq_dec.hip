@@ -709,7 +709,7 @@ extern "C" int pacx_debug_read_vqd(long long *out, int n)
 #else
 #define VQD_T(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(64 * VQD_WAVES, 4) void k_vq_dec_frame(PacxTables T, VqDecView V, VqDecArgs A)
+__global__ __launch_bounds__(64 * VQD_WAVES, 5) void k_vq_dec_frame(PacxTables T, VqDecView V, VqDecArgs A)
 {
 #ifdef PACX_VQD_DEBUG
     long long vqd_last = 0;

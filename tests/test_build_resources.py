@@ -41,7 +41,8 @@ HOT = [
     (r"^k_vq_frame\(", 102, 5),                          # gain-shape coder: five workgroups per CU is what it runs on
     (r"^k_vq\(", 128, 4),                                # ... its fallback for trees beyond the node store
     (r"^k_vq_join\(", None, None),
-    (r"^k_vq_dec\(", 168, 3),
+    (r"^k_vq_dec_frame\(", 102, 5),                      # gain-shape decoder: five workgroups per CU
+    (r"^k_vq_dec\(", 168, 3),                            # ... its fallback
     (r"^k_unpack\(", None, None),
     (r"^k_imdct_long\(", None, None),
     (r"^k_imdct_short\(", None, None),
