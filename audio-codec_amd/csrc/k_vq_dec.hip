@@ -850,7 +850,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 5) void k_vq_dec_frame(PacxTables T
            its region */
         int c_n = n, c_bits = bits_shape, c_par = -1, c_side = 0, c_depth = 0;
         bool have = live && bits_shape != 0;
-        int root = -1;
+        int root = -1, my_depth = 0;
         bool redo = false;
         int c_reg = 0;
         if (have) {
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 5) void k_vq_dec_frame(PacxTables T
                 sp = 0;
                 continue;
             }
-            atomicMax(&misc[6], c_depth);
+            my_depth = max(my_depth, c_depth);
             N.nn[id] = (unsigned short)c_n;
             N.off[id] = (unsigned short)c_off;
             N.reg[id] = (unsigned short)c_reg;
@@ -937,7 +937,16 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 5) void k_vq_dec_frame(PacxTables T
                 a_rest = 0;
             double theta = 0.0;
             unsigned long long theta_code = 0;
-            if (a_theta > 0 && a_theta <= 62) {
+            if (a_theta > 0 && a_theta <= 31) {
+                /* (the same values in 32-bit integers: one conversion instruction where the 64-bit ones take a dozen) */
+                const unsigned code = (unsigned)vqd_get(words, pos, a_theta);
+                theta_code = code;
+                const unsigned mag = code & ((1u << (a_theta - 1)) - 1u);
+                double dq = (double)(2u * mag) / (double)((1u << a_theta) - 1u);
+                if (code >> (a_theta - 1))
+                    dq = -dq;
+                theta = dq * half_pi;
+            } else if (a_theta > 0 && a_theta <= 62) {
                 const unsigned long long code = vqd_get(words, pos, a_theta);
                 theta_code = code;
                 const unsigned long long mag = code & ((1ull << (a_theta - 1)) - 1ull);
@@ -985,6 +994,11 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 5) void k_vq_dec_frame(PacxTables T
             item_root[vb] = root;
             item_n[vb] = n;
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            my_depth = max(my_depth, __shfl_xor(my_depth, o, 64));
+        if (lane == 0)
+            misc[6] = my_depth;
         if (__builtin_amdgcn_ballot_w64(redo) && lane == 0)
             misc[1] = 1;
     }
