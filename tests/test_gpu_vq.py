@@ -424,3 +424,24 @@ def test_level_walk_equals_depth_first_walk(A, monkeypatch):
                                                 use_sbr=kbps < 128))
         monkeypatch.delenv("PACX_VQ_FRAME", raising=False)
         assert outs[0] == outs[1] == outs[2] == outs[3], kbps
+
+
+def test_frame_decoder_equals_band_decoder(A, monkeypatch):
+    """k_vq_dec_frame (bands parsed one per lane, one leaf per lane, in-place combine; the default) and k_vq_dec
+    (a wave per band, depth first; PACX_VQ_DEC_FRAME=0; also what takes the blocks whose trees do not fit the
+    frame decoder's node store) give the same lines and the same PCM, at bit rates on both sides of that limit."""
+    rng = np.random.default_rng(12)
+    t = np.arange(16 * 1024)
+    tone = 0.4 * np.sin(2 * np.pi * 523 * t / 48000) + 0.2 * np.sin(2 * np.pi * 6100 * t / 48000)
+    pcm = np.stack([tone + 0.05 * rng.standard_normal(len(t)), 0.3 * rng.standard_normal(len(t))], axis=1)
+    pcm = np.clip(np.round(pcm * 20000), -32767, 32767).astype(np.int16)
+    for kbps in (64, 128, 320):
+        pac = A.pacfile.encode_stream(pcm, 48000, kbps, block_switching=True, use_vq=True, use_sbr=kbps < 128)
+        outs = []
+        for mode in ("0", None):
+            if mode is None:
+                monkeypatch.delenv("PACX_VQ_DEC_FRAME", raising=False)
+            else:
+                monkeypatch.setenv("PACX_VQ_DEC_FRAME", mode)
+            outs.append(A.pacfile.decode_stream(pac))
+        assert np.array_equal(outs[0], outs[1]), kbps

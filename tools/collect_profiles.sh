@@ -40,6 +40,8 @@ if [ -f audio-codec_amd/libpacx_dbg.so ]; then
   PACX_LIB=$R/audio-codec_amd/libpacx_dbg.so python3 tools/vq_phase_probe.py 96 >> $OUT/phases_vq.txt 2>&1
 fi
 python3 tools/mdct_sweep.py 8192 16384 65536 262144 > $OUT/mdct_sweep.txt 2>&1
+python3 tools/decode_probe.py 2>&1 | grep -v amdgpu > $OUT/decode_probe.txt
+if [ -f audio-codec_amd/libpacx_dbg.so ]; then PACX_LIB=$R/audio-codec_amd/libpacx_dbg.so python3 tools/vqd_phase_probe.py 128 2>&1 | grep -v amdgpu > $OUT/phases_vq_dec.txt; fi
 # the tail fused into the mask kernel: the same traffic passes with PACX_FUSE_TAIL=1
 cd /tmp
 PACX_FUSE_TAIL=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_f -- python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
