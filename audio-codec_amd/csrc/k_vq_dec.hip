@@ -758,68 +758,77 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 5) void k_vq_dec_frame(PacxTables T
         misc[tid] = 0;
     __syncthreads();
     VQD_T(7);
-    if (tid == 0) {
-        /* header: flags, then per (sub-)block the overall scale and the allocations (as k_vq_dec) */
+    if (tid < 64) {
+        /* header: flags, then per (sub-)block the overall scale and the allocations -- what k_vq_dec's thread 0
+           reads field by field, one band per lane here: the fields' positions are static inside a (sub-)block,
+           a band's body starts behind the bodies of the bands before it (a scan), and the next sub-block
+           behind the last body */
         const int limit = 8 * nbytes;
         const unsigned fl = bad ? 0u
                                 : (unsigned)vqd_get(words, 0, 1) | ((unsigned)vqd_get(words, 1, 1) << 1) |
                                       ((unsigned)vqd_get(words, 2, 1) << 2);
-        A.cf_flags[cf] = (uint8_t)fl;
         const int shrt = (fl >> 1) & 1;
         const int nb = shrt ? T.nb_short : T.nb_long;
         const int32_t *cnt = shrt ? T.band_lines_short : T.band_lines_long;
-        int pos = 3;
-        int sbr = 0;
-        if (3 + T.n_scale_bits + T.n_mant_size_bits * nb > limit)
+        const int head = T.n_scale_bits + T.n_mant_size_bits * nb;
+        const int b = lane;
+        if (3 + head > limit)
             bad = true;
+        int sbr = 0;
         if (T.use_sbr && !shrt && !bad) {
-            int p2 = pos + T.n_scale_bits;
-            for (int b = 0; b < nb; ++b) {
-                if (b >= T.first_omitted && vqd_get(words, p2, T.n_mant_size_bits) != 0)
-                    sbr = 1;
-                p2 += T.n_mant_size_bits;
-            }
+            const bool coded = b < nb && b >= T.first_omitted &&
+                               vqd_get(words, 3 + T.n_scale_bits + T.n_mant_size_bits * b, T.n_mant_size_bits) != 0;
+            sbr = __builtin_amdgcn_ballot_w64(coded) ? 1 : 0;
         }
+        int pos = 3;
         for (int s = 0; s < (shrt ? PACX_SUB : 1) && !bad; ++s) {
-            if (pos + T.n_scale_bits + T.n_mant_size_bits * nb > limit) {
+            if (pos + head > limit) {
                 bad = true;
                 break;
             }
-            A.overall[cf * PACX_SUB + s] = (int)vqd_get(words, pos, T.n_scale_bits);
-            pos += T.n_scale_bits;
-            int body = pos + T.n_mant_size_bits * nb;
-            for (int b = 0; b < nb; ++b) {
-                int a = (int)vqd_get(words, pos, T.n_mant_size_bits);
-                if (a)
-                    a += 1;
-                pos += T.n_mant_size_bits;
-                const int span = a * ((sbr && b >= T.first_omitted) ? 1 : cnt[b]);
-                if (a > 16 || body + span > limit) {
-                    bad = true;
-                    break;
-                }
+            int a = (b < nb) ? (int)vqd_get(words, pos + T.n_scale_bits + T.n_mant_size_bits * b, T.n_mant_size_bits) : 0;
+            if (a)
+                a += 1;
+            const int span = (b < nb) ? a * ((sbr && b >= T.first_omitted) ? 1 : cnt[b]) : 0;
+            int incl = span;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o)
+                    incl += t;
+            }
+            const int body = pos + head + incl - span;
+            if (__builtin_amdgcn_ballot_w64(b < nb && (a > 16 || body + span > limit))) {
+                bad = true;
+                break;
+            }
+            if (b < nb) {
                 A.bit_alloc[cf * T.band_stride + s * nb + b] = a;
                 item_pos[s * nb + b] = body;
                 item_ba[s * nb + b] = a;
-                body += span;
             }
-            pos = body;
+            if (lane == 0)
+                A.overall[cf * PACX_SUB + s] = (int)vqd_get(words, pos, T.n_scale_bits);
+            pos += head + __shfl(incl, 63, 64);
         }
         if (bad) {
-            for (int s = 0; s < PACX_SUB; ++s)
-                A.overall[cf * PACX_SUB + s] = 0;
-            for (int i = 0; i < T.band_stride; ++i)
+            if (lane < PACX_SUB)
+                A.overall[cf * PACX_SUB + lane] = 0;
+            for (int i = lane; i < T.band_stride; i += 64)
                 A.bit_alloc[cf * T.band_stride + i] = 0;
-            atomicOr(&A.status[cf], 32u);                          /* PACX_ST_MALFORMED */
+            if (lane == 0)
+                atomicOr(&A.status[cf], 32u);                      /* PACX_ST_MALFORMED */
             sbr = 0;
-        } else if (!shrt) {
-            for (int s = 1; s < PACX_SUB; ++s)
-                A.overall[cf * PACX_SUB + s] = 0;
+        } else if (!shrt && lane >= 1 && lane < PACX_SUB) {
+            A.overall[cf * PACX_SUB + lane] = 0;
         }
-        misc[2] = bad ? 0 : (shrt ? PACX_SUB : 1) * nb;
-        misc[3] = shrt;
-        misc[4] = sbr;
-        A.sbr_flag[cf] = (uint8_t)sbr;
+        if (lane == 0) {
+            A.cf_flags[cf] = (uint8_t)fl;
+            misc[2] = bad ? 0 : (shrt ? PACX_SUB : 1) * nb;
+            misc[3] = shrt;
+            misc[4] = sbr;
+            A.sbr_flag[cf] = (uint8_t)sbr;
+        }
     }
     __syncthreads();
     VQD_T(0);
