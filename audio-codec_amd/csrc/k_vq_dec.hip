@@ -627,18 +627,19 @@ __global__ __launch_bounds__(64 * VQD_WAVES) void k_vq_dec(PacxTables T, VqDecVi
  *      vqd_normalize's 64-lane one);
  *   4. gains and the lines.
  * Same arithmetic per node as k_vq_dec.  A block whose trees do not fit is left to k_vq_dec (sbr_flag 0x80). */
-#define VQDF_NCAP 320
+#define VQDF_NCAP 304
 #define VQDF_BUF 1536                  /* doubles: every node's vector lives in a region of pow2ceil(n) of them */
 #define VQDF_VB 64
 #define VQDF_STACK 16
 struct VqdfStore {
-    double *theta;                     /* [NCAP] a split's dequantised angle */
+    double *theta, *sn;                /* [NCAP] a split's dequantised angle (stage 2 turns it into its cosine), its sine */
     unsigned short *nn, *off, *bitpos, *kid0, *kid1, *reg;      /* reg: size of the node's region */
     unsigned char *kind, *bits, *depth, *band;   /* kind 0 split, 1 leaf, 2 zeros */
     __device__ __forceinline__ void bind(unsigned char *p)
     {
         theta = (double *)p;
-        nn = (unsigned short *)(p + VQDF_NCAP * 8);
+        sn = theta + VQDF_NCAP;
+        nn = (unsigned short *)(p + 2 * VQDF_NCAP * 8);
         off = nn + VQDF_NCAP;
         bitpos = off + VQDF_NCAP;
         kid0 = bitpos + VQDF_NCAP;
@@ -650,7 +651,7 @@ struct VqdfStore {
         band = depth + VQDF_NCAP;
     }
 };
-#define VQDF_STORE_BYTES (VQDF_NCAP * 8 + 6 * VQDF_NCAP * 2 + 4 * VQDF_NCAP)
+#define VQDF_STORE_BYTES (2 * VQDF_NCAP * 8 + 6 * VQDF_NCAP * 2 + 4 * VQDF_NCAP)
 #define VQDF_FIXED (VQD_WORDS * 4 + 7 * VQDF_VB * 4 + 32 * 4 + VQDF_VB * VQDF_STACK * 4 + VQDF_NCAP * 2)
 #define VQDF_SMEM (VQDF_FIXED + VQDF_BUF * 8 + VQDF_STORE_BYTES)
 
@@ -1022,8 +1023,14 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 5) void k_vq_dec_frame(PacxTables T
     /* ---- 2. leaves (and the halves without bits): one per lane */
     for (int j = tid; j < n_nodes; j += 64 * VQD_WAVES) {
         const int kd = N.kind[j];
-        if (kd == 0)
+        if (kd == 0) {
+            /* a split has nothing to decode: its lane takes the cosine and sine of its angle off the combine
+               passes, which are a chain of levels (here they run beside the index walks) */
+            const double theta = N.theta[j];
+            N.theta[j] = vqd_cos(theta);
+            N.sn[j] = vqd_sin(theta);
             continue;
+        }
         const int n = N.nn[j];
         double *y = buf0 + N.off[j];
         if (kd == 2) {
@@ -1088,12 +1095,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 5) void k_vq_dec_frame(PacxTables T
                     /* in place: the output overwrites the children's regions, so a lane reads everything it
                        needs (up to 8 x 64 components per half) before anybody writes */
                     const int cut = n / 2, half = n - cut;
-                    const double theta = N.theta[node];
-#ifdef VQDF_STUB_TRIG
-                    const double ct = 0.7 + theta * 1e-3, st = 0.7 - theta * 1e-3;
-#else
-                    const double ct = vqd_cos(theta), st = vqd_sin(theta);
-#endif
+                    const double ct = N.theta[node], st = N.sn[node];
                     const double root2 = sqrt(2.0);
                     const double *mid = buf0 + N.off[N.kid0[node]], *side = buf0 + N.off[N.kid1[node]];
                     double lft[8], rgt[8];
@@ -1140,12 +1142,7 @@ __global__ __launch_bounds__(64 * VQD_WAVES, 5) void k_vq_dec_frame(PacxTables T
                 double *o = buf0 + N.off[node];
                 const bool split = N.kind[node] == 0;
                 const int cut = n / 2;
-                const double theta = split ? N.theta[node] : 0.0;
-#ifdef VQDF_STUB_TRIG
-                const double ct = 0.7 + theta * 1e-3, st = 0.7 - theta * 1e-3;
-#else
-                const double ct = vqd_cos(theta), st = vqd_sin(theta);
-#endif
+                const double ct = split ? N.theta[node] : 0.0, st = split ? N.sn[node] : 0.0;
                 double val = 0.0;
                 if (e < n) {
                     if (split) {
