@@ -1231,24 +1231,24 @@ __global__ __launch_bounds__(SBR_THREADS) void k_sbr_recon(PacxTables T, VqDecVi
         return;
     }
     double *ln = (double *)smem;                 /* [M] lines                          */
-    double *ext = ln + M;                        /* [2 n_omit + 2 r] mirrored envelope */
-    double *smooth = ext + 2 * n_omit + 2 * r;   /* [n_omit]                           */
-    double *old = smooth + n_omit;               /* [M/up + 2] interpolation ordinates */
+    double *smooth = ln + M;                     /* [n_omit]                           */
+    double *old = smooth + n_omit;               /* [M/up + 2] interpolation ordinates, later a band's magnitudes */
     double *g = lines + cf * M;
     for (int i = tid; i < M; i += SBR_THREADS)
         ln[i] = g[i];
     __syncthreads();
-    /* envelope = lines[cut:] ++ zeros, extended by reflection (d c b a | a b c d | d c b a) */
+    /* envelope = lines[cut:] ++ zeros, extended by reflection (d c b a | a b c d | d c b a): position p of
+       the extended array, p = 0 .. n_env + 2 r - 1.  It is not materialised (21 KB of mostly zeros kept this
+       kernel at four workgroups per CU): the few reads of the smoothing loop below compute their sample */
     const int n_env = 2 * n_omit, period = 2 * n_env;
-    for (int p = tid; p < n_env + 2 * r; p += SBR_THREADS) {
+    auto ext_at = [&](int p) {
         int m = (p - r) % period;
         if (m < 0)
             m += period;
         if (m >= n_env)
             m = period - 1 - m;
-        ext[p] = (m < n_omit) ? ln[cut + m] : 0.0;
-    }
-    __syncthreads();
+        return (m < n_omit) ? ln[cut + m] : 0.0;
+    };
     /* correlate1d, symmetric kernel: centre first, then the pairs from the far end
        inwards.  The envelope holds one value per omitted band at its first nob
        positions and zeros elsewhere (its mirror image puts them at -nob..-1), so
@@ -1258,14 +1258,14 @@ __global__ __launch_bounds__(SBR_THREADS) void k_sbr_recon(PacxTables T, VqDecVi
     const int nob = T.nb_long - T.first_omitted;
     for (int i = tid; i < n_omit; i += SBR_THREADS) {
         const int c = i + r;
-        double acc = ext[c] * w[r];
+        double acc = ext_at(c) * w[r];
         int d_hi = i + nob, d_lo = i - nob + 1;
         if (d_hi > r)
             d_hi = r;
         if (d_lo < 1)
             d_lo = 1;
         for (int d = d_hi; d >= d_lo; --d)
-            acc += (ext[c - d] + ext[c + d]) * w[r - d];
+            acc += (ext_at(c - d) + ext_at(c + d)) * w[r - d];
         smooth[i] = acc;
     }
     /* transposition: lines[cut + i] = spline1(freq[cut + i] / up) through the points
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(SBR_THREADS) void k_sbr_recon(PacxTables T, VqDecVi
     __syncthreads();
     /* per omitted band: scale to the smoothed envelope over the mean magnitude */
     if (tid < 64) {
-        double *mag = ext;                       /* reuse: |lines| of the band for np.mean */
+        double *mag = old;                       /* reuse: |lines| of the band for np.mean */
         for (int b = T.first_omitted; b < T.nb_long; ++b) {
             const int lo = T.band_lower_long[b], cnt = T.band_lines_long[b];
             double mx = 0.0;
@@ -1389,9 +1389,8 @@ void pacx_launch_vq_dec(const PacxTables &T, const void *view, long long n_cf, c
         hipLaunchKernelGGL(k_vq_dec_frame, dim3((unsigned)n_cf), dim3(64 * VQD_WAVES), (size_t)VQDF_SMEM, st, T, V, A);
     hipLaunchKernelGGL(k_vq_dec, dim3((unsigned)n_cf), dim3(64 * VQD_WAVES), smem, st, T, V, A);
     if (T.use_sbr) {
-        /* LDS sized for the worst case (every line above the cut): lines, mirrored
-           envelope, smoothed envelope, interpolation ordinates */
-        const size_t s2 = (size_t)(PACX_M_LONG + (2 * PACX_M_LONG + 2 * V.gauss_r) + PACX_M_LONG + PACX_M_LONG + 2) * 8;
+        /* LDS sized for the worst case (every line above the cut) */
+        const size_t s2 = (size_t)(PACX_M_LONG + PACX_M_LONG + PACX_M_LONG + 2) * 8;      /* lines, smoothed envelope, ordinates */
         hipLaunchKernelGGL(k_sbr_recon, dim3((unsigned)n_cf), dim3(SBR_THREADS), s2, st, T, V, n_cf, sbr_flag, lines,
                            status);
     }
