@@ -241,8 +241,8 @@ __global__ __launch_bounds__(64) void k_imdct_short(PacxTables T, long long n_cf
                                                    const double *__restrict__ lines_in,
                                                    double *__restrict__ blocks)
 {
-    __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
-    __shared__ __attribute__((aligned(16))) double buf[PACX_SUB][PACX_M_SHORT];
+    __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];      /* shared with the lines, as in k_imdct_long */
+    double (*buf)[PACX_M_SHORT] = (double (*)[PACX_M_SHORT])tile;
     const int lane = threadIdx.x;
     const long long cf = blockIdx.x;
     if (cf >= n_cf)
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(64) void k_imdct_short(PacxTables T, long long n_cf
     }
     __syncthreads();
     fft64x8(v, tile, T.w512, lane);
+    __syncthreads();
 #pragma unroll
     for (int k3 = 0; k3 < 8; ++k3) {
         const int k = fft64_out_index(lane, k3);
