@@ -57,14 +57,87 @@ __global__ void k_bitalloc_generic(long long n, int nb, const int32_t *__restric
         bits_out[i * nb + b] = bits[b];
 }
 
+/* np.mean(np.abs(np.take(block, arange(upto), axis=1))) of coder/detect_transients.py:14 in NumPy's order, by ONE
+ * lane: the [nCh, upto] array is summed flattened (channel-major; columns past the hop are the look-ahead
+ * zeros) by NumPy's pairwise scheme -- up to 128 elements on eight interleaved accumulators folded
+ * ((0+1)+(2+3))+((4+5)+(6+7)) plus a scalar tail, longer runs cut at n/2 rounded down to a multiple of 8 --
+ * and divided by the element count.  The recursion runs on an explicit stack in LDS (depth <= 9 for 8 x 2048
+ * elements).  Only k_transient's exact-tie path calls this. */
+__device__ __forceinline__ double transient_np_mean(const PacxPcmView &in, const short *base, int n_ch, int upto, int hop)
+{
+    __shared__ int st_lo[12], st_n[12], st_state[12];
+    __shared__ double st_left[12];
+    const long long n_el = (long long)n_ch * upto;
+    auto at = [&](int i) {
+        const int ch = i / upto, col = i - ch * upto;
+        if (col >= hop)
+            return 0.0;
+        const int c = base[(long long)ch * in.ch_stride + (long long)col * in.samp_stride];
+        return pacx_pcm16_to_f64((c < 0 ? -c : c) & 32767);
+    };
+    auto block_sum = [&](int lo, int n) {
+        if (n < 8) {
+            double r = -0.0;
+            for (int i = 0; i < n; ++i)
+                r = r + at(lo + i);
+            return r;
+        }
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            r[j] = at(lo + j);
+        const int n8 = n - (n & 7);
+        for (int i = 8; i < n8; i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                r[j] = r[j] + at(lo + i + j);
+        }
+        double s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (int i = n8; i < n; ++i)
+            s = s + at(lo + i);
+        return s;
+    };
+    int top = 0;
+    st_lo[0] = 0;
+    st_n[0] = (int)n_el;
+    st_state[0] = 0;
+    double result = 0.0;
+    while (top >= 0) {
+        const int lo = st_lo[top], n = st_n[top], state = st_state[top];
+        int cut = n / 2;
+        cut -= cut % 8;
+        if (n <= 128) {
+            result = block_sum(lo, n);
+            --top;
+        } else if (state == 0) {
+            st_state[top] = 1;
+            ++top;
+            st_lo[top] = lo;
+            st_n[top] = cut;
+            st_state[top] = 0;
+        } else if (state == 1) {
+            st_left[top] = result;
+            st_state[top] = 2;
+            ++top;
+            st_lo[top] = lo + cut;
+            st_n[top] = n - cut;
+            st_state[top] = 0;
+        } else {
+            result = st_left[top] + result;
+            --top;
+        }
+    }
+    return result / (double)n_el;
+}
+
 /* Block-switching caller: parTransientDetect
  * (coder/detect_transients.py:5-23) on (hop || 1024 zeros), the only input the
  * reference's driver ever gives it (coder/pacfile.py:728-732).  One wave per hop:
  * per channel the peak |x| and its first position, then the mean of |x| over the
  * first min(max_ch(argmax)+500, 2048) columns of BOTH channels (zeros past 1024),
  * transient = any(peak / avg > 4.5); avg == 0 -> not a transient.
- * |x| = 2 (|c| & 32767) / 65535; the sum is taken exactly in integers and scaled
- * once (the reference adds the float fractions pairwise: same value to ~1e-16). */
+ * |x| = 2 (|c| & 32767) / 65535; the sum is taken exactly in integers, which decides peak / avg > 4.5
+ * exactly; at an exact tie the reference's rounding decides and its float mean is redone in its order. */
 __global__ __launch_bounds__(64) void k_transient(PacxPcmView in, long long n_hops, int hop,
                                                   uint8_t *__restrict__ transient)
 {
@@ -155,9 +228,24 @@ __global__ __launch_bounds__(64) void k_transient(PacxPcmView in, long long n_ho
     if (lane == 0) {
         bool tr = false;
         if (total > 0) {
-            const double avg = ((double)total * (2.0 / 65535.0)) / (double)((long long)in.n_ch * upto);
-            for (int ch = 0; ch < n_ch; ++ch)
-                tr = tr || (pacx_pcm16_to_f64(peak_c[ch]) / avg > 4.5);
+            /* peak / avg = P n / S in integers (P the peak code, S the sum of the codes, n = nCh * upto): against
+               4.5 that is 2 P n against 9 S.  Unequal integers differ by at least one part in 1.2e9, far above any
+               rounding of the reference's float arithmetic, so the integer comparison IS its decision -- except
+               at an exact tie, where the reference's par is 4.5 up to the rounding of its pairwise float mean
+               and lands on either side: then (rare: quiet passages of small codes) that mean is redone here in
+               NumPy's order */
+            const long long n_el = (long long)in.n_ch * upto;
+            bool tie = false;
+            for (int ch = 0; ch < n_ch; ++ch) {
+                const long long lhs = 2ll * peak_c[ch] * n_el, rhs = 9ll * total;
+                tr = tr || lhs > rhs;
+                tie = tie || lhs == rhs;
+            }
+            if (tie && !tr) {
+                const double avg = transient_np_mean(in, base, n_ch, upto, hop);
+                for (int ch = 0; ch < n_ch; ++ch)
+                    tr = tr || (pacx_pcm16_to_f64(peak_c[ch]) / avg > 4.5);
+            }
         }
         transient[h] = tr ? 1 : 0;
     }

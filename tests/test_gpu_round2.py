@@ -457,3 +457,58 @@ def test_scalar_sbr_block_mirrors(A, torch):
             last, cur = cur, nxt
         f.Close(cp2)
         assert open(path, "rb").read() == want
+
+
+# ------------------------------------------- transient detector: exact ties of peak / avg against 4.5
+def _tie_hop(rng, n_ch):
+    """one hop [1024, n_ch] of int16 whose peak-to-average ratio is EXACTLY 4.5 in rational arithmetic:
+    peak code P = 9 q in channel 0 at column a, upto = a + 500 columns counted (zeros past 1024), the codes
+    of all channels over those columns summing to 2 P n / 9 with n = n_ch * upto"""
+    while True:
+        q = int(rng.integers(1, 40))
+        P = 9 * q
+        a = int(rng.integers(0, 1024))
+        upto = min(a + 500, 2048)
+        cols = min(upto, 1024)
+        S = 2 * q * n_ch * upto                       # sum over the counted columns of every channel
+        m = np.zeros((n_ch, 1024), dtype=np.int64)
+        free = [(ch, i) for ch in range(n_ch) for i in range(cols) if (ch, i) != (0, a)]
+        rest = S - P
+        # codes before the peak stay below P (the first maximum is at a); the others at most P - 1 as well
+        if rest < 0 or rest > (P - 1) * len(free):
+            continue
+        base, extra = divmod(rest, len(free))
+        vals = np.full(len(free), base, dtype=np.int64)
+        vals[rng.permutation(len(free))[:extra]] += 1
+        for _ in range(4 * len(free)):                # shuffle mass around, the sum stays
+            i, j = rng.integers(0, len(free), 2)
+            d = int(rng.integers(0, P))
+            if vals[i] + d <= P - 1 and vals[j] - d >= 0:
+                vals[i] += d
+                vals[j] -= d
+        for (ch, i), v in zip(free, vals):
+            m[ch, i] = v
+        m[0, a] = P
+        for ch in range(n_ch):                        # columns past upto do not count: anything below the peak
+            m[ch, cols:] = rng.integers(0, P, 1024 - cols)
+        assert m[:, :cols].sum() == S and m.max() == P and int(np.argmax(m[0])) == a
+        sign = rng.choice([-1, 1], size=m.shape)
+        return (m * sign).T.astype(np.int16)
+
+
+@pytest.mark.parametrize("n_ch", [1, 2])
+def test_transient_detector_exact_ties(A, torch, n_ch):
+    """Quiet passages of small codes put peak / avg exactly on the detector's threshold now and then (a parity
+    soak found one stream in two thousand): coder/detect_transients.py:20-21 then goes by the rounding of its
+    pairwise float mean.  k_transient decides by integers and redoes that mean in NumPy's order at a tie:
+    600 constructed ties per channel count, decisions equal to the reference expression's."""
+    rng = np.random.default_rng(2024 + n_ch)
+    hops = [_tie_hop(rng, n_ch) for _ in range(600)]
+    pcm = np.concatenate(hops)
+    want = A.detect_transients.hop_transients(
+        np.stack([A.pcmfile.codes_to_fraction(pcm[:, ch]) for ch in range(n_ch)]).reshape(n_ch, len(hops), 1024).transpose(1, 0, 2))
+    enc = A.context.encoder(48000, 128 / 48.0)
+    tr, _ = enc.transient_flags(A.pacfile.device_stream(enc, pcm), len(hops))
+    got = tr.cpu().numpy().astype(bool)
+    assert got.tolist() == want.tolist(), f"{int((got != want).sum())} of {len(hops)} tie hops decided differently"
+    print(f"exact ties, {n_ch} channel(s): {int(want.sum())} of {len(hops)} are transients to the reference")
