@@ -307,7 +307,10 @@ __global__ __launch_bounds__(256) void k_frame_lists(const uint8_t *__restrict__
 }
 
 /* the same lists for batches of up to a few thousand frames, by ONE workgroup: no counters to
- * zero first (a memset launch), no atomics, and the lists come out in frame order */
+ * zero first (a memset launch), no atomics, and the lists come out in frame order.  The kernel sits at
+ * the head of the long-coded chain of a block-switched batch, so it is built around ONE round trip to
+ * memory and ONE barrier: a thread owns up to 16 consecutive frames, reads their flags together, and the
+ * counts are scanned over the wave (shuffles) and over the 16 waves (LDS). */
 #define LISTS_SMALL_MAX 16384
 __global__ __launch_bounds__(1024) void k_frame_lists_small(const uint8_t *__restrict__ flags, long long n_frames,
                                                             int n_ch, int32_t *__restrict__ list_long,
@@ -316,44 +319,57 @@ __global__ __launch_bounds__(1024) void k_frame_lists_small(const uint8_t *__res
 {
     __shared__ int ws[16], wl[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int run_s = 0, run_l = 0;                              /* frames placed so far (all threads agree) */
-    for (long long base = 0; base < n_frames; base += 1024) {
-        const long long f = base + tid;
-        const bool in_range = f < n_frames;
-        const bool is_short = in_range && (flags[f] & 2u);
-        const bool is_long = in_range && !is_short;
-        const unsigned long long ms = __ballot(is_short), ml = __ballot(is_long);
-        if (lane == 0) {
-            ws[wv] = __popcll(ms);
-            wl[wv] = __popcll(ml);
-        }
-        __syncthreads();
-        int before_s = 0, before_l = 0, all_s = 0, all_l = 0;
+    const int per = (int)((n_frames + 1023) / 1024);       /* <= 16 */
+    const long long f0 = (long long)tid * per;
+    unsigned valid = 0, shorts = 0;                        /* bit j: frame f0 + j */
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            before_s += w < wv ? ws[w] : 0;
-            before_l += w < wv ? wl[w] : 0;
-            all_s += ws[w];
-            all_l += wl[w];
+    for (int j = 0; j < LISTS_SMALL_MAX / 1024; ++j) {
+        if (j < per && f0 + j < n_frames) {
+            valid |= 1u << j;
+            if (flags[f0 + j] & 2u)
+                shorts |= 1u << j;
         }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (is_short) {
-            const int at = (run_s + before_s + __popcll(ms & below)) * n_ch;
+    }
+    const int ns = __popc(shorts), nl = __popc(valid & ~shorts);
+    int ss = ns, sl = nl;                                  /* inclusive scans over the wave */
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int a = __shfl_up(ss, off, 64), b = __shfl_up(sl, off, 64);
+        if (lane >= off) {
+            ss += a;
+            sl += b;
+        }
+    }
+    if (lane == 63) {
+        ws[wv] = ss;
+        wl[wv] = sl;
+    }
+    __syncthreads();
+    int at_s = ss - ns, at_l = sl - nl, all_s = 0, all_l = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        at_s += w < wv ? ws[w] : 0;
+        at_l += w < wv ? wl[w] : 0;
+        all_s += ws[w];
+        all_l += wl[w];
+    }
+    for (int j = 0; j < per; ++j) {
+        if (!((valid >> j) & 1u))
+            break;
+        const long long f = f0 + j;
+        if ((shorts >> j) & 1u) {
             for (int c = 0; c < n_ch; ++c)
-                list_short[at + c] = (int32_t)(f * n_ch + c);
-        }
-        if (is_long) {
-            const int at = (run_l + before_l + __popcll(ml & below)) * n_ch;
+                list_short[at_s * n_ch + c] = (int32_t)(f * n_ch + c);
+            ++at_s;
+        } else {
             for (int c = 0; c < n_ch; ++c)
-                list_long[at + c] = (int32_t)(f * n_ch + c);
+                list_long[at_l * n_ch + c] = (int32_t)(f * n_ch + c);
+            ++at_l;
         }
-        run_s += all_s;
-        run_l += all_l;
-        __syncthreads();
     }
     if (tid == 0) {
-        counts[0] = run_l * n_ch;
-        counts[1] = run_s * n_ch;
+        counts[0] = all_l * n_ch;
+        counts[1] = all_s * n_ch;
     }
 }
 
