@@ -184,8 +184,11 @@ def classify_scalar_mismatch(A, case, pcm, got, want):
       alloc-follows-smr  the allocations differ, the flag is down, but the product's allocation IS the oracle's
                  BitAlloc of the product's own SMRs, and those lie within 1e-9 dB of the oracle's: an earlier pass of
                  the water-filling loop (not the final one, which the flag watches) sat on a rounding boundary;
-      zero-line  only sign bits of zero-magnitude mantissas differ, on lines whose exact value is zero (the oracle's
-                 own line is below 1e-12 of the block maximum: the sign of NumPy's FFT rounding noise);
+      zero-line  a line whose exact value is zero (the oracle's own line is below 1e-12 of the block maximum).  Either
+                 only sign bits of zero-magnitude mantissas differ there (the sign of NumPy's FFT rounding noise), or
+                 the allocation differs and the oracle's SMRs, redone with those lines at exactly 0.0, are the
+                 product's: the reference's SPL() gives an exactly zero intensity 1e-8 (+16 dB) and a 1e-40 one the
+                 -30 dB floor, so the line's level hangs on whether the FFT's rounding left 0.0 or 1e-21;
       degenerate a quarter or more of the (sub-)block's lines are such rounding noise in the oracle's own MDCT (constant,
                  period-2 / period-4 and similar inputs: clipped stretches, +-2 LSB tones) or it holds a handful of
                  impulses (a flat spectrum): which noise bins are "peaks", and everything downstream, is the
@@ -272,8 +275,21 @@ def classify_scalar_mismatch(A, case, pcm, got, want):
                 mine = smr[s_ * nb:(s_ + 1) * nb]
                 again = po.bit_alloc(budget, max_mant, nb, bands.nLines, mine)
                 worst = float(np.max(np.abs(st["smr"][:nb] - mine)))
-                verdicts.add("alloc-follows-smr" if again.tolist() == a[1] and worst < 1e-9 else
-                             f"REAL (allocation; SMRs {worst:.1e} dB apart)")
+                if again.tolist() == a[1] and worst < 1e-9:
+                    verdicts.add("alloc-follows-smr")
+                    continue
+                # SPL() takes 1e-8 (+16 dB) for an intensity that is EXACTLY zero and the -30 dB floor for one of
+                # 1e-40 (coder/psychoac.py:13-24): a line that is zero in exact arithmetic gets one or the other
+                # depending on whether the FFT's rounding left 0.0 or 1e-21 -- 46 dB apart in that line's SMR.
+                # The oracle's SMRs redone with its rounding-noise lines set to exact zeros must then be the product's
+                sub = blk[448 + 128 * s_:448 + 128 * s_ + 256] if short else blk
+                X0 = np.where(np.abs(X) < 1e-12 * top, 0.0, X)
+                ov = po.scale_factor(top, p.nScaleBits)
+                smr0 = po.calc_smrs(po.pcm16_to_fraction(sub), X0 * (1 << ov), ov, case["sr"], bands)
+                if again.tolist() == a[1] and np.any(X0 != X) and float(np.max(np.abs(smr0[:nb] - mine))) < 1e-9:
+                    verdicts.add("zero-line")
+                else:
+                    verdicts.add(f"REAL (allocation; SMRs {worst:.1e} dB apart)")
             elif a[0] != b[0] or a[2] != b[2]:
                 verdicts.add("REAL (overall scale or scale factors)")
             else:
