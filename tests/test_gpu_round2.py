@@ -512,3 +512,30 @@ def test_transient_detector_exact_ties(A, torch, n_ch):
     got = tr.cpu().numpy().astype(bool)
     assert got.tolist() == want.tolist(), f"{int((got != want).sum())} of {len(hops)} tie hops decided differently"
     print(f"exact ties, {n_ch} channel(s): {int(want.sum())} of {len(hops)} are transients to the reference")
+
+
+# ------------------------------------------- an exactly zero MDCT line and the reference's SPL(0) rule
+def test_exactly_zero_line_takes_the_references_spl_rule(A, torch):
+    """coder/psychoac.py:13-24: SPL() replaces an intensity that is EXACTLY zero by 1e-8 (+16 dB) before the log,
+    while 1e-40 ends on the -30 dB floor.  A block whose last hop is written twice ([a, a], what the reference's
+    driver does at the end of every file) with a sparse a has lines that are zero in exact arithmetic; this build's
+    FFT returns 0.0 for them (pocketfft leaves 1e-21: the parity soak's 'zero-line' class).
+    Whatever the FFT returns, k_mask must apply the reference's rule to it: the oracle's CalcSMRs fed the PRODUCT's
+    lines gives the product's SMRs, and the exact zeros are what carries the band maxima (+16 dB against -30)."""
+    a = np.zeros(1024, np.int16)
+    a[[3, 18, 73, 97, 147, 416, 998]] = -1
+    a[[21, 505, 680]] = 1
+    blk = np.concatenate((a, a))                                        # seed 102376 of the soak, channel 1
+    enc = A.context.encoder(48000, 96 / 48.0)
+    view = A.engine.PcmView.frames(torch.as_tensor(blk, device=enc.device).view(1, 1, 2048))
+    lines, scale = enc.mdct(view, want_scale=True)
+    smr = enc.smr(view, lines).cpu().numpy()[0]
+    lines, ov = lines.cpu().numpy()[0], int(scale.cpu().numpy()[0])
+    assert np.count_nonzero(lines == 0.0) >= 1 and np.max(np.abs(lines)) > 0
+    p = po.make_params(48000, 2, 96)
+    data = po.pcm16_to_fraction(blk)
+    want = po.calc_smrs(data, lines * (1 << ov), ov, 48000, p.sfBands)
+    nb = p.sfBands.nBands
+    assert np.max(np.abs(smr[:nb] - want)) < 1e-9
+    floor_only = po.calc_smrs(data, np.where(lines == 0.0, 1e-30, lines) * (1 << ov), ov, 48000, p.sfBands)
+    assert np.max(want - floor_only) > 40.0                             # the rule decides some band by ~46 dB
