@@ -77,6 +77,11 @@ class Encoder:
             AssignMDCTLinesFromFreqLimits(N_LONG, self.sample_rate))
         self.sfBandsShort = sf_bands_short or ScaleFactorBands(
             AssignMDCTLinesFromFreqLimits(N_SHORT, self.sample_rate))
+        for bands in (self.sfBands, self.sfBandsShort):
+            if np.any(np.asarray(bands.nLines) <= 0):
+                # a band without lines (the default 25-band table below 31 kHz: bands above Nyquist are empty): the
+                # reference gets as far as CalcSMRs' np.amax over the empty band (coder/psychoac.py:289) and raises
+                raise ValueError("zero-size array to reduction operation maximum which has no identity")
 
         keep = self._host = {}
         def f64(name, arr):

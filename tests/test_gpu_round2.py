@@ -539,3 +539,23 @@ def test_exactly_zero_line_takes_the_references_spl_rule(A, torch):
     assert np.max(np.abs(smr[:nb] - want)) < 1e-9
     floor_only = po.calc_smrs(data, np.where(lines == 0.0, 1e-30, lines) * (1 << ov), ov, 48000, p.sfBands)
     assert np.max(want - floor_only) > 40.0                             # the rule decides some band by ~46 dB
+
+
+# ------------------------------------------- sample rates the reference's band table does not reach
+@pytest.mark.parametrize("sr", [16000, 30000])
+def test_sample_rate_with_an_empty_band_raises_like_the_reference(A, sr):
+    """Below 31 kHz the 25-band table has bands above Nyquist, without lines; the reference raises ValueError from
+    np.amax over the empty band in CalcSMRs (coder/psychoac.py:289) on its first block, and so do the oracle and
+    the host mirror (the C ABI refuses such a layout at pacx_create: PACX_E_ARG 'band with no lines')."""
+    pcm = A.synth.stream(4, 2, 48000, seed=3)
+    with pytest.raises(ValueError, match="zero-size array"):
+        po.encode_stream(pcm, sr, 96, False)
+    with pytest.raises(ValueError, match="zero-size array"):
+        A.pacfile.encode_stream(pcm, sr, 96)
+
+
+def test_lowest_sample_rate_the_band_table_reaches(A):
+    """31.5 kHz: the last band still has lines (16 long, 2 short): bytes against the oracle, block switching on"""
+    pcm = A.synth.stream(6, 2, 48000, seed=4)
+    pcm[3 * 1024 + 100:3 * 1024 + 140] = 28000
+    assert A.pacfile.encode_stream(pcm, 31500, 96, True) == po.encode_stream(pcm, 31500, 96, True)
