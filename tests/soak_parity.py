@@ -67,7 +67,7 @@ def programme(seed, n_hops, n_ch, sr):
 CODERS = ["scalar", "scalar_bs", "vq"]
 
 
-def draw_case(seed, coders=None, rates=None):
+def draw_case(seed, coders=None, rates=None, channels=None):
     rng = np.random.default_rng(seed ^ 0x5EED)
     coder = CODERS[int(rng.integers(0, 3))]
     if coders and coder not in coders:                     # a restricted run keeps the other draws of the seed
@@ -76,6 +76,8 @@ def draw_case(seed, coders=None, rates=None):
     if rates:
         sr = rates[seed % len(rates)]
     n_ch = int(rng.choice([1, 2, 3], p=[0.15, 0.75, 0.1]))
+    if channels:
+        n_ch = channels[seed % len(channels)]
     if coder == "vq":
         kbps = int(rng.choice([48, 64, 96, 128, 192, 256]))
         n_hops = int(rng.integers(8, 25))
@@ -363,6 +365,7 @@ def main():
     ap.add_argument("--seed0", type=int, default=1000)
     ap.add_argument("--seeds", default="", help="comma-separated seeds to replay instead of a timed run")
     ap.add_argument("--rates", default="", help="comma-separated sample rates instead of the 32 / 44.1 / 48 / 96 kHz mix")
+    ap.add_argument("--channels", default="", help="comma-separated channel counts instead of the 1 / 2 / 3 mix")
     ap.add_argument("--coders", default="", help="comma-separated subset of scalar,scalar_bs,vq (default: all three)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "soak.txt"))
     a = ap.parse_args()
@@ -375,26 +378,27 @@ def main():
     coders = [c for c in a.coders.split(",") if c] or None
     assert not coders or all(c in CODERS for c in coders)
     rates = [int(r) for r in a.rates.split(",") if r] or None
+    channels = [int(r) for r in a.channels.split(",") if r] or None
     if a.seeds:
         replay = [int(x) for x in a.seeds.split(",")]
         seeds = iter(())
         deadline = 0.0
-        pending = [pool.apply_async(oracle_side, (draw_case(x, coders, rates),)) for x in replay]
+        pending = [pool.apply_async(oracle_side, (draw_case(x, coders, rates, channels),)) for x in replay]
     else:
         seeds = iter(range(a.seed0, a.seed0 + 10 ** 6))
-        pending = [pool.apply_async(oracle_side, (draw_case(next(seeds), coders, rates),)) for _ in range(2 * a.workers)]
+        pending = [pool.apply_async(oracle_side, (draw_case(next(seeds), coders, rates, channels),)) for _ in range(2 * a.workers)]
     tally, bad, raised, dec_raised, last_print, noise = {}, [], 0, 0, time.time(), {}
     log = open(a.out, "w")
     def say(s):
         print(s, flush=True)
         log.write(s + "\n")
         log.flush()
-    say(f"parity soak: {a.minutes} min, {a.workers} oracle workers, seeds from {a.seed0}" + (f", coders {coders}" if coders else "") + (f", rates {rates}" if rates else ""))
+    say(f"parity soak: {a.minutes} min, {a.workers} oracle workers, seeds from {a.seed0}" + (f", coders {coders}" if coders else "") + (f", rates {rates}" if rates else "") + (f", channels {channels}" if channels else ""))
     while pending:
         res = pending.pop(0)
         case, want, dec_want, secs = res.get()
         if time.time() < deadline:
-            pending.append(pool.apply_async(oracle_side, (draw_case(next(seeds), coders, rates),)))
+            pending.append(pool.apply_async(oracle_side, (draw_case(next(seeds), coders, rates, channels),)))
         pcm = programme(case["seed"], case["n_hops"], case["n_ch"], case["sr"])
         vq = case["coder"] == "vq"
         try:
