@@ -65,6 +65,8 @@ def programme(seed, n_hops, n_ch, sr):
 
 
 CODERS = ["scalar", "scalar_bs", "vq"]
+EXTRA_CODERS = ["scalar_sbr"]        # only with --coders: scalar mantissas in an SBR file (the reference's driver never selects it;
+                                     # defined while no omitted band gets bits, TypeError otherwise: DESIGN.md section 7)
 
 
 def draw_case(seed, coders=None, rates=None, channels=None):
@@ -81,6 +83,9 @@ def draw_case(seed, coders=None, rates=None, channels=None):
     if coder == "vq":
         kbps = int(rng.choice([48, 64, 96, 128, 192, 256]))
         n_hops = int(rng.integers(8, 25))
+    elif coder == "scalar_sbr":
+        kbps = int(rng.choice([24, 32, 48, 64, 96]))
+        n_hops = int(rng.integers(8, 49))
     else:
         kbps = int(rng.choice([32, 64, 96, 128, 192, 320]))
         n_hops = int(rng.integers(16, 97))
@@ -95,7 +100,7 @@ def oracle_side(case):
     vq = case["coder"] == "vq"
     try:
         pac = pv.encode_stream_vq(pcm, case["sr"], case["kbps"]) if vq else \
-            po.encode_stream(pcm, case["sr"], case["kbps"], case["coder"] == "scalar_bs")
+            po.encode_stream(pcm, case["sr"], case["kbps"], case["coder"] != "scalar", use_sbr=case["coder"] == "scalar_sbr")
     except Exception as e:                                                # the oracle follows the reference's raises
         return case, None, "raised " + type(e).__name__, time.time() - t0
     try:
@@ -242,17 +247,18 @@ def classify_scalar_mismatch(A, case, pcm, got, want):
                  reference's FFT rounding (DESIGN.md section 2, "known limit");
     anything else is returned as 'REAL'."""
     from oracle import pac_oracle as po
-    bs = case["coder"] == "scalar_bs"
-    p = po.make_params(case["sr"], case["n_ch"], case["kbps"])
+    bs = case["coder"] != "scalar"
+    sbr = case["coder"] == "scalar_sbr"            # long blocks: another budget and overall scale -- only the guard flag,
+    p = po.make_params(case["sr"], case["n_ch"], case["kbps"])        # the zero-line and the degenerate tests apply
     hdr = len(po.pac_header(p, len(pcm)))
     if got[:hdr] != want[:hdr]:
         return ["REAL: header"]
     bg, bw = _blocks(got, hdr), _blocks(want, hdr)
     if len(bg) != len(bw):
         return [f"REAL: {len(bg)} blocks against {len(bw)}"]
-    key = (case["sr"], case["kbps"])
+    key = (case["sr"], case["kbps"], sbr)
     if key not in _GUARD_ENCODERS:
-        _GUARD_ENCODERS[key] = A.engine.Encoder(case["sr"], case["kbps"] / (case["sr"] / 1000), guard=True)
+        _GUARD_ENCODERS[key] = A.engine.Encoder(case["sr"], case["kbps"] / (case["sr"] / 1000), guard=True, use_sbr=sbr)
     enc = _GUARD_ENCODERS[key]
     planar = A.pacfile.device_stream(enc, pcm)
     flags = enc.transient_flags(planar, len(pcm) // 1024, 1024)[1] if bs else None
@@ -309,7 +315,9 @@ def classify_scalar_mismatch(A, case, pcm, got, want):
             if degenerate(po, blk[448 + 128 * s_:448 + 128 * s_ + 256] if short else blk, X):
                 verdicts.add("degenerate")                 # the reference's FFT rounding noise decides this (sub-)block
                 continue
-            if a[1] != b[1]:
+            if a[1] != b[1] and sbr and not short:
+                verdicts.add("REAL (allocation of a long block of an SBR file: not taken apart)")
+            elif a[1] != b[1]:
                 if smr is None:
                     view = A.engine.PcmView.frames(torch.as_tensor(np.ascontiguousarray(blk), device=enc.device).view(1, 1, 2048))
                     smr = enc.smr(view, enc.mdct(view, [tuple(fx)], short=short), short=short).cpu().numpy()[0]
@@ -376,7 +384,7 @@ def main():
     A = importlib.import_module("audio_codec_amd")
     deadline = time.time() + 60.0 * a.minutes
     coders = [c for c in a.coders.split(",") if c] or None
-    assert not coders or all(c in CODERS for c in coders)
+    assert not coders or all(c in CODERS + EXTRA_CODERS for c in coders)
     rates = [int(r) for r in a.rates.split(",") if r] or None
     channels = [int(r) for r in a.channels.split(",") if r] or None
     if a.seeds:
@@ -403,7 +411,7 @@ def main():
         vq = case["coder"] == "vq"
         try:
             got = A.pacfile.encode_stream(pcm, case["sr"], case["kbps"], block_switching=case["coder"] != "scalar",
-                                          use_vq=vq, use_sbr=vq and case["kbps"] < 128)
+                                          use_vq=vq, use_sbr=(vq and case["kbps"] < 128) or case["coder"] == "scalar_sbr")
         except Exception as e:
             got = None
             err = repr(e)
