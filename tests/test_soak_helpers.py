@@ -16,6 +16,10 @@ def test_cases_are_reproducible_and_cover_the_coders():
     assert {c["coder"] for c in cases} == {"scalar", "scalar_bs", "vq"}
     assert {c["sr"] for c in cases} == {32000, 44100, 48000, 96000}
     assert {c["n_ch"] for c in cases} == {1, 2, 3}
+    only = [S.draw_case(s, ["vq"], [88200, 192000], [4, 8]) for s in range(50)]
+    assert {c["coder"] for c in only} == {"vq"} and {c["sr"] for c in only} == {88200, 192000}
+    assert {c["n_ch"] for c in only} == {4, 8}
+    assert {S.draw_case(s, ["scalar_sbr"])["coder"] for s in range(20)} == {"scalar_sbr"}
     a = S.programme(1234, 8, 2, 48000)
     assert a.dtype == np.int16 and a.shape == (8 * 1024, 2)
     assert np.array_equal(a, S.programme(1234, 8, 2, 48000))
