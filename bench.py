@@ -3,7 +3,12 @@
 encode, 48 kHz, 1024-line long blocks, 128 kb/s/ch; MDCT HBM GB/s vs roofline).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 from the plain command: this process starts `python -m torch.distributed.run --nproc-per-node N`
+on this very file as a CHILD process (before anything here touches the GPU; it never does itself),
+relays rank 0's JSON line and the exit code -- the way the reference starts its own workers from one
+command (coder/pacfile.py:771-781, Pool(8).starmap).  Launched under torch.distributed.run already
+(WORLD_SIZE set), it is a rank and runs the bench.
 
 A step = one pass of the whole hot path over one device-resident batch of
 BASELINE configs[1]: 4096 synthetic 48 kHz stereo frames (8192 channel-frames) per
@@ -42,6 +47,27 @@ KBPS = 128
 MDCT_BYTES_PER_CF = 1024 * 2 + 1024 * 8      # int16 hop in + float64 lines out
 HBM_PEAK_GBS = 8000.0
 CORPUS_FRAMES = 1 << 20        # configs[4]: 1 048 576 stereo frames
+# the reference ITSELF (its own Python, imported in the build container where /root/reference exists; it
+# cannot travel to the GPU box): BASELINE.md section 3.1, tools/ref_cpu_timing.py -- quoted, not measured here
+REFERENCE_CPU = {"one_process": 32.2, "pool8": 234.0, "unit": "channel-frames/s", "cores": 8,
+                 "sample": "the reference's own PCMFile -> PACFile loop (coder/pacfile.py:674-757) on the first 120 "
+                           "hops of test_signals/harpsichord.wav, config 1 settings; one process, and eight the way "
+                           "its driver parallelises (Pool(8), coder/pacfile.py:780-781), 8-core build container",
+                 "source": "BASELINE.md section 3.1 (tools/ref_cpu_timing.py); quoted, not measured by this run"}
+
+
+def step_kernels(workload, n_cf):
+    """per-kernel figures of the step from the COMMITTED profiles of this command (rocprofv3 kernel trace + SQ
+    counter passes, tools/step_kernels.py -> profiles/r03_step_kernels.json): average microseconds, VALU-busy
+    fraction, PMC bytes.  Quoted with their source; a bench run by itself has no access to the counters."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_step_kernels.json")))
+        e = d.get(workload)
+        if e and e.get("cf_per_step") == n_cf:
+            return dict(e, source="profiles/r03_step_kernels.json (committed profile of this command; not measured by this run)")
+    except Exception:
+        pass
+    return None
 
 
 # ------------------------------------------------------------------ CPU baseline
@@ -105,7 +131,8 @@ def cpu_baseline(vq_kbps=None, frames_per_core=None):
            "sample": f"{cores} processes (usable cores: {cores}, os.cpu_count() = {os.cpu_count()}) x {per} stereo "
                      f"frames of the same kind of synthetic stream, {what}, {wall:.1f} s wall including process start-up",
            "one_core": {"value": per * N_CH / dt1, "cores": 1,
-                        "sample": f"{per} stereo frames ({per * N_CH} cf), {dt1:.1f} s"}}
+                        "sample": f"{per} stereo frames ({per * N_CH} cf), {dt1:.1f} s"},
+           "reference": REFERENCE_CPU}
     if not vq_kbps:
         ex = np.load(os.path.join(ROOT, "tests", "golden", "excerpt_harpsichord.npz"))
         pcm = ex["pcm"][:64 * 1024]
@@ -176,6 +203,65 @@ def verify_against_oracle(pcm, sample_rate, kbps, vq_kbps, flags, payload_rows, 
     return ok
 
 
+# ------------------------------------------------------------------ N ranks from one command
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as
+    children (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 at a free port),
+    pass their stderr through, print rank 0's ONE JSON line, return the launcher's exit code.
+    This process never initialises the GPU (no torch import here): the ranks are child
+    processes, not an exec of a process that holds the device."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = []
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            lines.append(ln.rstrip("\n"))
+        else:                                   # anything else a rank printed: to stderr, the JSON line stays alone
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench: expected one JSON line from rank 0, got {len(lines)}\n")
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
+def launcher_selftest(args):
+    """--launcher-selftest: what a rank does when only the launch itself is under test (the CPU test of
+    `python bench.py --gpus 2` in a container without a GPU): join the process group over gloo, see every
+    rank, rank 0 prints one line.  No encode, no value."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} ranks"
+    dist.init_process_group("gloo")
+    seen = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no encode)", "value": None, "unit": "channel-frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ranks_seen": [int(t.item()) for t in seen]}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,9 +272,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--mdct-launches", type=int, default=50)
-    ap.add_argument("--graph", action="store_true",
-                    help="replay a captured hipGraph of the step instead of launching its kernels one by one "
-                         "(measured slower on ROCm 7.2: 0.408 vs 0.397 ms/step -- the queue is GPU-bound)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=True,
+                    help="(default) the step's kernel launches are captured once into a hipGraph and the timed "
+                         "regions replay it: the launch gaps between the step's kernels go (DESIGN.md 5.1: +4 %% "
+                         "on the headline step)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="launch the step's kernels one by one instead")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="ranks only join the process group (gloo) and rank 0 prints one line: tests the "
+                         "self-launch of `bench.py --gpus N` where there is no GPU")
     ap.add_argument("--workload", choices=["scalar128", "vq128", "vq96", "bs128", "shipped128", "shipped96"],
                     default="scalar128",
                     help="scalar128 = BASELINE configs[1] (the headline); vq128 / vq96 = the gain-shape "
@@ -204,6 +296,12 @@ def main():
     ap.add_argument("--corpus-frames", type=int, default=CORPUS_FRAMES)
     args = ap.parse_args()
 
+    if (args.gpus > 1 or os.environ.get("PACX_BENCH_FORCE_DIST")) and "WORLD_SIZE" not in os.environ:
+        # the plain command: start the N ranks ourselves, as children (nothing above has touched the GPU)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.launcher_selftest:
+        return launcher_selftest(args)
+
     import torch
     import torch.distributed as dist
     import audio_codec_amd as A
@@ -216,7 +314,7 @@ def main():
     # rehearsal of that control flow on the one GPU of a test box (tests/test_gpu_rccl.py)
     multi = world > 1 or bool(os.environ.get("PACX_BENCH_FORCE_DIST"))
     if args.gpus > 1 or multi:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
+        assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} ranks"
         rehearsal = bool(os.environ.get("PACX_BENCH_ONE_GPU"))
         if rehearsal:
             # rehearsal of the N > 1 control flow on a 1-GPU box: every rank on cuda:0, the
@@ -296,10 +394,8 @@ def main():
         vq_out = {k: out[k] for k in ("overall", "bit_alloc", "status", "payload", "n_bytes")}
     do_gather = [True]
 
-    def device_step():
-        k = step_no[0] % len(bodies)
-        if gather is not None:
-            gather.wait(k)                      # the gather that last used this buffer (stream-level wait)
+    def encode_part(k):
+        """the kernels of one step, body into buffer k: what a hipGraph of the step holds"""
         if vq_kbps and block_switched:
             enc._call("pacx_transient_flags", ctypes.byref(hop_view), _ptr(tr_buf), _ptr(fl_buf), enc._stream())
             enc.encode_vq(view, fl_buf[:n_frames], vq_out)
@@ -312,6 +408,33 @@ def main():
             enc.encode_pack(view, None, out)
         enc._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(out["payload"]), _ptr(out["n_bytes"]),
                   _ptr(bodies[k]), ctypes.c_int64(cap), _ptr(total), enc._stream())
+
+    # the kernel launches of a step captured once into a hipGraph (one per body buffer) and replayed:
+    # the default.  The gather of the bodies (RCCL) stays outside the graph.
+    graphs = [None] * len(bodies)
+    if args.graph:
+        for k in range(len(bodies)):
+            encode_part(k)
+        torch.cuda.synchronize()
+        try:
+            for k in range(len(bodies)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    encode_part(k)
+                graphs[k] = g
+        except Exception as e:                      # capture not possible: plain launches
+            print(f"bench: hipGraph capture failed ({e}); launching kernels directly", file=sys.stderr)
+            graphs = [None] * len(bodies)
+        torch.cuda.synchronize()
+
+    def step():
+        k = step_no[0] % len(bodies)
+        if gather is not None:
+            gather.wait(k)                      # the gather that last used this buffer (stream-level wait)
+        if graphs[k] is not None:
+            graphs[k].replay()
+        else:
+            encode_part(k)
         if gather is not None and do_gather[0]:
             if dist.get_backend() == "gloo":            # rehearsal: stage through the host
                 host_bodies[k].copy_(bodies[k])
@@ -319,27 +442,6 @@ def main():
             else:
                 gather.launch(k, total)
         step_no[0] += 1
-
-    # optional: the kernel launches of a step captured once into a hipGraph and replayed
-    graph = None
-    if args.graph and not multi:
-        device_step()
-        torch.cuda.synchronize()
-        try:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                device_step()
-            graph = g
-        except Exception as e:                      # capture not possible: plain launches
-            print(f"bench: hipGraph capture failed ({e}); launching kernels directly", file=sys.stderr)
-            graph = None
-        torch.cuda.synchronize()
-
-    def step():
-        if graph is not None:
-            graph.replay()
-        else:
-            device_step()
 
     def sync_all():
         if gather is not None:
@@ -384,13 +486,23 @@ def main():
     assert body_bytes == int(n_bytes_h.astype(np.int64).sum()) + 4 * int(np.count_nonzero(n_bytes_h)), \
         "body size is not the sum of its records"
     verified = 0
-    if not args.no_verify and rank == 0:
+    if not args.no_verify:                 # EVERY rank checks its own output (its own stream or shard)
         picks = sorted(set(np.linspace(0, n_frames - 1, 16).astype(int).tolist()))
         rows = {f * N_CH + ch: out["payload"][f * N_CH + ch].cpu().numpy() for f in picks for ch in range(N_CH)}
         flags_h = fl_buf[:n_frames].cpu().numpy() if block_switched else None
         stream_h = pcm if pcm is not None else np.ascontiguousarray(shard[:, 1024:].T)
         halo_h = None if pcm is not None else np.ascontiguousarray(shard[:, :1024].T)
         verified = verify_against_oracle(stream_h, sample_rate, kbps, vq_kbps, flags_h, rows, n_bytes_h, picks, halo_h)
+    verified_per_rank = [verified]
+    if multi:                              # rank 0 reports every rank's count; a rank whose check fails has raised
+        cnt = torch.tensor([verified], dtype=torch.int64,
+                           device=torch.device("cpu") if dist.get_backend() == "gloo" else dev)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        verified_per_rank = [int(c.item()) for c in cnts]
+        if not args.no_verify:
+            assert min(verified_per_rank) > 0, f"a rank verified nothing: {verified_per_rank}"
+        verified = sum(verified_per_rank)
 
     # ---- MDCT kernel alone: HIP events on the stream the kernel runs on
     mdct_cf = min(n_cf, 2 * FRAMES_PER_GPU) if corpus else n_cf
@@ -425,7 +537,7 @@ def main():
     # the figure of the committed PMC passes of this same command is quoted, with its
     # source, when the launch geometry matches
     traffic, traffic_src = None, None
-    for name in ("r02_mdct_pmc.json", "r01_mdct_pmc.json"):
+    for name in ("r03_mdct_pmc.json", "r02_mdct_pmc.json", "r01_mdct_pmc.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if pmc["cf_per_launch"] == mdct_cf:
@@ -478,9 +590,13 @@ def main():
                        "ms_per_step_regions": [r / args.steps * 1e3 for r in regions],
                        "body_bytes_per_step": body_bytes,
                        "verified": f"{verified} channel-frames of the timed run's output re-encoded by the oracle, "
-                                   "payload bytes equal" if verified else "not verified",
-                       "launch": "hipGraph replay of the captured step" if graph is not None else "direct launches",
-                       "sharding": f"{world} x frame-range shards, no data-path collective"},
+                                   "payload bytes equal" + (f" (per rank: {verified_per_rank})" if multi else "")
+                                   if verified else "not verified",
+                       "verified_per_rank": verified_per_rank,
+                       "launch": "hipGraph replay of the captured step" if graphs[0] is not None else "direct launches",
+                       "sharding": f"{world} x frame-range shards, no data-path collective; process group: "
+                                   + (f"{dist.get_backend()} with {dist.get_world_size()} ranks" if multi
+                                      else "none (one process)")},
             "roofline": {"kernel": "k_mdct_long_x2p (window + MDCT, int16 in, float64 lines out; two frames per wave alternating on one FFT tile, PCM prefetched a whole iteration ahead)",
                          "bound": "hbm", "achieved": mdct_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": mdct_gbs / HBM_PEAK_GBS, "traffic": traffic,
@@ -493,6 +609,9 @@ def main():
                          "bytes_per_cf": MDCT_BYTES_PER_CF, "cf_per_launch": mdct_cf,
                          "mdct_cf_per_s": mdct_cf / (mdct_ms * 1e-3)},
         }
+        sk = step_kernels(args.workload, n_cf)
+        if sk:
+            res["config"]["step_kernels"] = sk
         if regions_nogather is not None:
             d2 = float(np.median(regions_nogather))
             res["config"]["value_without_gather"] = total_cf * args.steps / d2
