@@ -126,14 +126,31 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.environ.get("PACX_LIB"):
-        # the library must belong to the sources next to it: build.py keys that on a content
-        # hash (sources + headers + flags) stored beside the .so and rebuilds on a mismatch
-        from . import build as _build
-        try:
-            _build.ensure()
-        except Exception as e:                       # no hipcc, compile error: say so, no fallback
-            raise PacxError(f"libpacx.so is missing or stale and could not be rebuilt: {e}") from e
+    # The library must belong to the sources next to it: build.py keys that on a content hash
+    # (sources + headers + flags) stored beside the .so.  A stale or missing library is an ERROR here,
+    # not a silent ten-compile rebuild inside whatever process happened to import the package (a
+    # torchrun rank, a run under rocprofv3, a timed test).  PACX_AUTOBUILD=1 opts in to the rebuild
+    # (__graft_entry__, bench.py and the test suite set it; the rebuild says so on stderr).
+    from . import build as _build
+    if os.environ.get("PACX_LIB"):
+        # a kernel-variant or debug library (build.py --variant / --phase-debug): it carries the hash of the
+        # sources it was built from as well
+        if _build._read(LIB_PATH + ".hash") != _build.library_hash():
+            raise PacxError(f"{LIB_PATH} (PACX_LIB) was not built from the sources in this tree: rebuild it with "
+                            "`python audio-codec_amd/build.py --variant ...` / `--phase-debug`")
+    elif not _build.is_current():
+        if os.environ.get("PACX_AUTOBUILD") == "1":
+            import sys
+            print("audio_codec_amd: libpacx.so is missing or stale -- rebuilding (PACX_AUTOBUILD=1)", file=sys.stderr,
+                  flush=True)
+            try:
+                _build.build(verbose=False)
+            except Exception as e:                   # no hipcc, compile error: say so, no fallback
+                raise PacxError(f"libpacx.so is missing or stale and could not be rebuilt: {e}") from e
+        else:
+            raise PacxError("libpacx.so is missing or does not belong to the sources in this tree (content hash "
+                            "mismatch): run `python audio-codec_amd/build.py` (or set PACX_AUTOBUILD=1).  "
+                            "There is no CPU implementation of this path.")
     if not os.path.exists(LIB_PATH):
         raise PacxError(
             f"{LIB_PATH} not found: build it with `python audio-codec_amd/build.py` "

@@ -8,7 +8,7 @@ The .so is git-ignored but travels to the GPU box with the source snapshot.
 Staleness is decided by CONTENT, not by mtimes: every object carries the sha256 of
 (compiler flags + its source + every header it may include) in build/<name>.o.hash and the
 library the hash of all of those in libpacx.so.hash, so a library that does not belong to
-the sources next to it is never loaded silently (`_lib.load()` calls `ensure()`).
+the sources next to it is never loaded silently (`_lib.load()` raises on a mismatch, or rebuilds with PACX_AUTOBUILD=1).
 
 Every compile also records the compiler's per-kernel resource report (VGPRs, spills, scratch,
 occupancy, LDS: -Rpass-analysis=kernel-resource-usage) in build/resources.json;
@@ -219,6 +219,8 @@ def build_phase_debug():
     subprocess.check_call([_hipcc(), "-shared", "--offload-arch=gfx950", "-o", out] + objs + dbg_objs)
     for obj in dbg_objs:
         os.remove(obj)
+    with open(out + ".hash", "w") as f:          # the sources it belongs to (_lib.load checks PACX_LIB libraries too)
+        f.write(library_hash())
     return out
 
 
@@ -240,6 +242,8 @@ def build_variant(name, defines):
             objs.append(os.path.join(OBJ, s.replace(".hip", ".o")))
     out = os.path.join(out_dir, f"libpacx_{name}.so")
     subprocess.check_call([_hipcc(), "-shared", "--offload-arch=gfx950", "-o", out] + objs)
+    with open(out + ".hash", "w") as f:
+        f.write(library_hash())
     return out
 
 

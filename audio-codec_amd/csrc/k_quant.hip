@@ -33,8 +33,10 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
     bool alive = cf < n_cf;
     const unsigned fl = (alive && flags) ? flags[cf / n_ch] : 0u;
     const bool is_short = mixed ? ((fl & 2u) != 0) : (short_blocks != 0);
-    if (!is_short && (sb != 0 || skip_long))
+    if (!is_short && (sb != 0 || skip_long == 1))
         alive = false;                                   /* long frames may belong to k_tail_long */
+    if (is_short && skip_long == 2)
+        alive = false;                                   /* 2: the long frames only (the short chain has its own launch) */
     const int nb = is_short ? T.nb_short : T.nb_long;
     /* an SBR file counts every omitted band of a long block as one line
        (BitAlloc_SBR, coder/bitalloc.py:141-143) */
@@ -820,7 +822,7 @@ void pacx_launch_bitalloc(const PacxTables &T, const uint8_t *flags, int n_ch, l
     if (n_cf <= 0)
         return;
     const bool dense = !short_blocks && !(mixed && flags);
-    if (dense && skip_long)
+    if (dense && skip_long == 1)
         return;                                 /* every frame is long and was allocated by the mask kernel */
     const long long units = dense ? n_cf : n_cf * PACX_SUB;       /* two units per wave */
     hipLaunchKernelGGL(k_bitalloc, dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st, T, flags, n_ch,

@@ -160,6 +160,20 @@ static int fail(pacx_handle *h, int code, const std::string &msg)
             return fail(h, PACX_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+/* Inside a fork/join region (work already queued on the handle's internal streams, which share the
+   handle's workspaces with the caller's stream): an error must not leave those streams unjoined --
+   the caller's next call could overwrite ws_lines / ws_smr / ws_peaks / ws_lists under kernels that
+   are still running.  On the error path the internal streams are drained before returning. */
+static void drain_internal(pacx_handle *h);
+#define HIP_TRY_FORKED(h, call)                                                        \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            drain_internal(h);                                                         \
+            return fail(h, PACX_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        }                                                                              \
+    } while (0)
+
 template <typename Tp>
 static int upload(pacx_handle *h, const Tp *host, size_t n, const Tp **dev)
 {
@@ -601,6 +615,23 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     return PACX_OK;
 }
 
+static void drain_internal(pacx_handle *h)
+{
+    for (hipStream_t s2 : {h->side_stream, h->short_stream, h->short_side_stream})
+        if (s2)
+            (void)hipStreamSynchronize(s2);
+}
+
+static int post_launch_forked(pacx_handle *h, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        drain_internal(h);
+        return fail(h, PACX_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+    return PACX_OK;
+}
+
 static void free_ws(pacx_handle *h)
 {
     void *p[] = {h->ws_lines, h->ws_smr, h->ws_peaks, h->ws_npeaks, h->ws_overall, h->ws_chunks, h->ws_offs,
@@ -660,21 +691,38 @@ extern "C" int pacx_reserve(pacx_handle *h, int64_t n_cf)
         return fail(h, PACX_E_ARG, "pacx_reserve: bad argument");
     if (n_cf <= h->ws_cf)
         return PACX_OK;
+    if (n_cf > 0x7fffffffLL / PACX_SUB)
+        return fail(h, PACX_E_ARG, "pacx_reserve: too many channel-frames for one call");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
     free_ws(h);
     const size_t n = (size_t)n_cf;
-    HIP_TRY(h, hipMalloc((void **)&h->ws_lines, n * PACX_M_LONG * sizeof(double)));
-    HIP_TRY(h, hipMalloc((void **)&h->ws_smr, n * h->T.band_stride * sizeof(double)));
-    HIP_TRY(h, hipMalloc((void **)&h->ws_peaks, n * PACX_MAX_PEAKS * sizeof(PacxPeak)));
-    HIP_TRY(h, hipMalloc((void **)&h->ws_npeaks, n * PACX_SUB * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc((void **)&h->ws_nkept, n * PACX_SUB * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc((void **)&h->ws_overall, n * PACX_SUB * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc((void **)&h->ws_chunks, (n / 256 + 2) * sizeof(long long)));
-    HIP_TRY(h, hipMalloc((void **)&h->ws_offs, (n + 1) * sizeof(long long)));
-    HIP_TRY(h, hipMalloc((void **)&h->ws_lists, (2 * n + 2) * sizeof(int32_t)));
-    if (h->T.use_sbr)
-        HIP_TRY(h, hipMalloc((void **)&h->ws_sbr_mean, n * PACX_SUB * sizeof(double)));
+    /* all or nothing: a failing hipMalloc (the workspace of a 262 144-frame batch is 8 GB) leaves the
+       handle with NO workspace and ws_cf = 0 -- nothing leaks, and a later, smaller call reserves again */
+    struct { void **p; size_t bytes; } want[] = {
+        {(void **)&h->ws_lines, n * PACX_M_LONG * sizeof(double)},
+        {(void **)&h->ws_smr, n * h->T.band_stride * sizeof(double)},
+        {(void **)&h->ws_peaks, n * PACX_MAX_PEAKS * sizeof(PacxPeak)},
+        {(void **)&h->ws_npeaks, n * PACX_SUB * sizeof(int32_t)},
+        {(void **)&h->ws_nkept, n * PACX_SUB * sizeof(int32_t)},
+        {(void **)&h->ws_overall, n * PACX_SUB * sizeof(int32_t)},
+        {(void **)&h->ws_chunks, (n / 256 + 2) * sizeof(long long)},
+        {(void **)&h->ws_offs, (n + 1) * sizeof(long long)},
+        {(void **)&h->ws_lists, (2 * n + 2) * sizeof(int32_t)},
+        {(void **)&h->ws_sbr_mean, h->T.use_sbr ? n * PACX_SUB * sizeof(double) : 0},
+    };
+    for (auto &w : want) {
+        if (!w.bytes)
+            continue;
+        hipError_t e = hipMalloc(w.p, w.bytes);
+        if (e != hipSuccess) {
+            *w.p = nullptr;
+            free_ws(h);
+            (void)hipGetLastError();             /* the failed allocation must not poison the next launch check */
+            return fail(h, PACX_E_HIP, std::string("pacx_reserve: hipMalloc of ") + std::to_string(w.bytes) +
+                                           " bytes: " + hipGetErrorString(e) + " (workspace released)");
+        }
+    }
     h->ws_cf = n_cf;
     return PACX_OK;
 }
@@ -910,8 +958,8 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
     }
     /* fork: the side chain only reads the PCM, so it runs on its own stream next to the MDCT */
     if (!split)
-        HIP_TRY(h, hipEventRecord(h->ev_fork, st));
-    HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+        HIP_TRY_FORKED(h, hipEventRecord(h->ev_fork, st));
+    HIP_TRY_FORKED(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
     if (split) {
         /* A block-switched batch is two independent chains that touch disjoint frames:
              long-coded :  k_mdct_long_v2 || k_side_long  ->  k_mask<1024> (+ tail)
@@ -919,40 +967,40 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
            Every one of these kernels is latency-bound at the occupancy its registers and LDS
            allow and none fills the chip with half of the frames, so the two chains run side by
            side on four streams and meet again before the body gather. */
-        HIP_TRY(h, hipStreamWaitEvent(h->short_stream, h->ev_fork, 0));
-        HIP_TRY(h, hipStreamWaitEvent(h->short_side_stream, h->ev_fork, 0));
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_stream, h->ev_fork, 0));
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_side_stream, h->ev_fork, 0));
         pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed | PACX_PART_LONG, h->ws_peaks, h->ws_npeaks,
                          h->ws_nkept, nullptr, nullptr, h->side_stream);
-        HIP_TRY(h, hipEventRecord(h->ev_join, h->side_stream));
+        HIP_TRY_FORKED(h, hipEventRecord(h->ev_join, h->side_stream));
         pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_npeaks,
                          h->ws_nkept, nullptr, nullptr, h->short_side_stream);
-        HIP_TRY(h, hipEventRecord(h->ev_short_side, h->short_side_stream));
+        HIP_TRY_FORKED(h, hipEventRecord(h->ev_short_side, h->short_side_stream));
         /* short chain */
         pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale, PACX_SUB, status,
                          h->short_stream);
-        HIP_TRY(h, hipStreamWaitEvent(h->short_stream, h->ev_short_side, 0));
-        HIP_TRY(h, hipStreamWaitEvent(h->short_stream, h->ev_lists, 0));
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_stream, h->ev_short_side, 0));
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_stream, h->ev_lists, 0));
         pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_nkept, h->ws_lines,
                          h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, nullptr, h->short_stream);
         pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
                          mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, list_short, counts + 1, 1,
                          h->short_stream);
-        HIP_TRY(h, hipEventRecord(h->ev_short_done, h->short_stream));
+        HIP_TRY_FORKED(h, hipEventRecord(h->ev_short_done, h->short_stream));
         /* long chain */
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status, h->n_cu,
                             list_long, counts, st);
-        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(st, h->ev_join, 0));
         pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_LONG, h->ws_peaks, h->ws_nkept, h->ws_lines,
                          h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, fuse ? &mt : nullptr, st);
         if (!fuse)
             pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
                              mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, nullptr, nullptr, 2, st);
-        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_short_done, 0));       /* both chains done */
-        return post_launch(h, what);
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(st, h->ev_short_done, 0));       /* both chains done */
+        return post_launch_forked(h, what);
     }
     pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
                      nullptr, nullptr, h->side_stream);
-    HIP_TRY(h, hipEventRecord(h->ev_join, h->side_stream));
+    HIP_TRY_FORKED(h, hipEventRecord(h->ev_join, h->side_stream));
     if (fast) {
         /* long frames: persistent roofline kernel; short (CUR) frames: k_mdct_short */
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
@@ -964,14 +1012,14 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
                          PACX_SUB, status, st);
     }
-    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));       /* join */
+    HIP_TRY_FORKED(h, hipStreamWaitEvent(st, h->ev_join, 0));       /* join */
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
                      nullptr, h->n_cu, list_long, list_short, counts, fuse ? &mt : nullptr, st);
     /* what is left: the long frames when not fused, the short-coded frames of a mixed batch */
     if (!fuse || mixed)
         pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
                          mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, list_short, counts + 1, fuse, st);
-    return post_launch(h, what);
+    return post_launch_forked(h, what);
 }
 
 extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,
@@ -1055,16 +1103,18 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
            side by side on two streams; the side chains and the short MDCT go by the flags alone and start
            while the frame lists are made */
         int32_t *const list_long = h->ws_lists, *const list_short = h->ws_lists + n_cf, *const counts = h->ws_lists + 2 * n_cf;
+        const char *vfs_env = getenv("PACX_VQ_FUSE_ALLOC");     /* 0: k_bitalloc behind the mask kernel here too */
+        const int vq_fuse_split = vfs_env ? (atoi(vfs_env) != 0) : 1;
         HIP_TRY(h, hipEventRecord(h->ev_fork, st));
-        HIP_TRY(h, hipStreamWaitEvent(h->short_stream, h->ev_fork, 0));
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_stream, h->ev_fork, 0));
         pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, list_long, list_short, counts, st);
-        HIP_TRY(h, hipEventRecord(h->ev_lists, st));
+        HIP_TRY_FORKED(h, hipEventRecord(h->ev_lists, st));
         /* short chain */
         pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale, PACX_SUB, status,
                          h->short_stream);
         pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_npeaks,
                          h->ws_nkept, nullptr, nullptr, h->short_stream);
-        HIP_TRY(h, hipStreamWaitEvent(h->short_stream, h->ev_lists, 0));
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_stream, h->ev_lists, 0));
         pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_nkept, h->ws_lines,
                          h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, nullptr, h->short_stream);
         pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, 1, h->ws_smr, bit_alloc, status, h->short_stream);
@@ -1073,18 +1123,20 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
                        h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
                        h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, 1, list_short, counts + 1,
                        h->short_stream);
-        HIP_TRY(h, hipEventRecord(h->ev_short_done, h->short_stream));
+        HIP_TRY_FORKED(h, hipEventRecord(h->ev_short_done, h->short_stream));
         /* long chain */
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status, h->n_cu,
                             list_long, counts, st);
         pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed | PACX_PART_LONG, h->ws_peaks, h->ws_npeaks,
                          h->ws_nkept, T.use_sbr ? h->ws_sbr_mean : nullptr, T.use_sbr ? overall_scale : nullptr, st);
         pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_LONG, h->ws_peaks, h->ws_nkept, h->ws_lines,
-                         h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, &mt, st);
+                         h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, vq_fuse_split ? &mt : nullptr, st);
+        if (!vq_fuse_split)       /* BitAlloc of the long frames in k_bitalloc behind the mask kernel (part 2 = long only) */
+            pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, 2, h->ws_smr, bit_alloc, status, st);
         pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
                        h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
                        h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, 1, list_long, counts, st);
-        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_short_done, 0));       /* both chains done */
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(st, h->ev_short_done, 0));       /* both chains done */
         vq_stage = 2;
     } else {
         if (mixed)

@@ -39,6 +39,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("PACX_AUTOBUILD", "1")     # a stale libpacx.so is rebuilt (and reported on stderr), never loaded
 
 FRAMES_PER_GPU = 4096          # stereo frames per step and GPU (configs[1])
 N_CH = 2

@@ -4,6 +4,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("PACX_AUTOBUILD", "1")       # the suite may rebuild a stale libpacx.so (audio-codec_amd/_lib.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 if ROOT not in sys.path:
