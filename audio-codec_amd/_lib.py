@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PACX_LIB") or os.path.join(HERE, "libpacx.so")   # PACX_LIB: kernel-variant experiments
 
-PACX_ABI_VERSION = 3
+PACX_ABI_VERSION = 4
 PCM_I16, PCM_F64 = 0, 1
 FLAG_LAST, FLAG_CUR, FLAG_NEXT = 1, 2, 4
 ST_SHORT, ST_ZERO_SUBBLOCK, ST_ALLOC_CAP, ST_VQ_UNDEFINED, ST_GUARD, ST_MALFORMED = 1, 2, 4, 8, 16, 32
@@ -103,6 +103,13 @@ SIGNATURES = {
     "pacx_quantize_uniform": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P]),
     "pacx_scale_factor": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, _P, _P]),
     "pacx_mantissa": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "pacx_dequantize_uniform": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P]),
+    "pacx_dequantize": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "pacx_mantissa_fp": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "pacx_dequantize_fp": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "pacx_imdct_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P]),
+    "pacx_mdct_direct_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
+    "pacx_transient_detect_f64": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _P, ctypes.c_double, _P, _P]),
     "pacx_unpack_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pacx_decode_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pacx_decode_vq_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, _P, _P,

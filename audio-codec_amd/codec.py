@@ -154,6 +154,16 @@ def Encode_SBR(data, codingParams, lastTrans=False, curTrans=False, nextTrans=Fa
     return _encode_vq(data, codingParams, lastTrans, curTrans, nextTrans, sbr=True)
 
 
+def EncodeSingleChannel_SBR(data, codingParams, lastTrans=False, curTrans=False, nextTrans=False):
+    """coder/codec.py:426-555 for one channel: (bitAlloc, indices, idx_bits, overallScale) with
+    codingParams.useVQ, else (scaleFactor, bitAlloc, mantissa, overallScale)."""
+    one = type("P", (), {})()
+    one.__dict__.update(codingParams.__dict__)
+    one.nChannels = 1
+    r = Encode_SBR([data], one, lastTrans, curTrans, nextTrans)
+    return r[0][0], r[1][0], r[2][0], r[3][0]
+
+
 def EncodeSingleChannel(data, codingParams, lastTrans=False, curTrans=False, nextTrans=False):
     """coder/codec.py:266-380 for one channel."""
     one = type("P", (), {})()

@@ -8,14 +8,19 @@ _cache = {}
 
 def encoder(sample_rate, target_bits_per_sample, n_scale_bits=4, n_mant_size_bits=12,
             sf_bands=None, sf_bands_short=None, use_vq=False, use_sbr=False):
+    # the layout by its line ranges, and a private copy for the handle: a caller's sfBands.nLines may have been
+    # overwritten by BitAlloc_SBR (1 for the omitted bands, coder/bitalloc.py:141-143) -- the reference's own
+    # slicing goes by lowerLine / upperLine, which stay
+    from .psychoac import bands_from_counts, true_line_counts
+    long_lines, short_lines = true_line_counts(sf_bands), true_line_counts(sf_bands_short)
     key = (int(sample_rate), float(target_bits_per_sample), int(n_scale_bits), int(n_mant_size_bits),
-           bool(use_vq), bool(use_sbr),
-           None if sf_bands is None else tuple(int(v) for v in sf_bands.nLines),
-           None if sf_bands_short is None else tuple(int(v) for v in sf_bands_short.nLines))
+           bool(use_vq), bool(use_sbr), long_lines, short_lines)
     enc = _cache.get(key)
     if enc is None:
         enc = engine.Encoder(sample_rate, target_bits_per_sample, n_scale_bits, n_mant_size_bits,
-                             sf_bands, sf_bands_short, use_vq=use_vq, use_sbr=use_sbr)
+                             None if long_lines is None else bands_from_counts(long_lines),
+                             None if short_lines is None else bands_from_counts(short_lines),
+                             use_vq=use_vq, use_sbr=use_sbr)
         _cache[key] = enc
     return enc
 

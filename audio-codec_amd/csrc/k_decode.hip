@@ -145,20 +145,12 @@ __global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, con
     }
 }
 
-/* one dequantised line: vDequantize (coder/quantize.py:260-274) then / 2^overall */
+/* one dequantised line: vDequantize (coder/quantize.py:260-274, pacx_exact.h) then / 2^overall */
 __device__ __forceinline__ double dequant_line(int mant, int scale, int ba, int n_scale_bits, int overall)
 {
     if (!ba)
         return 0.0;
-    const int r_bits = (1 << n_scale_bits) - 1 + ba;
-    const long long sign = (mant & (1 << (ba - 1))) ? -1 : 1;
-    const long long code = mant & ((1 << (ba - 1)) - 1);
-    const int shift = r_bits - scale - ba;                 /* = 2^nScaleBits - 1 - scale */
-    long long a = code << (shift > 0 ? shift : 0);
-    if (scale < (1 << n_scale_bits) - 1 && code > 0)
-        a += 1ll << (shift - 1);
-    const double v = (double)(sign * 2 * a) / (double)((1ll << r_bits) - 1);
-    return v / (double)(1 << overall);
+    return pacx_dequantize(mant, scale, n_scale_bits, ba) / (double)(1 << overall);
 }
 
 /* -------------------------------------------------------------- IMDCT long */
@@ -168,9 +160,11 @@ __global__ __launch_bounds__(64) void k_imdct_long(PacxTables T, long long n_cf,
                                                   const int32_t *__restrict__ bit_alloc,
                                                   const int32_t *__restrict__ mantissa,
                                                   const double *__restrict__ lines_in,
-                                                  double *__restrict__ blocks)
+                                                  double *__restrict__ blocks, int plain)
 {
-    /* the lines, the FFT exchange tile and the DCT-IV output follow one another in time (the lines are in
+    /* plain (mdct.IMDCT, coder/mdct.py:73-77): lines_in are the lines themselves -- no flags, no overall
+       scale, no window: the bare 2 * unfold(DCT-IV).
+       The lines, the FFT exchange tile and the DCT-IV output follow one another in time (the lines are in
        registers before the first exchange, the spectrum is in registers before the output is written) and
        share their LDS: 9 KB per wave instead of 17 -- a one-wave kernel bound by how many of its waves fit a CU */
     __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];
@@ -180,10 +174,10 @@ __global__ __launch_bounds__(64) void k_imdct_long(PacxTables T, long long n_cf,
     const long long cf = blockIdx.x;
     if (cf >= n_cf)
         return;
-    const unsigned fl = cf_flags[cf];
+    const unsigned fl = plain ? 0u : cf_flags[cf];
     if (fl & 2u)
         return;                                            /* short frame: k_imdct_short */
-    const int ov = overall[cf * PACX_SUB];
+    const int ov = plain ? 0 : overall[cf * PACX_SUB];
     if (lines_in) {                                        /* gain-shape streams: lines come from k_vq_dec */
         const double rescale = (double)(1 << ov);
         for (int k = lane; k < PACX_M_LONG; k += 64)
@@ -228,7 +222,7 @@ __global__ __launch_bounds__(64) void k_imdct_long(PacxTables T, long long n_cf,
             t = -buf[3 * Q - 1 - i];
         else
             t = -buf[i - 3 * Q];
-        out[i] = w[i] * (2.0 * t);
+        out[i] = plain ? 2.0 * t : w[i] * (2.0 * t);
     }
 }
 
@@ -239,21 +233,24 @@ __global__ __launch_bounds__(64) void k_imdct_short(PacxTables T, long long n_cf
                                                    const int32_t *__restrict__ bit_alloc,
                                                    const int32_t *__restrict__ mantissa,
                                                    const double *__restrict__ lines_in,
-                                                   double *__restrict__ blocks)
+                                                   double *__restrict__ blocks, int plain)
 {
+    /* plain: the eight 128-line rows of lines_in through the bare IMDCT, unwindowed, overlap-added at their
+       positions 448 + 128 s (a lone row in sub-block 0 comes out at samples 448..703) */
     __shared__ __attribute__((aligned(16))) cplx tile[WFFT_TILE];      /* shared with the lines, as in k_imdct_long */
     double (*buf)[PACX_M_SHORT] = (double (*)[PACX_M_SHORT])tile;
     const int lane = threadIdx.x;
     const long long cf = blockIdx.x;
     if (cf >= n_cf)
         return;
-    const unsigned fl = cf_flags[cf];
+    const unsigned fl = plain ? 2u : cf_flags[cf];
     if (!(fl & 2u))
         return;
     if (lines_in) {
         for (int k = lane; k < PACX_M_LONG; k += 64) {
             const int s = k / PACX_M_SHORT, kk = k % PACX_M_SHORT;
-            buf[s][kk] = lines_in[cf * PACX_M_LONG + k] / (double)(1 << overall[cf * PACX_SUB + s]);
+            buf[s][kk] = plain ? lines_in[cf * PACX_M_LONG + k]
+                               : lines_in[cf * PACX_M_LONG + k] / (double)(1 << overall[cf * PACX_SUB + s]);
         }
     } else {
         const int32_t *ba = bit_alloc + cf * T.band_stride, *sf = scale_factor + cf * T.band_stride;
@@ -305,7 +302,7 @@ __global__ __launch_bounds__(64) void k_imdct_short(PacxTables T, long long n_cf
                 t = -buf[s][3 * Q - 1 - ii];
             else
                 t = -buf[s][ii - 3 * Q];
-            acc += w[ii] * (2.0 * t);
+            acc += plain ? 2.0 * t : w[ii] * (2.0 * t);
         }
         out[i] = acc;
     }
@@ -354,13 +351,27 @@ void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const
     const long long n_cf = n_blocks * n_ch;
     if (n_cf > 0) {
         hipLaunchKernelGGL(k_imdct_long, dim3((unsigned)n_cf), dim3(64), 0, st, T, n_cf, cf_flags, overall,
-                           scale_factor, bit_alloc, mantissa, lines_in, blocks);
+                           scale_factor, bit_alloc, mantissa, lines_in, blocks, 0);
         hipLaunchKernelGGL(k_imdct_short, dim3((unsigned)n_cf), dim3(64), 0, st, T, n_cf, cf_flags, overall,
-                           scale_factor, bit_alloc, mantissa, lines_in, blocks);
+                           scale_factor, bit_alloc, mantissa, lines_in, blocks, 0);
     }
     if (pcm) {
         const long long total = (n_blocks + 1) * PACX_M_LONG * n_ch;
         hipLaunchKernelGGL(k_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n_blocks, n_ch, blocks,
                            pcm);
     }
+}
+
+/* mdct.IMDCT for rows of 1024 lines (short_blocks: rows of 8 x 128 lines) -> 2048 samples each, unwindowed */
+void pacx_launch_imdct_plain(const PacxTables &T, long long n_rows, int short_blocks, const double *lines,
+                             double *blocks, hipStream_t st)
+{
+    if (n_rows <= 0)
+        return;
+    if (short_blocks)
+        hipLaunchKernelGGL(k_imdct_short, dim3((unsigned)n_rows), dim3(64), 0, st, T, n_rows, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, lines, blocks, 1);
+    else
+        hipLaunchKernelGGL(k_imdct_long, dim3((unsigned)n_rows), dim3(64), 0, st, T, n_rows, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, lines, blocks, 1);
 }

@@ -20,7 +20,8 @@ __global__ void k_window(const double *__restrict__ win, long long n_rows, int l
 
 /* op 0: vQuantizeUniform(x, a)            -> sign<<(a-1) | magnitude
  * op 1: ScaleFactor(x, a, b)              (a = nScaleBits, b = nMantBits)
- * op 2: vMantissa(x, scale, a, b) */
+ * op 2: vMantissa(x, scale, a, b)
+ * op 3: MantissaFP(x, scale, a, b) (coder/quantize.py:130-150) */
 __global__ void k_quant_elem(int op, long long n, const double *__restrict__ x, int scale, int a, int b,
                              int64_t *__restrict__ out)
 {
@@ -33,9 +34,52 @@ __global__ void k_quant_elem(int op, long long n, const double *__restrict__ x, 
         out[i] = (v < 0.0 ? ((int64_t)1 << (a - 1)) : 0) + mag;
     } else if (op == 1) {
         out[i] = pacx_scale_factor(fabs(v), a, b);
-    } else {
+    } else if (op == 2) {
         out[i] = pacx_mantissa(v, scale, a, b);
+    } else {
+        out[i] = pacx_mantissa_fp(v, scale, a, b);
     }
+}
+
+/* decode-side element ops (quantize.py mirrors): op 0: vDequantizeUniform(codes, a) (coder/quantize.py:82-95);
+ * op 1: vDequantize(scale, mantissas, a = nScaleBits, b = nMantBits) (coder/quantize.py:254-274);
+ * op 2: DequantizeFP(scale, mantissa, a, b) (coder/quantize.py:154-175) */
+__global__ void k_dequant_elem(int op, long long n, const int64_t *__restrict__ codes, int scale, int a, int b,
+                               double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    out[i] = (op == 0) ? pacx_dequant_uniform(codes[i], a)
+           : (op == 1) ? pacx_dequantize(codes[i], scale, a, b) : pacx_dequantize_fp(codes[i], scale, a, b);
+}
+
+/* mdct.py for ANY block split a + b (coder/mdct.py:14-77: MDCTslow, MDCT, IMDCT -- the reference's own
+ * self-test runs a = b = 4 and a = b = 6, coder/mdct.py:86-107): the defining sums, one output per thread,
+ *   forward  X[k] = 2/N sum_n x[n] cos(2 pi/N (n + n0)(k + 1/2)),  n0 = (b + 1)/2,  k < N/2
+ *   inverse  x[n] = 2   sum_k X[k] cos(2 pi/N (n + n0)(k + 1/2)),                    n < N
+ * with the phase reduced in integers: (2n + b + 1)(2k + 1) mod 4N, cos(2 pi p / 4N) = cospi(p / 2N), so the
+ * cosine's argument is exact to the last place at any size.  The codec's own sizes (a = b = 1024 / 128) take
+ * the FFT kernels; this one is O(N^2) and serves the function-level mirror for the sizes they do not. */
+__global__ void k_mdct_direct(long long n_rows, int a, int b, int inverse, const double *__restrict__ x,
+                              double *__restrict__ y)
+{
+    const int N = a + b, H = N / 2;
+    const int n_out = inverse ? N : H, n_in = inverse ? H : N;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * n_out)
+        return;
+    const long long row = i / n_out;
+    const int o = (int)(i % n_out);
+    const double *__restrict__ in = x + row * n_in;
+    const long long four_n = 4ll * N;
+    double acc = 0.0;
+    for (int j = 0; j < n_in; ++j) {
+        const int n = inverse ? o : j, k = inverse ? j : o;
+        const long long p = ((2ll * n + b + 1) * (2ll * k + 1)) % four_n;
+        acc += in[j] * cospi((double)p / (double)(2 * N));
+    }
+    y[i] = inverse ? 2.0 * acc : acc * 2.0 / (double)N;
 }
 
 __global__ void k_bitalloc_generic(long long n, int nb, const int32_t *__restrict__ n_lines,
@@ -63,18 +107,12 @@ __global__ void k_bitalloc_generic(long long n, int nb, const int32_t *__restric
  * ((0+1)+(2+3))+((4+5)+(6+7)) plus a scalar tail, longer runs cut at n/2 rounded down to a multiple of 8 --
  * and divided by the element count.  The recursion runs on an explicit stack in LDS (depth <= 9 for 8 x 2048
  * elements).  Only k_transient's exact-tie path calls this. */
-__device__ __forceinline__ double transient_np_mean(const PacxPcmView &in, const short *base, int n_ch, int upto, int hop)
+template <typename At>
+__device__ __forceinline__ double np_pairwise_mean(long long n_el_ll, At at)
 {
     __shared__ int st_lo[12], st_n[12], st_state[12];
     __shared__ double st_left[12];
-    const long long n_el = (long long)n_ch * upto;
-    auto at = [&](int i) {
-        const int ch = i / upto, col = i - ch * upto;
-        if (col >= hop)
-            return 0.0;
-        const int c = base[(long long)ch * in.ch_stride + (long long)col * in.samp_stride];
-        return pacx_pcm16_to_f64((c < 0 ? -c : c) & 32767);
-    };
+    const long long n_el = n_el_ll;
     auto block_sum = [&](int lo, int n) {
         if (n < 8) {
             double r = -0.0;
@@ -128,6 +166,18 @@ __device__ __forceinline__ double transient_np_mean(const PacxPcmView &in, const
         }
     }
     return result / (double)n_el;
+}
+
+/* the int16 hop of k_transient: |x| = 2 (|c| & 32767) / 65535, zeros past the hop */
+__device__ __forceinline__ double transient_np_mean(const PacxPcmView &in, const short *base, int n_ch, int upto, int hop)
+{
+    return np_pairwise_mean((long long)n_ch * upto, [&](int i) {
+        const int ch = i / upto, col = i - ch * upto;
+        if (col >= hop)
+            return 0.0;
+        const int c = base[(long long)ch * in.ch_stride + (long long)col * in.samp_stride];
+        return pacx_pcm16_to_f64((c < 0 ? -c : c) & 32767);
+    });
 }
 
 /* Block-switching caller: parTransientDetect
@@ -248,6 +298,56 @@ __global__ __launch_bounds__(64) void k_transient(PacxPcmView in, long long n_ho
             }
         }
         transient[h] = tr ? 1 : 0;
+    }
+}
+
+/* detect_transients.parTransientDetect(block, thresh, axis=1) for ANY float64 block (the function-level
+ * mirror; the encode path uses k_transient on the int16 hops): blocks [n_blocks][n_ch][n].  One wave per block:
+ * per channel the peak |x| and its first position, cols = min(max(argmax) + 500, n), the mean of |x| over the
+ * first cols columns of all channels in NumPy's pairwise order (one lane), then any(peak / avg > thresh).
+ * out: 2 where avg == 0 (the reference returns the int 0 there), else 1 / 0. */
+__global__ __launch_bounds__(64) void k_transient_f64(long long n_blocks, int n_ch, int n, const double *__restrict__ blocks,
+                                                      double thresh, uint8_t *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const long long blk = blockIdx.x;
+    if (blk >= n_blocks)
+        return;
+    const double *__restrict__ x = blocks + blk * (long long)n_ch * n;
+    int upto = 0;
+    for (int ch = 0; ch < n_ch; ++ch) {
+        double best = -1.0;
+        int where = 0;
+        for (int i = lane; i < n; i += 64) {
+            const double m = fabs(x[(long long)ch * n + i]);
+            if (m > best) { best = m; where = i; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 64);
+            const int ow = __shfl_xor(where, off, 64);
+            if (ob > best || (ob == best && ow < where)) { best = ob; where = ow; }
+        }
+        upto = max(upto, where + 500);
+    }
+    const int cols = upto < n ? upto : n;
+    if (lane == 0) {
+        const double avg = np_pairwise_mean((long long)n_ch * cols, [&](int i) {
+            const int ch = i / cols, col = i - ch * cols;
+            return fabs(x[(long long)ch * n + col]);
+        });
+        int res = 0;
+        if (avg == 0.0) {
+            res = 2;
+        } else {
+            for (int ch = 0; ch < n_ch; ++ch) {
+                double best = 0.0;
+                for (int i = 0; i < n; ++i)
+                    best = fmax(best, fabs(x[(long long)ch * n + i]));
+                if (best / avg > thresh)
+                    res = 1;
+            }
+        }
+        out[blk] = (uint8_t)res;
     }
 }
 
@@ -388,6 +488,14 @@ void pacx_launch_frame_lists(const uint8_t *flags, long long n_frames, int n_ch,
                        n_ch, list_long, list_short, counts);
 }
 
+void pacx_launch_transient_f64(long long n_blocks, int n_ch, int n, const double *blocks, double thresh, uint8_t *out,
+                               hipStream_t st)
+{
+    if (n_blocks > 0)
+        hipLaunchKernelGGL(k_transient_f64, dim3((unsigned)n_blocks), dim3(64), 0, st, n_blocks, n_ch, n, blocks, thresh,
+                           out);
+}
+
 void pacx_launch_transient(const PacxPcmView &in, long long n_hops, int hop, uint8_t *transient,
                            uint8_t *flags, hipStream_t st)
 {
@@ -412,6 +520,22 @@ void pacx_launch_quant_elem(int op, long long n, const double *x, int scale, int
     if (n > 0)
         hipLaunchKernelGGL(k_quant_elem, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, n, x, scale,
                            a, b, out);
+}
+
+void pacx_launch_dequant_elem(int op, long long n, const int64_t *codes, int scale, int a, int b, double *out,
+                              hipStream_t st)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(k_dequant_elem, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, n, codes, scale,
+                           a, b, out);
+}
+
+void pacx_launch_mdct_direct(long long n_rows, int a, int b, int inverse, const double *x, double *y, hipStream_t st)
+{
+    const long long n = n_rows * (inverse ? (a + b) : (a + b) / 2);
+    if (n > 0)
+        hipLaunchKernelGGL(k_mdct_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_rows, a, b, inverse,
+                           x, y);
 }
 
 void pacx_launch_bitalloc_generic(long long n, int nb, const int32_t *n_lines, const double *budget,

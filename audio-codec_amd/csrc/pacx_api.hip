@@ -59,11 +59,18 @@ void pacx_launch_gather(long long n_cf, const uint8_t *payload, int payload_stri
 
 void pacx_launch_window(const double *win, long long n_rows, int len, const double *x, double *y,
                         hipStream_t st);
+void pacx_launch_dequant_elem(int op, long long n, const int64_t *codes, int scale, int a, int b, double *out,
+                              hipStream_t st);
+void pacx_launch_mdct_direct(long long n_rows, int a, int b, int inverse, const double *x, double *y, hipStream_t st);
+void pacx_launch_imdct_plain(const PacxTables &T, long long n_rows, int short_blocks, const double *lines,
+                             double *blocks, hipStream_t st);
 void pacx_launch_quant_elem(int op, long long n, const double *x, int scale, int a, int b, int64_t *out,
                             hipStream_t st);
 void pacx_launch_bitalloc_generic(long long n, int nb, const int32_t *n_lines, const double *budget,
                                   int max_mant, const double *smr, int32_t *bits, hipStream_t st);
 
+void pacx_launch_transient_f64(long long n_blocks, int n_ch, int n, const double *blocks, double thresh, uint8_t *out,
+                               hipStream_t st);
 void pacx_launch_transient(const PacxPcmView &in, long long n_hops, int hop, uint8_t *transient,
                            uint8_t *flags, hipStream_t st);
 
@@ -1256,7 +1263,7 @@ static int quant_elem(pacx_handle *h, int op, int64_t n, const double *x, int sc
     if (n < 0 || !x || !out)
         return fail(h, PACX_E_ARG, std::string(what) + ": bad argument");
     const int r_bits = (op == 0) ? a : ((1 << a) - 1 + b);
-    if (a < 1 || b < 0 || r_bits < 1 || r_bits > 62 || (op == 2 && b < 1))
+    if (a < 1 || b < 0 || r_bits < 1 || r_bits > 62 || (op >= 2 && (b < 1 || scale < 0 || scale > (1 << a) - 1)))
         return fail(h, PACX_E_UNSUPPORTED, std::string(what) + ": bit widths out of range");
     HIP_TRY(h, hipSetDevice(h->device));
     pacx_launch_quant_elem(op, n, x, scale, a, b, out, (hipStream_t)stream);
@@ -1279,6 +1286,76 @@ extern "C" int pacx_mantissa(pacx_handle *h, int64_t n, const double *x, int sca
                              int n_mant_bits, int64_t *mantissa, void *stream)
 {
     return quant_elem(h, 2, n, x, scale, n_scale_bits, n_mant_bits, mantissa, stream, "pacx_mantissa");
+}
+
+static int dequant_elem(pacx_handle *h, int op, int64_t n, const int64_t *codes, int scale, int a, int b,
+                        double *out, void *stream, const char *what)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n < 0 || !codes || !out)
+        return fail(h, PACX_E_ARG, std::string(what) + ": bad argument");
+    const int r_bits = (op == 0) ? a : ((1 << a) - 1 + b);
+    /* 2 * code and 2^R - 1 must be exact doubles for the one division to be the reference's value */
+    if (a < 1 || b < 0 || r_bits < 1 || r_bits > 53 || (op >= 1 && (b < 1 || scale < 0 || scale > (1 << a) - 1)))
+        return fail(h, PACX_E_UNSUPPORTED, std::string(what) + ": bit widths out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_dequant_elem(op, n, codes, scale, a, b, out, (hipStream_t)stream);
+    return post_launch(h, what);
+}
+
+extern "C" int pacx_dequantize_uniform(pacx_handle *h, int64_t n, const int64_t *codes, int n_bits, double *x,
+                                       void *stream)
+{
+    return dequant_elem(h, 0, n, codes, 0, n_bits, 0, x, stream, "pacx_dequantize_uniform");
+}
+
+extern "C" int pacx_dequantize(pacx_handle *h, int64_t n, const int64_t *mantissa, int scale, int n_scale_bits,
+                               int n_mant_bits, double *x, void *stream)
+{
+    return dequant_elem(h, 1, n, mantissa, scale, n_scale_bits, n_mant_bits, x, stream, "pacx_dequantize");
+}
+
+extern "C" int pacx_mantissa_fp(pacx_handle *h, int64_t n, const double *x, int scale, int n_scale_bits,
+                                int n_mant_bits, int64_t *mantissa, void *stream)
+{
+    return quant_elem(h, 3, n, x, scale, n_scale_bits, n_mant_bits, mantissa, stream, "pacx_mantissa_fp");
+}
+
+extern "C" int pacx_dequantize_fp(pacx_handle *h, int64_t n, const int64_t *mantissa, int scale, int n_scale_bits,
+                                  int n_mant_bits, double *x, void *stream)
+{
+    return dequant_elem(h, 2, n, mantissa, scale, n_scale_bits, n_mant_bits, x, stream, "pacx_dequantize_fp");
+}
+
+extern "C" int pacx_imdct_batch(pacx_handle *h, int64_t n_rows, int mode, const double *lines, double *blocks,
+                                void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_rows == 0)
+        return PACX_OK;
+    if (n_rows < 0 || n_rows > 0x7fffffffLL || !lines || !blocks || (mode & ~PACX_MDCT_SHORT))
+        return fail(h, PACX_E_ARG, "pacx_imdct_batch: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_imdct_plain(h->T, n_rows, (mode & PACX_MDCT_SHORT) ? 1 : 0, lines, blocks, (hipStream_t)stream);
+    return post_launch(h, "pacx_imdct_batch");
+}
+
+extern "C" int pacx_mdct_direct_batch(pacx_handle *h, int64_t n_rows, int a, int b, int inverse, const double *x,
+                                      double *y, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_rows == 0)
+        return PACX_OK;
+    if (n_rows < 0 || !x || !y || a < 1 || b < 1 || ((a + b) & 1))
+        return fail(h, PACX_E_ARG, "pacx_mdct_direct_batch: bad argument (a, b >= 1, a + b even)");
+    if (a + b > 16384 || n_rows * (long long)(a + b) > 0x7fffffffLL * 128)
+        return fail(h, PACX_E_UNSUPPORTED, "pacx_mdct_direct_batch: block longer than 16384 samples");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_mdct_direct(n_rows, a, b, inverse ? 1 : 0, x, y, (hipStream_t)stream);
+    return post_launch(h, "pacx_mdct_direct_batch");
 }
 
 extern "C" int pacx_bitalloc_generic(pacx_handle *h, int64_t n, int n_bands, const int32_t *band_lines,
@@ -1316,6 +1393,22 @@ extern "C" int pacx_transient_flags(pacx_handle *h, const pacx_pcm *hops, uint8_
 }
 
 /* ---- decode side (k_decode.hip) ------------------------------------------ */
+extern "C" int pacx_transient_detect_f64(pacx_handle *h, int64_t n_blocks, int n_channels, int n_samples,
+                                         const double *blocks, double thresh, uint8_t *result, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_blocks == 0)
+        return PACX_OK;
+    if (n_blocks < 0 || n_blocks > 0x7fffffffLL || n_channels < 1 || n_samples < 1 || !blocks || !result)
+        return fail(h, PACX_E_ARG, "pacx_transient_detect_f64: bad argument");
+    if ((long long)n_channels * n_samples > 0x7fffffffLL)
+        return fail(h, PACX_E_UNSUPPORTED, "pacx_transient_detect_f64: block too large");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_transient_f64(n_blocks, n_channels, n_samples, blocks, thresh, result, (hipStream_t)stream);
+    return post_launch(h, "pacx_transient_detect_f64");
+}
+
 extern "C" int pacx_unpack_batch(pacx_handle *h, int64_t n_cf, const uint8_t *payload, int payload_stride,
                                  const int64_t *offsets, const int32_t *n_bytes, uint8_t *cf_flags,
                                  int32_t *overall_scale, int32_t *scale_factor, int32_t *bit_alloc,

@@ -127,6 +127,63 @@ PACX_HD int32_t pacx_mantissa(double x, int scale, int n_scale_bits, int n_mant_
     return (int32_t)(sign + m);
 }
 
+/* Decode side of the quantisers (function-level mirrors and k_decode.hip).
+ * vDequantizeUniform, coder/quantize.py:88-95: sign * 2 * code / (2^R - 1) -- integer product, then one
+ * true division (the scalar DequantizeUniform, :46-57, divides Python ints, correctly rounded: the same
+ * value while 2 * code and 2^R - 1 are exact doubles, R <= 53). */
+PACX_HD double pacx_dequant_uniform(int64_t code_word, int r_bits)
+{
+    if (r_bits <= 0)
+        return 0.0;
+    const int64_t sign = (code_word & ((int64_t)1 << (r_bits - 1))) ? -1 : 1;
+    const int64_t code = code_word & (((int64_t)1 << (r_bits - 1)) - 1);
+    return (double)(sign * 2 * code) / (double)(((int64_t)1 << r_bits) - 1);
+}
+
+/* vDequantize / Dequantize, coder/quantize.py:260-274 (and :216-225): block-floating-point mantissa back to a
+ * signed fraction -- sign to bit R-1, magnitude shifted up by R - scale - nMantBits, half a step added for a
+ * non-zero magnitude unless the scale is the largest one. */
+PACX_HD double pacx_dequantize(int64_t mant, int scale, int n_scale_bits, int n_mant_bits)
+{
+    const int r_bits = (1 << n_scale_bits) - 1 + n_mant_bits;
+    const int64_t code = mant & (((int64_t)1 << (n_mant_bits - 1)) - 1);
+    const int shift = r_bits - scale - n_mant_bits;
+    int64_t a = (mant & ((int64_t)1 << (n_mant_bits - 1))) ? ((int64_t)1 << (r_bits - 1)) : 0;
+    a += code << (shift > 0 ? shift : 0);
+    if (scale < (1 << n_scale_bits) - 1 && code > 0)
+        a += (int64_t)1 << (shift - 1);
+    return pacx_dequant_uniform(a, r_bits);
+}
+
+/* MantissaFP / DequantizeFP, coder/quantize.py:130-175: the floating-point (not block-floating-point) pair of
+ * the reference's quantiser module -- the leading one is implied, so one more bit of the magnitude is kept.  Not
+ * used by the codec; mirrored so that a module swap of quantize.py and its self-test (:283-319) are complete. */
+PACX_HD int32_t pacx_mantissa_fp(double x, int scale, int n_scale_bits, int n_mant_bits)
+{
+    const int r_bits = (1 << n_scale_bits) - 1 + n_mant_bits;
+    const int64_t mag = pacx_quant_mag(fabs(x), r_bits);
+    const int64_t keep = ((int64_t)1 << (n_mant_bits - 1)) - 1;
+    const int64_t sign = (x < 0.0) ? ((int64_t)1 << (n_mant_bits - 1)) : 0;
+    if (scale == (1 << n_scale_bits) - 1)
+        return (int32_t)(sign + (mag & keep));
+    return (int32_t)(sign + ((mag >> (r_bits - scale - n_mant_bits - 1)) & keep));
+}
+
+PACX_HD double pacx_dequantize_fp(int64_t mant, int scale, int n_scale_bits, int n_mant_bits)
+{
+    const int r_bits = (1 << n_scale_bits) - 1 + n_mant_bits;
+    const int64_t code = mant & (((int64_t)1 << (n_mant_bits - 1)) - 1);
+    int64_t a = (mant & ((int64_t)1 << (n_mant_bits - 1))) ? ((int64_t)1 << (r_bits - 1)) : 0;
+    const int up = r_bits - scale - n_mant_bits - 1;
+    a += code << (up > 0 ? up : 0);
+    if (scale != (1 << n_scale_bits) - 1)
+        a += (int64_t)1 << (r_bits - scale - 2);
+    const int shift = r_bits - scale - n_mant_bits - 2;
+    if (shift > 0)
+        a += (int64_t)1 << shift;
+    return pacx_dequant_uniform(a, r_bits);
+}
+
 /* np.sum of a contiguous float64 vector (NumPy pairwise_sum: plain loop below
  * 8 elements, else 8 running accumulators folded as ((0+1)+(2+3))+((4+5)+(6+7))
  * and a scalar tail; n <= 128 here so no recursive split). */

@@ -419,6 +419,57 @@ class Encoder:
     def mantissa(self, x, scale, n_scale_bits, n_mant_bits):
         return self._elem("pacx_mantissa", x, scale, n_scale_bits, n_mant_bits)
 
+    def mantissa_fp(self, x, scale, n_scale_bits, n_mant_bits):
+        return self._elem("pacx_mantissa_fp", x, scale, n_scale_bits, n_mant_bits)
+
+    def _delem(self, name, codes, *ints):
+        codes = codes.contiguous()
+        assert codes.dtype == torch.int64
+        out = self._empty(codes.shape, torch.float64)
+        self._call(name, ctypes.c_int64(codes.numel()), _ptr(codes), *[int(i) for i in ints], _ptr(out),
+                   self._stream())
+        return out
+
+    def dequantize_uniform(self, codes, n_bits):
+        """vDequantizeUniform (coder/quantize.py:82-95) of int64 codes on the device"""
+        return self._delem("pacx_dequantize_uniform", codes, n_bits)
+
+    def dequantize(self, mant, scale, n_scale_bits, n_mant_bits):
+        """vDequantize (coder/quantize.py:254-274)"""
+        return self._delem("pacx_dequantize", mant, scale, n_scale_bits, n_mant_bits)
+
+    def dequantize_fp(self, mant, scale, n_scale_bits, n_mant_bits):
+        return self._delem("pacx_dequantize_fp", mant, scale, n_scale_bits, n_mant_bits)
+
+    def imdct(self, lines, short=False):
+        """mdct.IMDCT for rows of 1024 lines (short: rows of 8 x 128) -> [n, 2048] samples, unwindowed
+        (k_imdct_long / k_imdct_short of the decode path)."""
+        lines = lines.contiguous().view(-1, N_LONG)
+        out = self._empty((lines.shape[0], 2 * N_LONG), torch.float64)
+        self._call("pacx_imdct_batch", ctypes.c_int64(lines.shape[0]), _lib.MDCT_SHORT if short else 0, _ptr(lines),
+                   _ptr(out), self._stream())
+        return out
+
+    def mdct_direct(self, x, a, b, inverse=False):
+        """MDCT / IMDCT by the defining sums for any a + b (rows of x): coder/mdct.py:14-77"""
+        n_in = (a + b) // 2 if inverse else a + b
+        n_out = a + b if inverse else (a + b) // 2
+        x = x.contiguous().view(-1, n_in)
+        out = self._empty((x.shape[0], n_out), torch.float64)
+        self._call("pacx_mdct_direct_batch", ctypes.c_int64(x.shape[0]), int(a), int(b), int(bool(inverse)), _ptr(x),
+                   _ptr(out), self._stream())
+        return out
+
+    def transient_detect(self, blocks, thresh=4.5):
+        """parTransientDetect (coder/detect_transients.py:5-23, axis=1) of float64 blocks [n, nCh, len] on the
+        device: uint8 [n], 2 = the mean is exactly zero (the reference returns 0), 1 / 0 = transient or not."""
+        blocks = blocks.contiguous()
+        n, n_ch, ln = blocks.shape
+        out = self._empty((n,), torch.uint8)
+        self._call("pacx_transient_detect_f64", ctypes.c_int64(n), int(n_ch), int(ln), _ptr(blocks),
+                   ctypes.c_double(float(thresh)), _ptr(out), self._stream())
+        return out
+
     def bit_alloc_generic(self, budget, max_mant_bits, n_lines, smr):
         """BitAlloc for rows of smr [n, nBands] with per-row budgets [n]."""
         smr = smr.contiguous()

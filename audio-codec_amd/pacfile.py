@@ -14,7 +14,6 @@ import numpy as np
 
 from . import _lib, codec, context
 from .audiofile import AudioFile
-from .detect_transients import hop_transients
 from .engine import PcmView
 from .pcmfile import codes_to_fraction
 from .psychoac import AssignMDCTLinesFromFreqLimits, ScaleFactorBands
@@ -183,17 +182,15 @@ class PACFile(AudioFile):
 
 def stream_flags(pcm, block_switching, hop=1024):
     """(last, cur, next) for every written hop of the driver loop
-    (coder/pacfile.py:717-741) plus the Close block.  pcm: int16 [n_hops*hop, nCh]."""
+    (coder/pacfile.py:717-741) plus the Close block.  pcm: int16 [n_hops*hop, nCh].
+    Detector and flag shifting run on the GPU (pacx_transient_flags), as in encode_stream."""
     n_hops = len(pcm) // hop
-    if block_switching:
-        frac = np.stack([codes_to_fraction(pcm[:, ch]) for ch in range(pcm.shape[1])])
-        t = hop_transients(frac.reshape(pcm.shape[1], n_hops, hop).transpose(1, 0, 2))
-    else:
-        t = np.zeros(n_hops, dtype=bool)
-    t = np.concatenate((t, [False]))                      # EOF pass: next = False
     flags = np.zeros((n_hops + 2, 3), dtype=np.uint8)
-    for f in range(n_hops + 1):
-        flags[f] = (t[f - 2] if f >= 2 else 0, t[f - 1] if f >= 1 else 0, t[f])
+    if block_switching and n_hops:
+        enc = context.any_encoder()
+        _, packed = enc.transient_flags(device_stream(enc, np.ascontiguousarray(pcm), hop), n_hops, hop)
+        packed = packed.cpu().numpy()
+        flags[:, 0], flags[:, 1], flags[:, 2] = packed & 1, (packed >> 1) & 1, (packed >> 2) & 1
     return flags                                          # last row (Close) stays 0,0,0
 
 

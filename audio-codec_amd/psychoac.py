@@ -36,6 +36,28 @@ class ScaleFactorBands:
         self.upperLine = (self.lowerLine + n - 1).astype(int)
 
 
+def bands_from_counts(lines):
+    """A ScaleFactorBands holding exactly these line counts (no merge step): the private copy an Encoder keeps."""
+    b = ScaleFactorBands.__new__(ScaleFactorBands)
+    n = np.array(lines, dtype=int)
+    b.nLines, b.nBands = n, len(n)
+    b.lowerLine = np.concatenate(([0], np.cumsum(n)[:-1])).astype(int)
+    b.upperLine = (b.lowerLine + n - 1).astype(int)
+    return b
+
+
+def true_line_counts(bands):
+    """Line counts of a band table taken from its line RANGES where it has them.  The reference's BitAlloc_SBR
+    overwrites sfBands.nLines of the SBR-omitted bands with 1 and leaves it that way for the rest of the file
+    (coder/bitalloc.py:141-143); lowerLine / upperLine keep the layout, and they are what its slicing uses."""
+    if bands is None:
+        return None
+    lo, up = getattr(bands, "lowerLine", None), getattr(bands, "upperLine", None)
+    if lo is not None and up is not None and len(lo) == len(up) == len(bands.nLines):
+        return tuple(int(u) - int(l) + 1 for l, u in zip(lo, up))
+    return tuple(int(v) for v in bands.nLines)
+
+
 def _run(data, MDCTdata, MDCTscale, sampleRate, sfBands, want_threshold):
     import torch
     from . import context

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PACX_ABI_VERSION 3
+#define PACX_ABI_VERSION 4
 
 /* error codes */
 #define PACX_OK            0
@@ -402,6 +402,32 @@ int pacx_scale_factor(pacx_handle *h, int64_t n, const double *x, int n_scale_bi
 /* quantize.py: vMantissa(x, scale, n_scale_bits, n_mant_bits) (coder/quantize.py:229-250) */
 int pacx_mantissa(pacx_handle *h, int64_t n, const double *x, int scale, int n_scale_bits,
                   int n_mant_bits, int64_t *mantissa, void *stream);
+/* quantize.py, decode side: vDequantizeUniform(codes, n_bits) (coder/quantize.py:82-95; the scalar
+ * DequantizeUniform, :40-57, gives the same values) -- float64 signed fractions; n_bits <= 53 */
+int pacx_dequantize_uniform(pacx_handle *h, int64_t n, const int64_t *codes, int n_bits, double *x,
+                            void *stream);
+/* quantize.py: vDequantize(scale, mantissa, n_scale_bits, n_mant_bits) (coder/quantize.py:254-274; the
+ * scalar Dequantize, :200-225, likewise) */
+int pacx_dequantize(pacx_handle *h, int64_t n, const int64_t *mantissa, int scale, int n_scale_bits,
+                    int n_mant_bits, double *x, void *stream);
+/* quantize.py: MantissaFP / DequantizeFP (coder/quantize.py:130-175), the floating-point pair of the module
+ * (not used by the codec; for a complete module swap and the module's self-test, :283-319) */
+int pacx_mantissa_fp(pacx_handle *h, int64_t n, const double *x, int scale, int n_scale_bits,
+                     int n_mant_bits, int64_t *mantissa, void *stream);
+int pacx_dequantize_fp(pacx_handle *h, int64_t n, const int64_t *mantissa, int scale, int n_scale_bits,
+                       int n_mant_bits, double *x, void *stream);
+/* mdct.py: IMDCT(lines, a, a) (coder/mdct.py:56-62, 73-77) for the codec's block sizes, on the FFT kernels
+ * of the decode path.  mode 0: rows of n_lines_long lines -> rows of 2*n_lines_long samples; PACX_MDCT_SHORT:
+ * rows of 8 x n_lines_short lines -> the eight 256-sample outputs overlap-added at 448 + 128 s inside a
+ * 2048-sample row (a lone sub-block 0 comes out at samples 448..703).  No window, no overall scale. */
+int pacx_imdct_batch(pacx_handle *h, int64_t n_rows, int mode, const double *lines, double *blocks,
+                     void *stream);
+/* mdct.py for ANY split a + b (coder/mdct.py:14-77: MDCTslow / MDCT / IMDCT at the sizes the FFT kernels do
+ * not cover -- the reference's own self-test uses a = b = 4 and 6): the defining cosine sums with an exact
+ * integer phase reduction, O(N^2) per row.  forward: x [n_rows][a+b] -> y [n_rows][(a+b)/2]; inverse: the
+ * other way round (the reference's scaling: 2/N on the forward transform, 2 on the inverse). */
+int pacx_mdct_direct_batch(pacx_handle *h, int64_t n_rows, int a, int b, int inverse, const double *x,
+                           double *y, void *stream);
 /* bitalloc.py: BitAlloc(budget[i], max_mant_bits, n_bands, band_lines, smr[i])
  * for n independent problems (coder/bitalloc.py:62-121); all pointers device. */
 int pacx_bitalloc_generic(pacx_handle *h, int64_t n, int n_bands, const int32_t *band_lines,
@@ -416,6 +442,13 @@ int pacx_bitalloc_generic(pacx_handle *h, int64_t n, int n_bands, const int32_t 
  * driver writes (every hop, the last hop a second time, the Close block). */
 int pacx_transient_flags(pacx_handle *h, const pacx_pcm *hops, uint8_t *transient,
                          uint8_t *frame_flags, void *stream);
+
+/* detect_transients.parTransientDetect(block, thresh, axis=1) (coder/detect_transients.py:5-23) for any
+ * float64 blocks [n_blocks][n_channels][n_samples] (device): result[i] = 2 where the mean is exactly zero (the
+ * reference returns the int 0 there), else 1 / 0 = any(peak / avg > thresh).  The mean is taken in NumPy's
+ * pairwise order.  The encode path itself uses pacx_transient_flags on the int16 hops. */
+int pacx_transient_detect_f64(pacx_handle *h, int64_t n_blocks, int n_channels, int n_samples,
+                              const double *blocks, double thresh, uint8_t *result, void *stream);
 
 /* ---- decode side (scalar-mantissa streams) ---------- */
 

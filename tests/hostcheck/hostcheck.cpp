@@ -9,6 +9,10 @@ long long hc_quant_mag(double ax, int r) { return pacx_quant_mag(ax, r); }
 int hc_scale_factor(double ax, int nsb, int nmb) { return pacx_scale_factor(ax, nsb, nmb); }
 int hc_mantissa(double x, int scale, int nsb, int nmb) { return pacx_mantissa(x, scale, nsb, nmb); }
 double hc_np_sum(const double *a, int n) { return pacx_np_sum(a, n); }
+double hc_dequant_uniform(long long c, int r) { return pacx_dequant_uniform(c, r); }
+int hc_mantissa_fp(double x, int scale, int nsb, int nmb) { return pacx_mantissa_fp(x, scale, nsb, nmb); }
+double hc_dequantize_fp(long long m, int scale, int nsb, int nmb) { return pacx_dequantize_fp(m, scale, nsb, nmb); }
+double hc_dequantize(long long m, int scale, int nsb, int nmb) { return pacx_dequantize(m, scale, nsb, nmb); }
 double hc_bit_budget(double tbps, int half_n, int is_short, int lon, int nsb, int nmsb, int nb)
 { return pacx_bit_budget(tbps, half_n, is_short, lon, nsb, nmsb, nb, 0, 0); }
 double hc_bit_budget_vq(double tbps, int half_n, int is_short, int lon, int nsb, int nmsb, int nb, int sbr_long)

@@ -118,3 +118,222 @@ def test_reserve_failure_releases_everything(A):
     assert np.array_equal(nb, want[1])
     got = after["payload"].cpu().numpy()
     assert all(np.array_equal(got[i, :nb[i]], want[0][i, :nb[i]]) for i in range(len(nb)))
+
+
+# ------------------------------------------------------------ function-level mirrors (VERDICT r2 missing #3)
+def test_mdct_module_self_test(A, tables):
+    """The reference's own mdct.py self-test (coder/mdct.py:86-107) run against the mirror: TDAC round trip
+    with a = b = 4, MDCTslow == MDCT and their inverses on the 20-sample ramp block -- and the outputs the
+    reference itself produced for that block (tests/golden/tables.npz, made by running it)."""
+    M = A.mdct
+    x = np.array([0, 1, 2, 3, 4, 4, 4, 4, 3, 1, -1, -3], dtype=np.float64)
+    frame_size, noverlap = 8, 4
+    x = np.concatenate([np.zeros(noverlap), x, np.zeros(noverlap)])
+    x_hat = np.zeros_like(x)
+    for i in range(0, len(x) - noverlap, noverlap):
+        data = x[i:i + frame_size]
+        mdct = M.MDCTslow(data, 4, 4, isInverse=False)
+        x_hat[i:i + frame_size] += M.MDCTslow(mdct, 4, 4, isInverse=True) / 2
+    assert np.allclose(x, x_hat)
+    a = b = len(x) // 2
+    mdct_a, mdct_b = M.MDCTslow(x, a, b), M.MDCT(x, a, b)
+    assert np.allclose(mdct_a, mdct_b)
+    assert np.allclose(M.MDCTslow(mdct_a, a, b, isInverse=True), M.MDCT(mdct_b, a, b, isInverse=True))
+    # against the reference's own numbers
+    ramp = tables["mdct_ramp_in"]
+    for got, want in ((M.MDCT(ramp, 10, 10), tables["mdct_ramp_fast"]), (M.MDCTslow(ramp, 10, 10), tables["mdct_ramp_slow"]),
+                      (M.IMDCT(tables["mdct_ramp_fast"], 10, 10), tables["imdct_ramp_fast"])):
+        assert got.shape == want.shape and np.max(np.abs(got - want)) <= 1e-13 * max(1.0, np.max(np.abs(want)))
+    # unequal halves (the reference's formula has n0 = (b + 1) / 2)
+    from oracle import pac_oracle as po
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal(24)
+    assert np.max(np.abs(M.MDCT(y, 16, 8) - po.mdct_slow(y, 16, 8))) < 1e-13
+
+
+@pytest.mark.parametrize("half", [1024, 128])
+def test_imdct_at_the_codec_sizes(A, half):
+    """mdct.IMDCT / MDCT(isInverse=True) at a = b = 1024 and 128 (k_imdct_long / k_imdct_short of the decode
+    path, unwindowed) against the oracle's restatement of coder/mdct.py:56-62, the timing loop's round trip
+    (coder/mdct.py:109-122) and TDAC with the sine window."""
+    from oracle import pac_oracle as po
+    rng = np.random.default_rng(half)
+    for _ in range(4):
+        lines = rng.standard_normal(half) * 10.0 ** rng.uniform(-4, 0)
+        got = A.mdct.IMDCT(lines, half, half)
+        want = po.mdct_inverse(lines, half, half)
+        assert got.shape == (2 * half,)
+        assert np.max(np.abs(got - want)) <= 2e-12 * np.max(np.abs(want))
+    # windowed TDAC: three overlapping blocks, the middle hop comes back
+    x = rng.standard_normal(4 * half)
+    w = A.window.SineWindow(np.ones(2 * half))
+    rec = np.zeros(4 * half)
+    for i in range(3):
+        blk = x[i * half:(i + 2) * half]
+        rec[i * half:(i + 2) * half] += w * A.mdct.IMDCT(A.mdct.MDCT(w * blk, half, half), half, half)
+    assert np.max(np.abs(rec[half:3 * half] - x[half:3 * half])) < 1e-11
+
+
+def test_quantize_module_self_test(A, tables):
+    """coder/quantize.py:283-319 against the mirror, plus the values the reference itself printed for it"""
+    Q = A.quantize
+    inputs = tables["quant_in"]
+    for bits in (8, 12):
+        scal = [Q.DequantizeUniform(Q.QuantizeUniform(float(v), bits), bits) for v in inputs]
+        vec = Q.vDequantizeUniform(Q.vQuantizeUniform(inputs, bits), bits)
+        assert np.array_equal(vec, np.array(scal))
+        assert np.array_equal(vec, tables[f"dequant_v{bits}"])
+        assert [Q.QuantizeUniform(float(v), bits) for v in inputs] == tables[f"quant_u{bits}"].tolist()
+    deq = []
+    for v in inputs:
+        v = float(v)
+        scale = Q.ScaleFactor(v)
+        fp = Q.DequantizeFP(scale, Q.MantissaFP(v, scale))
+        m = Q.Mantissa(v, scale)
+        bfp = Q.Dequantize(scale, m)
+        assert abs(fp - v) < 0.05 and abs(bfp - v) < 0.05
+        mv = Q.vMantissa(np.array([v]), scale)
+        assert int(mv[0]) == m
+        assert abs(Q.vDequantize(scale, mv)[0] - bfp) < 1e-5            # the reference's own assertion
+        assert Q.vDequantize(scale, mv)[0] == bfp
+        deq.append(bfp)
+    assert np.array_equal(np.array(deq), tables["quant_deq_3_5"])
+    assert Q.DequantizeUniform(5, 0) == 0 and Q.QuantizeUniform(0.3, 0) == 0
+
+
+def test_dequantizers_against_the_oracle(A):
+    """vDequantize / vDequantizeUniform / MantissaFP / DequantizeFP over random codes at the codec's widths
+    (nScaleBits 4, 2..16 mantissa bits) and the homework's (3, 5): bit-equal to the oracle's restatement"""
+    from oracle import pac_oracle as po
+    rng = np.random.default_rng(9)
+    for nsb, nmb in [(4, b) for b in (2, 3, 5, 8, 12, 16)] + [(3, 5), (2, 4)]:
+        r = (1 << nsb) - 1 + nmb
+        codes = rng.integers(0, 1 << r, 4000)
+        assert np.array_equal(A.quantize.vDequantizeUniform(codes, r), po.dequantize_uniform_vec(codes, r))
+        mant = rng.integers(0, 1 << nmb, 4000)
+        for scale in range(1 << nsb):
+            assert np.array_equal(A.quantize.vDequantize(scale, mant, nsb, nmb), po.dequantize_vec(scale, mant, nsb, nmb)), (nsb, nmb, scale)
+
+
+def test_fp_pair_matches_a_plain_python_restatement(A):
+    """MantissaFP / DequantizeFP (coder/quantize.py:130-175) against the formula written out with Python ints"""
+    def mant_fp(x, scale, nsb, nmb):
+        r = 2 ** nsb - 1 + nmb
+        code = 2 ** (r - 1) - 1 if abs(x) >= 1 else int(((2 ** r - 1) * abs(x) + 1) // 2)
+        s = (1 << (nmb - 1)) if x < 0 else 0
+        if scale == 2 ** nsb - 1:
+            return s + (code & (2 ** (nmb - 1) - 1))
+        return s + ((code >> (r - scale - nmb - 1)) & (2 ** (nmb - 1) - 1))
+
+    def deq_fp(scale, m, nsb, nmb):
+        r = 2 ** nsb - 1 + nmb
+        a = (1 << (r - 1)) if m & (1 << (nmb - 1)) else 0
+        code = m & (2 ** (nmb - 1) - 1)
+        a += code << max(r - scale - nmb - 1, 0)
+        if scale != 2 ** nsb - 1:
+            a += 1 << (r - scale - 2)
+        if r - scale - nmb - 2 > 0:
+            a += 1 << (r - scale - nmb - 2)
+        sign = -1 if a & (1 << (r - 1)) else 1
+        return sign * 2 * (a & (2 ** (r - 1) - 1)) / (2 ** r - 1)
+
+    rng = np.random.default_rng(4)
+    for nsb, nmb in ((3, 5), (4, 8), (2, 3)):
+        for _ in range(300):
+            x = float(rng.uniform(-1.1, 1.1) * 10.0 ** rng.uniform(-4, 0))
+            scale = A.quantize.ScaleFactor(x, nsb, nmb)
+            m = A.quantize.MantissaFP(x, scale, nsb, nmb)
+            assert m == mant_fp(x, scale, nsb, nmb)
+            assert A.quantize.DequantizeFP(scale, m, nsb, nmb) == deq_fp(scale, m, nsb, nmb)
+
+
+def test_bitalloc_sbr_mirror(A, tables):
+    """BitAlloc_SBR (coder/bitalloc.py:123-145): omitted bands count one line -- written into the caller's
+    array, as the reference does -- then BitAlloc; against the oracle's allocation of the same problem"""
+    from oracle import pac_oracle as po
+    rng = np.random.default_rng(3)
+    n_lines0 = tables["bands_1024_48000_nLines"].astype(int)
+    omitted = [int(b) for b in tables["bands_1024_48000_omitted"]]
+    for _ in range(40):
+        smr = rng.uniform(-20, 30, len(n_lines0))
+        budget = float(rng.uniform(400, 3000))
+        n_lines = n_lines0.copy()
+        got = A.bitalloc.BitAlloc_SBR(budget, 16, len(n_lines), n_lines, smr, omitted)
+        assert all(n_lines[b] == 1 for b in omitted)
+        want_lines = n_lines0.copy()
+        want_lines[omitted] = 1
+        assert got.tolist() == po.bit_alloc(budget, 16, len(want_lines), want_lines, smr).tolist()
+
+
+def test_encode_single_channel_sbr_mirror(A):
+    """EncodeSingleChannel_SBR (coder/codec.py:426-555) = one channel of Encode_SBR, both coders"""
+    from oracle import pac_oracle_vq as pv
+    pcm = A.synth.stream(3, 2)
+    p = pv.make_params_vq(48000, 2, 96)
+    from oracle import pac_oracle as po
+    x = [po.pcm16_to_fraction(pcm[1024:3072, ch]) for ch in range(2)]
+    both = A.codec.Encode_SBR(x, p)
+    for ch in range(2):
+        one = A.codec.EncodeSingleChannel_SBR(x[ch], p)
+        assert one[0].tolist() == both[0][ch].tolist() and one[1] == both[1][ch] and one[2] == both[2][ch]
+        assert one[3] == both[3][ch]
+        # the oracle, like the reference (BitAlloc_SBR, coder/bitalloc.py:141-143), leaves p.sfBands.nLines at 1
+        # for the omitted bands from here on; the mirror must go on by the line ranges, as the reference does
+        ba, idx, bits, ov = pv.encode_channel_sbr_vq(x[ch], p)
+        assert one[0].tolist() == list(ba) and one[3] == ov and one[1] == [list(map(int, i)) for i in idx]
+    assert [int(p.sfBands.nLines[b]) for b in p.omittedBands] == [1] * len(p.omittedBands)
+    again = A.codec.Encode_SBR(x, p)
+    assert [a.tolist() for a in again[0]] == [b.tolist() for b in both[0]] and again[1] == both[1]
+    # the scalar-mantissa branch of the same function (useVQ False)
+    ps = pv.make_params_vq(48000, 2, 96)
+    ps.useVQ = False
+    try:
+        s2 = A.codec.Encode_SBR(x, ps)
+        for ch in range(2):
+            s1 = A.codec.EncodeSingleChannel_SBR(x[ch], ps)
+            assert s1[0].tolist() == s2[0][ch].tolist() and s1[1].tolist() == s2[1][ch].tolist()
+            assert s1[2].tolist() == s2[2][ch].tolist() and s1[3] == s2[3][ch]
+    except TypeError as e:                     # an omitted band got bits: the reference raises there, and so do we
+        assert str(e) == A._lib.REF_SCALAR_SBR_ERROR
+
+
+@pytest.mark.parametrize("name", ["castanet", "harpsichord", "quar48_1", "spmg"])
+def test_stream_flags_match_reference(A, name):
+    """(moved from the CPU suite: the detector of the mirror runs on the GPU now) the block-switching flags of
+    the excerpts as the reference's own driver loop produced them"""
+    from conftest import load_excerpt
+    ex = load_excerpt(name)
+    pcm = ex["pcm"]
+    pcm = np.concatenate((pcm, np.zeros((-len(pcm) % 1024, 2), pcm.dtype)))
+    got = A.pacfile.stream_flags(pcm, True)
+    assert got[:-1].tolist() == ex["flags_bs"].tolist()
+    assert got[-1].tolist() == [0, 0, 0]
+    assert not A.pacfile.stream_flags(pcm, False).any()
+
+
+def test_transient_detector_mirror_matches_oracle(A):
+    """detect_transients.parTransientDetect on the GPU (k_transient_f64: any float block, any threshold,
+    both axes; mean in NumPy's pairwise order) against the oracle's restatement of coder/detect_transients.py"""
+    from oracle import pac_oracle as po
+    rng = np.random.default_rng(0)
+    for t in range(200):
+        blk = np.zeros((2, 2048))
+        blk[:, :1024] = rng.standard_normal((2, 1024)) * 10.0 ** rng.uniform(-3, 0)
+        if t % 3 == 0:
+            blk[rng.integers(2), rng.integers(1024)] = rng.uniform(0.2, 1.0)
+        if t % 17 == 0:
+            blk[:] = 0
+        got = A.detect_transients.parTransientDetect(blk)
+        want = po.transient_detect(blk)
+        assert got == want and type(got) is type(want), t
+    # other shapes, thresholds, axis=0 (the reference's own __main__ calls it that way) and exact ties
+    for t in range(100):
+        n_ch, n = int(rng.integers(1, 5)), int(rng.integers(3, 3000))
+        blk = rng.standard_normal((n_ch, n)) * (rng.random((n_ch, n)) < rng.uniform(0.01, 1.0))
+        thr = float(rng.uniform(1.0, 8.0))
+        assert A.detect_transients.parTransientDetect(blk, thr) == po.transient_detect(blk, thr), (t, n_ch, n)
+        assert A.detect_transients.parTransientDetect(blk.T, thr, axis=0) == po.transient_detect(blk, thr)
+    tie = np.zeros((1, 600))
+    tie[0, 0] = 4.5
+    tie[0, 1:500] = 1.0                      # peak / mean of the first 500 = 4.5 / ((4.5 + 499) / 500)
+    assert A.detect_transients.parTransientDetect(tie) == po.transient_detect(tie)

@@ -36,6 +36,12 @@ def hc(tmp_path_factory):
     for f in ("hc_spl_array", "hc_spl_scalar", "hc_bark", "hc_thresh_quiet", "hc_round_trip"):
         getattr(lib, f).restype = ctypes.c_double
         getattr(lib, f).argtypes = [ctypes.c_double]
+    lib.hc_dequant_uniform.restype = ctypes.c_double
+    lib.hc_dequant_uniform.argtypes = [ctypes.c_longlong, ctypes.c_int]
+    for f in ("hc_dequantize", "hc_dequantize_fp"):
+        getattr(lib, f).restype = ctypes.c_double
+        getattr(lib, f).argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.hc_mantissa_fp.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.hc_window_kind.argtypes = [ctypes.c_uint]
     lib.hc_quant_guard.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_double]
     lib.hc_scale_guard.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double]
@@ -77,6 +83,28 @@ def test_scale_factor_and_mantissa(hc, tables):
         want = po.mantissa_vec(x, sc, 4, ba)
         got = [hc.hc_mantissa(float(v), sc, 4, ba) for v in x]
         assert got == want.tolist()
+
+
+def test_dequantizers(hc, tables):
+    """pacx_dequant_uniform / pacx_dequantize (decode path and the quantize.py mirrors) against the oracle's
+    restatement of coder/quantize.py:82-95, 254-274 and the reference's own self-test outputs"""
+    q_in = tables["quant_in"]
+    for bits in (8, 12):
+        codes = tables[f"quant_v{bits}"]
+        got = [hc.hc_dequant_uniform(int(c), bits) for c in codes]
+        assert got == tables[f"dequant_v{bits}"].tolist()
+    got = [hc.hc_dequantize(int(m), int(s), 3, 5) for m, s in zip(tables["quant_mant_3_5"], tables["quant_scale_3_5"])]
+    assert got == tables["quant_deq_3_5"].tolist()
+    rng = np.random.default_rng(5)
+    for nsb, nmb in ((4, 2), (4, 7), (4, 16), (3, 5)):
+        r = (1 << nsb) - 1 + nmb
+        codes = rng.integers(0, 1 << r, 500)
+        assert [hc.hc_dequant_uniform(int(c), r) for c in codes] == po.dequantize_uniform_vec(codes, r).tolist()
+        mant = rng.integers(0, 1 << nmb, 300)
+        for scale in range(1 << nsb):
+            want = po.dequantize_vec(scale, mant, nsb, nmb)
+            assert [hc.hc_dequantize(int(m), scale, nsb, nmb) for m in mant] == want.tolist()
+    assert hc.hc_dequant_uniform(1 << 7, 8) == 0.0 and np.signbit(hc.hc_dequant_uniform(1 << 7, 8)) == False  # -0 code -> +0.0
 
 
 def test_np_sum_order(hc):
