@@ -57,6 +57,11 @@ struct VqView {
        ticket, so wave w only needs scratch for the (w+1)-th largest band */
     uint8_t order_long[PACX_MAX_BANDS], order_short[PACX_MAX_BANDS];
     int scr_off[VQ_WAVES + 1];         /* doubles: scratch of wave w = [scr_off[w], scr_off[w+1]) */
+    /* k_vq_frame2: band b's vector lives in a region of pow2ceil(size) doubles at reg_*[b] (short: of sub-block 0;
+       sub-block j adds j * reg_short_total); rlog_* = log2 of the region */
+    unsigned short reg_long[PACX_MAX_BANDS], reg_short[PACX_MAX_BANDS];
+    unsigned char rlog_long[PACX_MAX_BANDS], rlog_short[PACX_MAX_BANDS];
+    int reg_long_total, reg_short_total, max_band;
 };
 
 /* read-only table entry at a wave-uniform address: through the constant address space the
@@ -1198,6 +1203,7 @@ struct VqArgs {
     const int32_t *cf_list;    /* k_vq_frame: the channel-frames of this launch (NULL: all n_cf) ... */
     const int32_t *cf_count;   /* ... and how many (device side) */
     int bfs;                   /* shape bits from which a band's tree is walked level by level (vq_shape_bfs); 0: never */
+    int rot;                   /* k_vq_frame: 1 = the wave that runs the serial stages rotates with the workgroup index */
 };
 
 #ifdef PACX_VQ_DEBUG
@@ -1550,6 +1556,27 @@ __device__ __forceinline__ void vq_quantize_code(double x, int n_bits, unsigned 
 #else
 #define VQF_SUB(k) do { } while (0)
 #endif
+/* -DPACX_VQ_WAITDBG (measuring aid, tools/vq_wait_probe.py): per ROLE of a wave (0 = sorts the levels and runs the
+   scalar stage) the cycles it spends busy before, and waiting at, each of the two barriers of a level, plus the
+   workgroup's whole time: stamps only next to barriers (where the LDS queue is drained anyway), accumulated in
+   registers, one atomic per counter at the end -- the kernel runs as it does without them */
+#ifdef PACX_VQ_WAITDBG
+__device__ long long g_vqw_dbg[32];
+extern "C" int pacx_debug_read_vqw(long long *out, int n, int clear)
+{
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vqw_dbg), sizeof(long long) * n);
+    if (clear) {
+        long long z[32] = {0};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_vqw_dbg), z, sizeof(z));
+    }
+    return rc;
+}
+#define VQW_NOW(v) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define VQW_BARRIER(busy, wait) do { long long a_, b_; VQW_NOW(a_); __syncthreads(); VQW_NOW(b_); \
+                                     busy += a_ - vqw_t; wait += b_ - a_; vqw_t = b_; } while (0)
+#else
+#define VQW_BARRIER(busy, wait) __syncthreads()
+#endif
 #define VQF_HL 64                      /* 0.5 log2(L), L < 64, in LDS */
 #define VQF_LT 127                     /* log2(tan) of the angle codes of 1..7 bits in LDS */
 __shared__ double vqf_half_log2[VQF_HL];
@@ -1586,7 +1613,20 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                   "fixed part of k_vq_frame's LDS");
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PACX_VQ_WAITDBG
+    long long vqw_start, vqw_p;
+    VQW_NOW(vqw_start);
+    vqw_p = vqw_start;
+#define VQW_P(k) do { long long n_; VQW_NOW(n_); if (tid == 0) atomicAdd((unsigned long long *)&g_vqw_dbg[21 + (k)], (unsigned long long)(n_ - vqw_p)); vqw_p = n_; } while (0)
+#else
+#define VQW_P(k) do { } while (0)
+#endif
+    /* `wave` is the wave's ROLE in the level loop, not its hardware slot: role 0 sorts the levels and runs the
+       (first chunk of the) scalar stage while the others code leaves.  The four waves of a workgroup sit on the
+       four SIMDs of the CU; with the role fixed to the hardware wave, the serial stages of all five resident
+       workgroups land on one SIMD and the other three idle -- the role rotates with the workgroup index */
+    const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = A.rot ? ((hw_wave + (int)(blockIdx.x & 3u)) & 3) : hw_wave;
     const unsigned long long below = (1ull << lane) - 1ull;
     long long cf = blockIdx.x;
     if (A.cf_list) {                           /* a launch over one of the frame lists of a block-switched batch */
@@ -1645,6 +1685,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         }
     }
     __syncthreads();
+    VQW_P(0);
     for (int vb = wave; vb < n_vb; vb += VQ_WAVES) {
         const int j = sub_of(vb), b = vb - j * nb;
         double g;
@@ -1667,7 +1708,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             gain_s[vb] = g;
     }
     __syncthreads();
-    if (tid < 64) {
+    VQW_P(1);
+    if (wave == 0) {
         /* final allocations, band positions, header fields, the roots of the trees: one band per lane.
            The stream: 3 flag bits, then per (sub-)block its head (overall scale, nb allocation fields)
            and the fields of its bands back to back (coder/pacfile.py:552-592; eight of those for a short
@@ -1808,7 +1850,13 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         if (carry > VQF_BUF && lane == 0)
             misc[1] = 1;
     };
+    VQW_P(2);
     VQF_T(0);
+#ifdef PACX_VQ_WAITDBG
+    long long vqw_busy1 = 0, vqw_wait1 = 0, vqw_busy2 = 0, vqw_wait2 = 0, vqw_t, vqw_t0, vqw_levels = 0;
+    VQW_NOW(vqw_t);
+    vqw_t0 = vqw_t;
+#endif
     bool undefined = false;
     int lev_b = 0, lev_e = misc[0], depth = 0;
     if (wave == 0)
@@ -1843,10 +1891,15 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 const double x = (valid && l < n) ? cur[N.off[node] + l] : 0.0;
                 bool ok = false;
                 unsigned long long term;
+#ifdef VQF_STUB_LEAF       /* timing experiment only (wrong indices): what the small leaves cost */
+                ok = true;
+                term = (unsigned long long)(x != 0.0) + (unsigned long long)K;
+#else
                 if (c == 0)
                     term = vq_leaf_group<16, true>(V, x, n, K < 0 ? 0 : K, l, ok);
                 else
                     term = vq_leaf_group<32, true>(V, x, n, K < 0 ? 0 : K, l, ok);
+#endif
                 if (valid && l == 0) {
                     if (K < 0) {                   /* a 1-dimensional leaf: the reference never returns */
                         N.kind[node] = 3;
@@ -1970,7 +2023,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             const int split_order[5] = {7, 6, 5, 4, 3};
             deal(split_order, 5, EVEN, 4);
         }
-        __syncthreads();
+        VQW_BARRIER(vqw_busy1, vqw_wait1);
         VQF_T(2);
         /* ---- the level's splits, one per lane: angle, bit split, children */
         const int s_b = cls_c[3], s_n = cls_c[8] - s_b;
@@ -1989,7 +2042,11 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             const int half = sn - sn / 2;
             const int bits = has ? N.bb[snode] : 0;
             const double q = has ? __longlong_as_double((long long)N.val[snode]) : -1.0;
+#ifdef VQF_STUB_ATAN       /* timing experiment only (wrong angles) */
+            const double theta = (q < 0.0) ? 0.0 : q / (1.0 + q);
+#else
             const double theta = (q < 0.0) ? 0.0 : vq_atan(q);
+#endif
             VQF_SUB(26);
             const double hl = (half < VQF_HL) ? vqf_half_log2[half] : V.half_log2[half];
             const int a_theta = (int)floor((double)bits / (double)half + hl);
@@ -2120,7 +2177,10 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             }
             deal(leaf_order, 3, pat, per);
         }
-        __syncthreads();
+        VQW_BARRIER(vqw_busy2, vqw_wait2);
+#ifdef PACX_VQ_WAITDBG
+        vqw_levels += 1;
+#endif
         VQF_T(3);
         if (misc[1])
             break;
@@ -2155,6 +2215,24 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
     const int n_nodes = misc[0];
     if (tid == 0)
         N.lvl[depth + 1] = (unsigned short)n_nodes;
+#ifdef PACX_VQ_WAITDBG
+    {
+        long long t_end;
+        VQW_NOW(t_end);
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&g_vqw_dbg[wave * 4 + 0], (unsigned long long)vqw_busy1);
+            atomicAdd((unsigned long long *)&g_vqw_dbg[wave * 4 + 1], (unsigned long long)vqw_wait1);
+            atomicAdd((unsigned long long *)&g_vqw_dbg[wave * 4 + 2], (unsigned long long)vqw_busy2);
+            atomicAdd((unsigned long long *)&g_vqw_dbg[wave * 4 + 3], (unsigned long long)vqw_wait2);
+            if (hw_wave == 0) {
+                atomicAdd((unsigned long long *)&g_vqw_dbg[16], (unsigned long long)(t_end - vqw_t0));   /* level loop */
+                atomicAdd((unsigned long long *)&g_vqw_dbg[17], (unsigned long long)vqw_levels);
+                atomicAdd((unsigned long long *)&g_vqw_dbg[18], 1ull);
+                atomicAdd((unsigned long long *)&g_vqw_dbg[19], (unsigned long long)(vqw_t0 - vqw_start));   /* phase A */
+            }
+        }
+    }
+#endif
     __syncthreads();
     /* ---- subtree widths and field counts bottom-up (counts ride in nn[], field numbers in off[]) */
     for (int d = depth; d >= 0; --d) {
@@ -2169,9 +2247,9 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         }
         __syncthreads();
     }
-    if (tid < n_vb && root_s[tid] != 0xFFFF) {
-        N.pos[root_s[tid]] = (unsigned short)start_s[tid];
-        N.off[root_s[tid]] = 0;
+    if (hw_wave == 0 && lane < n_vb && root_s[lane] != 0xFFFF) {
+        N.pos[root_s[lane]] = (unsigned short)start_s[lane];
+        N.off[root_s[lane]] = 0;
     }
     __syncthreads();
     for (int d = 0; d <= depth; ++d) {
@@ -2194,6 +2272,9 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         __syncthreads();
     }
     VQF_T(4);
+#ifdef PACX_VQ_WAITDBG
+    VQW_NOW(vqw_p);
+#endif
     /* ---- every field by its own lane */
     for (int j = tid; j < n_nodes; j += 64 * VQ_WAVES) {
         const int w = N.wid[j];
@@ -2212,8 +2293,9 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             A.log[slot * A.log_cap + N.off[j]] = e;
         }
     }
+    VQW_P(3);
     /* ---- the gains of all bands side by side (mu-law, QuantizeUniform; the index soaks up the slack) */
-    if (tid < 64) {
+    if (wave == 0) {
         const int vb = lane, sj = sub_of(vb < n_vb ? vb : 0), b = vb - sj * nb;
         const int ba = (vb < n_vb) ? ba_s[vb] : 0;
         const long long slot = (cf * PACX_SUB + sj) * PACX_MAX_BANDS + b;
@@ -2260,6 +2342,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
     if (__builtin_amdgcn_ballot_w64(undefined) && lane == 0 && A.status)
         atomicOr(&A.status[cf], PACX_ST_VQ_UNDEFINED);
     __syncthreads();
+    VQW_P(4);
 
     VQF_T(5);
     /* hand the string over.  getNumBytesNeeded (coder/pacfile.py:342-361) also charges a scale factor per band
@@ -2272,7 +2355,986 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         dst[i] = __builtin_bswap32(words[i]);
     if (tid == 0)
         A.n_bytes[cf] = nbytes;
+#ifdef PACX_VQ_WAITDBG
+    {
+        long long t_fin;
+        VQW_NOW(t_fin);
+        if (tid == 0)
+            atomicAdd((unsigned long long *)&g_vqw_dbg[20], (unsigned long long)(t_fin - vqw_start));         /* whole unit */
+    }
+#endif
     VQF_T(6);
+}
+
+/* ------------------------------------------------ frame-level walk, second form (k_vq_frame2) */
+/* Round 3.  k_vq_frame, measured with stamps next to its barriers (tools/vq_wait_probe.py,
+ * profiles/r03_vq_wait_before.txt): a unit takes ~250 k cycles for ~8 k instructions per wave; the level loop is
+ * 70 % of it, and inside a level the wave that codes the most LEAVES is the critical path, not the scalar stage
+ * (leaf passes: 108 k cycles on the busiest wave against 83 k for the wave with the scalar stage and the sorting);
+ * the small leaves are 45 % of the kernel's vector instructions (15 packed passes of four leaves per unit, each a
+ * chain of cross-lane reads with run-time trip counts).  What changes here, bytes unchanged:
+ *   - ONE buffer, in place: a node of n components owns a region of R = pow2ceil(n) doubles (a band's root the
+ *     region of its band), its mid child the first half of it, its side child the second (ceil(n/2) <= R/2) -- a
+ *     pass reads its node into registers before it writes, nobody else touches the region.  No room to allocate per
+ *     level, and every leaf's vector stays where it is until the end of the walk;
+ *   - so the level loop holds only the splits (packed passes, scalar stage), and the leaves are coded AFTER it, all
+ *     of the unit's at once: ONE LEAF PER LANE for the ~60 leaves of up to 16 components (L1 norm in np.sum order,
+ *     targets, the pulse ranking as 240 register compares, prefix of the pulses -- no cross-lane traffic at all),
+ *     the components' (pulses, pulses left) left in place of the vector; then the enumeration terms ONE COMPONENT
+ *     PER THREAD on all four waves (four independent table reads each, one round trip for the whole unit) added
+ *     into the leaf's index with a 64-bit LDS atomic (integers: any order).  Leaves of 17..32 components keep the
+ *     half-wave group coder, larger ones the whole-wave coder (one scratch: the first wave takes them);
+ *   - node records are two words (lengths / offset / child as one 64-bit store, kind / width / band / flags as one
+ *     32-bit store) instead of ten byte and short stores per child;
+ *   - the bands' lines go from memory straight to their regions and the wave that placed a band also takes its
+ *     norm: one barrier fewer in front of the walk.
+ * Arithmetic per node is k_vq_frame's, so the bytes are (tests/test_gpu_vq.py, the path-switch matrix of
+ * tests/test_gpu_round3.py: PACX_VQ_FRAME=1 selects the first form). */
+#define VQ2_NCAP 272
+#define VQ2_NLV 256
+#define VQ2_BUF 1504                   /* doubles: sum of the bands' regions (1504 at 48 kHz, 1472 at 44.1 kHz, 1408 short);
+                                          other layouts run on k_vq_frame.  With the node store and the scratch this is the
+                                          LDS of five workgroups per CU to the last kilobyte */
+#define VQ2_SCR 752                    /* doubles: t / y of one leaf of more than 32 components (2 n); before that, as
+                                          VQ2_BUF ints, the floors of the small leaves' components (by buffer position) */
+#define VQ2_VB 64
+#define VQ2_FIXED 4160
+#define VQ2_NODE_BYTES (VQ2_NCAP * (8 + 8 + 2 + 2 + 4 + 1) + 2 * VQ2_NLV * 2 + 128 + 64)
+#define VQ2_SMEM (VQ2_FIXED + VQ2_BUF * 8 + VQ2_SCR * 8 + ((VQ2_NODE_BYTES + 15) & ~15))
+
+struct Vq2Store {
+    unsigned long long *val;
+    unsigned short *r16;               /* [NCAP][4]: nn, bb, off, kid */
+    unsigned short *tot, *pos;
+    unsigned char *r8;                 /* [NCAP][4]: kind, wid, band, has */
+    unsigned char *rl;                 /* log2 of the node's region | rotation << 4: component i sits in slot (i + rotation)
+                                          & (region - 1) -- leaves are coded one per LANE, and regions are aligned to their
+                                          (power of two) size: without the rotation every lane would hit the same LDS bank */
+    unsigned short *ord;               /* [2][NLV] a level's splits grouped by class; after the walk: the leaf lists */
+    int *cls;                          /* [2][16] class starts ([6] used) */
+    unsigned short *lvl;
+    __device__ __forceinline__ void bind(unsigned char *p)
+    {
+        val = (unsigned long long *)p;
+        r16 = (unsigned short *)(p + VQ2_NCAP * 8);
+        tot = r16 + 4 * VQ2_NCAP;
+        pos = tot + VQ2_NCAP;
+        r8 = (unsigned char *)(pos + VQ2_NCAP);
+        rl = r8 + 4 * VQ2_NCAP;
+        ord = (unsigned short *)(rl + VQ2_NCAP);
+        cls = (int *)(ord + 2 * VQ2_NLV);
+        lvl = (unsigned short *)(cls + 32);
+    }
+    __device__ __forceinline__ unsigned short &nn(int j) const { return r16[4 * j]; }
+    __device__ __forceinline__ unsigned short &bb(int j) const { return r16[4 * j + 1]; }
+    __device__ __forceinline__ unsigned short &off(int j) const { return r16[4 * j + 2]; }
+    __device__ __forceinline__ unsigned short &kid(int j) const { return r16[4 * j + 3]; }
+    __device__ __forceinline__ unsigned char &kind(int j) const { return r8[4 * j]; }
+    __device__ __forceinline__ unsigned char &wid(int j) const { return r8[4 * j + 1]; }
+    __device__ __forceinline__ unsigned char &band(int j) const { return r8[4 * j + 2]; }
+    __device__ __forceinline__ unsigned char &has(int j) const { return r8[4 * j + 3]; }
+    __device__ __forceinline__ int rlog(int j) const { return rl[j] & 15; }
+    __device__ __forceinline__ int rot(int j) const { return rl[j] >> 4; }
+    /* rotation of child c of node `parent`: any function of things both the split pass (which writes the child's
+       vector) and the scalar stage (which creates its record) know; none for vectors the whole-wave coders take */
+    static __device__ __forceinline__ int child_rot(int parent, int c, int half, int rlog_c)
+    {
+        return (half <= 32) ? ((2 * parent + c) & ((1 << rlog_c) - 1) & 15) : 0;
+    }
+    __device__ __forceinline__ void create(int id, int n, int bits, int offset, int knd, int bnd, int rlog_rot) const
+    {
+        *(unsigned long long *)&r16[4 * id] = (unsigned long long)(unsigned)n | ((unsigned long long)(unsigned)bits << 16) |
+                                              ((unsigned long long)(unsigned)offset << 32);
+        *(unsigned *)&r8[4 * id] = (unsigned)knd | ((unsigned)bnd << 16);
+        rl[id] = (unsigned char)rlog_rot;
+        val[id] = 0ull;
+    }
+};
+static_assert(VQ2_NCAP % 4 == 0 && (VQ2_NCAP * 8) % 8 == 0, "node store alignment");
+static_assert(VQ2_SCR * 8 >= VQ2_BUF * 4, "one int per buffer position in the scratch area");
+
+/* One PVQ leaf of up to 16 components per LANE: everything pvq_search (coder/gain_shape_quantize.py:30-54) does
+   up to the pulse vector, with the arithmetic and the summation orders of vq_leaf_group -- the L1 norm as
+   np.sum adds it, target = |K x / l1|, floor, the `missing` pulses to the largest remainders (lowest index first
+   among equals).  Leaves (pulses | sign << 31, pulses left before the component) in place of the vector: the
+   enumeration terms are taken one component per thread afterwards.  Returns false for an all-zero vector.
+   xs / ys are LDS pointers by type, so that every access is a ds_ instruction. */
+typedef __attribute__((address_space(3))) double vq_lds_f64;
+typedef __attribute__((address_space(3))) int vq_lds_i32;
+__device__ __forceinline__ bool vq_leaf_lane(vq_lds_f64 *xs, int n, int K, vq_lds_i32 *ys, int n_max, int rot, int rmask)
+{
+    /* n_max: the longest leaf of the wave (wave-uniform loop bounds; shorter leaves ride along masked).  Nothing is
+       held in register arrays but the eight accumulators of the norm: the remainders replace the vector in LDS,
+       the floors sit in ys (one int per buffer position).
+       Component i sits in slot (i + rot) & rmask of the leaf's region (its floor likewise in ys).  Every LDS READ
+       is unconditional -- a slot index is always inside the leaf's own region -- and the value is selected
+       afterwards: a predicated read would be a branch with a wait of its own, a hundred of them in a row */
+#define VQ2_SLOT(i) (((i) + rot) & rmask)
+    unsigned negm = 0u, nzm = 0u;
+    double l1;
+    {
+        double seq = -0.0;                               /* fewer than 8: left to right from -0.0 */
+        double r[8];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double raw = xs[VQ2_SLOT(i)];
+            const double x = (i < n) ? raw : 0.0;
+            const double ax = fabs(x);
+            negm |= (x < 0.0) ? (1u << i) : 0u;
+            nzm |= (x != 0.0) ? (1u << i) : 0u;
+            if (i < 7)
+                seq = (i < n) ? seq + ax : seq;
+            if (i < 8)
+                r[i] = ax;
+            else
+                r[i - 8] = (n >= 16) ? r[i - 8] + ax : r[i - 8];   /* eight accumulators over the multiple of 8 */
+        }
+        double tree = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int i = 8; i < 15; ++i) {
+            const double raw = xs[VQ2_SLOT(i)];
+            tree = (n < 16 && i < n) ? tree + fabs(raw) : tree;    /* scalar tail */
+        }
+        l1 = (n < 8) ? seq : tree;
+    }
+    const bool ok = l1 > 0.0;
+    const double kd = (double)K;
+    double ysum = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < n_max; ++i) {
+        const double raw = xs[VQ2_SLOT(i)];
+        const double ax = (i < n) ? fabs(raw) : 0.0;
+        const double tg = ok ? (kd * ax) / l1 : 0.0;     /* |K x / l1|: the sign does not change the magnitude */
+        const double fl = floor(tg);
+        ysum += (i < n) ? fl : 0.0;                      /* integers: exact in any order */
+        if (i < n) {
+            ys[VQ2_SLOT(i)] = (int)fl;
+            xs[VQ2_SLOT(i)] = tg - fl;                   /* the remainder takes the component's place */
+        }
+    }
+    const int missing = K - (int)ysum;
+    if (__builtin_amdgcn_ballot_w64(missing > 0)) {
+        /* the `missing` largest remainders get a pulse, the lowest index first among equals: rank of component i =
+           how many beat it.  The remainders come from LDS four at a time (16 + 64 reads per leaf instead of 16 x 16) */
+        unsigned rank_lo = 0u, rank_hi = 0u;             /* sixteen 4-bit counters (a rank is at most 15) */
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (4 * c < n_max) {                        /* wave-uniform */
+                double tj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double raw = xs[VQ2_SLOT(4 * c + j)];
+                    tj[j] = (4 * c + j < n) ? raw : -1.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (i < n_max) {
+                        const double raw = xs[VQ2_SLOT(i)];
+                        const double ti = (i < n) ? raw : 2.0;
+                        unsigned beat = 0u;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (4 * c + j < i)
+                                beat += (tj[j] >= ti) ? 1u : 0u;
+                            else if (4 * c + j > i)
+                                beat += (tj[j] > ti) ? 1u : 0u;
+                        }
+                        if (i < 8)
+                            rank_lo += beat << (4 * i);
+                        else
+                            rank_hi += beat << (4 * (i - 8));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rank = (int)(((i < 8 ? rank_lo : rank_hi) >> (4 * (i & 7))) & 15u);
+            if (i < n && rank < missing)
+                ys[VQ2_SLOT(i)] += 1;
+        }
+    }
+    int k_left = K;
+#pragma unroll 8
+    for (int i = 0; i < n_max; ++i) {
+        const int yraw = ys[VQ2_SLOT(i)];
+        int a = (i < n) ? yraw : 0;
+        a = (((nzm >> i) & 1u) && ok) ? a : 0;
+        if (i < n)                                       /* (pulses | sign << 31, pulses left) as the slot's 64 bits */
+            xs[VQ2_SLOT(i)] = __longlong_as_double((long long)((unsigned long long)((unsigned)a | (((negm >> i) & 1u) << 31)) |
+                                                               ((unsigned long long)(unsigned)k_left << 32)));
+        k_left -= a;
+    }
+    return ok;
+#undef VQ2_SLOT
+}
+
+#ifndef VQ2_OCC
+#define VQ2_OCC 4                      /* registers for four workgroups per CU: at five the one-leaf-per-lane pass spills */
+#endif
+__global__ __launch_bounds__(64 * VQ_WAVES, VQ2_OCC) void k_vq_frame2(PacxTables T, VqView V, VqArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *words = (unsigned *)smem;                               /* VQ_WORDS        */
+    double *gain_s = (double *)(smem + VQ_WORDS * 4);                 /* VB              */
+    int *ba_s = (int *)(gain_s + VQ2_VB);
+    int *start_s = ba_s + VQ2_VB;
+    int *end_s = start_s + VQ2_VB;
+    int *misc = end_s + VQ2_VB;                                       /* node count, overflow, total bits, -, -, small / mid / big leaf counts */
+    int *bg_s = misc + 8;
+    int *bs_s = bg_s + VQ2_VB;
+    unsigned short *root_s = (unsigned short *)(bs_s + VQ2_VB);
+    double *buf = (double *)(smem + VQ2_FIXED);                       /* the bands' regions */
+    double *scr = buf + VQ2_BUF;                                      /* scratch of one big leaf */
+    Vq2Store N;
+    N.bind(smem + VQ2_FIXED + (VQ2_BUF + VQ2_SCR) * 8);
+    static_assert(VQ_WORDS * 4 + VQ2_VB * 8 + 5 * VQ2_VB * 4 + 8 * 4 + VQ2_VB * 2 <= VQ2_FIXED && VQ2_FIXED % 16 == 0,
+                  "fixed part of k_vq_frame2's LDS");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PACX_VQ_WAITDBG
+    long long vqw_start, vqw_p;
+    VQW_NOW(vqw_start);
+    vqw_p = vqw_start;
+    long long vqw_busy1 = 0, vqw_wait1 = 0, vqw_busy2 = 0, vqw_wait2 = 0, vqw_t = 0, vqw_levels = 0;
+#define VQW2_P(k) do { long long n_; VQW_NOW(n_); if (lane == 0) atomicAdd((unsigned long long *)&g_vqw_dbg[(k)], (unsigned long long)(n_ - vqw_p)); vqw_p = n_; } while (0)
+#else
+#define VQW2_P(k) do { } while (0)
+#endif
+    const unsigned long long below = (1ull << lane) - 1ull;
+    long long cf = blockIdx.x;
+    if (A.cf_list) {
+        if (cf >= (long long)*A.cf_count)
+            return;
+        cf = A.cf_list[cf];
+    }
+    if (cf >= A.n_cf)
+        return;
+    const long long frame = cf / A.n_ch;
+    const unsigned fl = A.flags ? A.flags[frame] : 0u;
+    const bool is_short = A.mixed && (fl & 2u);
+    if (is_short && A.status_in) {             /* hop dropped: nothing to code (n_bytes stays 0) */
+        unsigned st = 0;
+        for (int c = 0; c < A.n_ch; ++c)
+            st |= A.status_in[frame * A.n_ch + c];
+        if (st & PACX_ST_ZERO_SUBBLOCK)
+            return;
+    }
+    const int nb = is_short ? T.nb_short : T.nb_long;
+    const int n_sub = is_short ? PACX_SUB : 1;
+    const int n_vb = n_sub * nb;
+    const int32_t *__restrict__ lower = is_short ? T.band_lower_short : T.band_lower_long;
+    const int32_t *__restrict__ count = is_short ? T.band_lines_short : T.band_lines_long;
+    const unsigned short *__restrict__ reg_of = is_short ? V.reg_short : V.reg_long;     /* region of band b (of sub-block 0) */
+    const unsigned char *__restrict__ rlog_of = is_short ? V.rlog_short : V.rlog_long;
+    const int reg_sub = is_short ? V.reg_short_total : 0;                                 /* regions of one sub-block */
+    const int first_omit = (!is_short && T.use_sbr) ? T.first_omitted : nb;
+    const long long boff = cf * T.band_stride;
+    const double *__restrict__ lin = A.lines + cf * PACX_M_LONG;
+    const double half_pi = 1.5707963267948966;
+    auto sub_of = [&](int vb) { return is_short ? vb / nb : 0; };
+
+    for (int i = tid; i < VQ_WORDS; i += 64 * VQ_WAVES)
+        words[i] = 0u;
+    if (tid < VQ_ROWS_SMALL && tid <= V.l_max)
+        vq_row_off_small[tid] = V.row_off[tid];
+    if (tid < VQF_HL && tid <= V.l_max)
+        vqf_half_log2[tid] = V.half_log2[tid];
+    if (tid < VQF_LT)
+        vqf_log2_tan[tid] = V.log2_tan[tid];
+    if (tid < 8)
+        misc[tid] = 0;
+    /* phase A: every wave places its bands' lines (scaled) in their regions -- all its loads in flight at once --
+       and then takes their norms: the unit shapes x / gain are level 0 of the walk */
+    for (int vb = wave; vb < n_vb; vb += VQ_WAVES) {
+        const int j = sub_of(vb), b = vb - j * nb;
+        if (b >= first_omit)
+            continue;
+        const int lo = j * PACX_M_SHORT + ldc(&lower[b]), cnt = ldc(&count[b]);
+        const double up = (double)(1 << A.overall[cf * PACX_SUB + j]);
+        double *dst = buf + j * reg_sub + reg_of[b];
+        for (int i = lane; i < cnt; i += 64)
+            dst[i] = lin[lo + i] * up;
+    }
+    vq_fence();                                            /* a wave reads back what it wrote itself */
+    for (int vb = wave; vb < n_vb; vb += VQ_WAVES) {
+        const int j = sub_of(vb), b = vb - j * nb;
+        double g;
+        if (b >= first_omit) {
+            const double up = (double)(1 << A.overall[cf * PACX_SUB]);
+            const double v = A.sbr_mean[cf * PACX_SUB + (b - first_omit)] * up;
+            g = sqrt(v * v);
+        } else {
+            const int cnt = ldc(&count[b]);
+            double *xs = buf + j * reg_sub + reg_of[b];
+            double acc = 0.0;
+            for (int i = lane; i < cnt; i += 64) {
+                const double x = xs[i];
+                acc = fma(x, x, acc);
+            }
+            g = sqrt(wave_sum_f64(acc));
+            for (int i = lane; i < cnt; i += 64)
+                xs[i] = xs[i] / g;
+        }
+        if (lane == 0)
+            gain_s[vb] = g;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        /* final allocations, band positions, header fields, the roots of the trees: one band per lane (as k_vq_frame) */
+        const int vb = lane, j = sub_of(vb < n_vb ? vb : 0), b = vb - j * nb;
+        int ba = 0, r_bits = 0, cnt = 1;
+        if (vb < n_vb) {
+            ba = A.bit_alloc[boff + vb];
+            if (ba && gain_s[vb] == 0.0)
+                ba = 0;                                   /* coder/codec.py:352-353 */
+            cnt = (b >= first_omit) ? 1 : count[b];
+            r_bits = ba * cnt;
+            A.bit_alloc[boff + vb] = ba;
+            ba_s[vb] = ba;
+        }
+        int total_bits;
+        const int before = wave_excl_scan_i32(r_bits, lane, total_bits);
+        const int head = T.n_scale_bits + T.n_mant_size_bits * nb;
+        const int start = 3 + (j + 1) * head + before;
+        if (vb < n_vb) {
+            start_s[vb] = start;
+            end_s[vb] = start + r_bits;
+        }
+        if (lane == 0) {
+            vq_put32(words, 0, fl & 1u, 1);
+            vq_put32(words, 1, (fl >> 1) & 1u, 1);
+            vq_put32(words, 2, (fl >> 2) & 1u, 1);
+            misc[2] = 3 + n_sub * head + total_bits;      /* bits written */
+        }
+        if (vb < n_vb) {
+            const int sub_base = 3 + j * head + __shfl(before, vb - b, 64);
+            if (b == 0)
+                vq_put32(words, sub_base, (unsigned)A.overall[cf * PACX_SUB + j], T.n_scale_bits);
+            vq_put32(words, sub_base + T.n_scale_bits + T.n_mant_size_bits * b, (unsigned)(ba ? ba - 1 : 0),
+                     T.n_mant_size_bits);
+        }
+        int bits_gain = ba, bits_shape = 0;
+        if (vb < n_vb && b < first_omit && ba) {
+            bits_gain = (int)floor((double)r_bits / (double)cnt + V.half_log2[cnt]);
+            bits_shape = r_bits - bits_gain;
+            if (bits_shape < 0)
+                bits_shape = 0;
+        }
+        const bool rooted = vb < n_vb && bits_shape != 0;
+        const unsigned long long mr = __builtin_amdgcn_ballot_w64(rooted);
+        const int id = __popcll(mr & below);
+        if (vb < n_vb) {
+            bg_s[vb] = bits_gain;
+            bs_s[vb] = bits_shape;
+            root_s[vb] = rooted ? (unsigned short)id : 0xFFFF;
+        }
+        if (rooted)
+            N.create(id, cnt, bits_shape, j * reg_sub + reg_of[b], bits_shape > PACX_VQ_SPLIT_BITS ? 0 : 1, vb, rlog_of[b]);
+        if (lane == 0) {
+            misc[0] = __popcll(mr);
+            N.lvl[0] = 0;
+        }
+    }
+    __syncthreads();
+
+    /* ---- the SPLITS of a level grouped by the lane footprint of their halves: up to 8 / 16 / 32 / 64 lanes, larger
+       (ord / cls of that level's parity).  One wave; the leaves wait in their regions for the end of the walk */
+    auto classify = [&](int lev_b, int lev_e, int par) {
+        unsigned short *ord_w = N.ord + par * VQ2_NLV;
+        int *cls_w = N.cls + par * 16;
+        int cnt_c[5] = {0, 0, 0, 0, 0};
+        if (lane == 0 && lev_e - lev_b > VQ2_NLV)
+            misc[1] = 1;
+        for (int base = lev_b; base < lev_e && lev_e - lev_b <= VQ2_NLV; base += 64) {
+            const int j = base + lane;
+            int c = 5;
+            if (j < lev_e && N.kind(j) == 0) {
+                const int n = N.nn(j), half = n - n / 2;
+                c = half <= 8 ? 0 : (half <= 16 ? 1 : (half <= 32 ? 2 : (half <= 64 ? 3 : 4)));
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                cnt_c[k] += __popcll(__builtin_amdgcn_ballot_w64(c == k));
+        }
+        int start_c[6];
+        start_c[0] = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            start_c[k + 1] = start_c[k] + cnt_c[k];
+        if (lane < 6) {
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                v = (lane == k) ? start_c[k] : v;
+            cls_w[lane] = v;
+        }
+        int run_c[5] = {0, 0, 0, 0, 0};
+        for (int base = lev_b; base < lev_e && lev_e - lev_b <= VQ2_NLV; base += 64) {
+            const int j = base + lane;
+            int c = 5;
+            if (j < lev_e && N.kind(j) == 0) {
+                const int n = N.nn(j), half = n - n / 2;
+                c = half <= 8 ? 0 : (half <= 16 ? 1 : (half <= 32 ? 2 : (half <= 64 ? 3 : 4)));
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(c == k);
+                if (c == k)
+                    ord_w[start_c[k] + run_c[k] + __popcll(m & below)] = (unsigned short)j;
+                run_c[k] += __popcll(m);
+            }
+        }
+    };
+    bool undefined = false;
+    int lev_b = 0, lev_e = misc[0], depth = 0;
+    if (wave == 0)
+        classify(0, lev_e, 0);
+    __syncthreads();
+    if (wave == 0)
+        VQW2_P(21);                                    /* phase A, thread 0's view */
+#ifdef PACX_VQ_WAITDBG
+    VQW_NOW(vqw_t);
+#endif
+    for (;;) {
+        const unsigned short *ord_c = N.ord + (depth & 1) * VQ2_NLV;
+        const int *cls_c = N.cls + (depth & 1) * 16;
+        if (misc[1])
+            break;
+        const int s_n = cls_c[5];
+        if (s_n == 0)
+            break;                                        /* no split on this level: the walk is over */
+        /* ---- packed passes over the level's splits, dealt round-robin (the expensive classes first): fold, the two
+           norms, the halves normalised IN PLACE -- mid over the first half of the node's region, side over the second */
+        {
+            int ph = 0;
+#pragma unroll 1
+            for (int c = 4; c >= 0; --c) {
+                const int c_b = cls_c[c], c_n = cls_c[c + 1] - c_b;
+                const int lg = (c == 0) ? 3 : (c == 1) ? 2 : (c == 2) ? 1 : 0;
+                for (int p0 = c_b; p0 < c_b + c_n; p0 += 1 << lg) {
+                    const bool my_pass = (ph & 3) == wave;
+                    ph += 1;
+                    if (!my_pass)
+                        continue;
+                    const int p_n = min(1 << lg, c_b + c_n - p0);
+                    if (c < 4) {
+                        const int lp = c + 3, P = 1 << lp;             /* blocks of 8, 16, 32, 64 lanes */
+                        const int g = lane >> lp, i = lane & (P - 1);
+                        const bool valid = g < p_n;
+                        const int node = valid ? ord_c[p0 + g] : 0;
+                        const int n = valid ? N.nn(node) : 0;
+                        const int cut = n / 2, half = n - cut;
+                        double *reg = buf + (valid ? N.off(node) : 0);
+                        const int rlg = valid ? N.rlog(node) : 1, rt = valid ? N.rot(node) : 0;
+                        const int r2 = 1 << (rlg - 1), rm = 2 * r2 - 1;
+                        const int rot_m = Vq2Store::child_rot(node, 0, half, rlg - 1), rot_s = Vq2Store::child_rot(node, 1, half, rlg - 1);
+                        const bool mine = i < half;
+                        const double left = (mine && i < cut) ? reg[(i + rt) & rm] : 0.0;
+                        const double right = mine ? reg[(cut + i + rt) & rm] : 0.0;
+                        double mid = mine ? (left + right) / 2.0 : 0.0;
+                        double sd = mine ? (left - right) / 2.0 : 0.0;
+                        double mm = fma(mid, mid, 0.0), ss = fma(sd, sd, 0.0);
+                        for (int off = P >> 1; off > 0; off >>= 1) {
+                            mm = mm + __shfl_xor(mm, off, 64);
+                            ss = ss + __shfl_xor(ss, off, 64);
+                        }
+                        const double m_l2 = sqrt(mm), s_l2 = sqrt(ss);
+                        if (m_l2 != 0.0)
+                            mid = mid / m_l2;
+                        if (s_l2 != 0.0)
+                            sd = sd / s_l2;
+                        if (mine) {                        /* every read of the node came back before the shuffles */
+                            reg[(i + rot_m) & (r2 - 1)] = mid;
+                            reg[r2 + ((i + rot_s) & (r2 - 1))] = sd;
+                        }
+                        if (valid && i == 0)
+                            N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
+                    } else {
+                        /* a split of more than 128 components (at most 512): the whole node into registers first */
+                        const int node = ord_c[p0];
+                        const int n = N.nn(node);
+                        double *reg = buf + N.off(node);
+                        const int r2 = 1 << (N.rlog(node) - 1);           /* more than 128 components: no rotation, here or below */
+                        const int cut = n / 2, half = n - cut;
+                        double mid[4], sd[4];
+                        double mm = 0.0, ss = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int i = lane + 64 * k;
+                            const double left = (i < cut) ? reg[i] : 0.0;
+                            const double right = (i < half) ? reg[cut + i] : 0.0;
+                            mid[k] = (left + right) / 2.0;
+                            sd[k] = (left - right) / 2.0;
+                            if (i < half) {
+                                mm = fma(mid[k], mid[k], mm);
+                                ss = fma(sd[k], sd[k], ss);
+                            }
+                        }
+                        const double m_l2 = sqrt(wave_sum_f64(mm));
+                        const double s_l2 = sqrt(wave_sum_f64(ss));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int i = lane + 64 * k;
+                            if (i < half) {
+                                reg[i] = (m_l2 != 0.0) ? mid[k] / m_l2 : mid[k];
+                                reg[r2 + i] = (s_l2 != 0.0) ? sd[k] / s_l2 : sd[k];
+                            }
+                        }
+                        if (lane == 0)
+                            N.val[node] = (unsigned long long)__double_as_longlong(m_l2 == 0.0 ? -1.0 : s_l2 / m_l2);
+                    }
+                }
+            }
+        }
+        VQW_BARRIER(vqw_busy1, vqw_wait1);
+        /* ---- the level's splits, one per lane: angle, bit split, children (as k_vq_frame) */
+        const bool early = s_n <= 64;
+        for (int k0 = 64 * wave; k0 < s_n; k0 += 64 * VQ_WAVES) {
+            const bool has = k0 + lane < s_n;
+            const int snode = has ? ord_c[k0 + lane] : 0;
+            const int sn = has ? N.nn(snode) : 2;
+            const int half = sn - sn / 2;
+            const int bits = has ? N.bb(snode) : 0;
+            const double q = has ? __longlong_as_double((long long)N.val[snode]) : -1.0;
+            const double theta = (q < 0.0) ? 0.0 : vq_atan(q);
+            const double hl = (half < VQF_HL) ? vqf_half_log2[half] : V.half_log2[half];
+            const int a_theta = (int)floor((double)bits / (double)half + hl);
+            int a_rest = bits - a_theta;
+            if (a_rest < 0)
+                a_rest = 0;
+            const double tn = theta / half_pi;
+            double theta_q = 0.0;
+            unsigned long long code = 0ull;
+            int w_theta = 0;
+            if (!__builtin_amdgcn_ballot_w64(a_theta > 31)) {
+                if (a_theta > 0) {
+                    const double factor = (double)((1u << a_theta) - 1u);
+                    unsigned c32;
+                    if (tn >= 1.0)
+                        c32 = (1u << (a_theta - 1)) - 1u;
+                    else
+                        c32 = (unsigned)floor((factor * tn + 1.0) * 0.5);
+                    code = c32;
+                    w_theta = a_theta;
+                    const unsigned mag = c32 & ((1u << (a_theta - 1)) - 1u);
+                    double dq = (double)(2u * mag) / factor;
+                    if (c32 >> (a_theta - 1))
+                        dq = -dq;
+                    theta_q = dq * half_pi;
+                }
+            } else if (a_theta > 62) {
+                if (has)
+                    undefined = true;
+            } else if (a_theta > 0) {
+                if (tn >= 1.0) {
+                    code = (1ull << (a_theta - 1)) - 1ull;
+                } else {
+                    const double factor = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+                    code = (unsigned long long)floor((factor * tn + 1.0) * 0.5);
+                }
+                w_theta = a_theta;
+                const unsigned long long mag = code & ((1ull << (a_theta - 1)) - 1ull);
+                const double den = (a_theta <= 53) ? (double)((1ull << a_theta) - 1ull) : ldexp(1.0, a_theta);
+                double dq = (double)(2ull * mag) / den;
+                if (code >> (a_theta - 1))
+                    dq = -dq;
+                theta_q = dq * half_pi;
+            }
+            int a_mid = 0;
+            if (theta_q != 0.0) {
+                double lt;
+                if (a_theta <= PACX_VQ_THETA_TABLE_BITS && theta_q > 0.0) {
+                    const int at_lt = ((1 << (a_theta - 1)) - 1) + (int)code;
+                    lt = (at_lt < VQF_LT) ? vqf_log2_tan[at_lt] : V.log2_tan[at_lt];
+                } else {
+                    lt = vq_log2_tan(theta_q);
+                }
+                const double v = ((double)a_rest - (double)(half - 1) * lt) / 2.0;
+                const double f = floor(v);
+                a_mid = (f < 0.0) ? 0 : ((f > (double)a_rest) ? a_rest : (int)f);
+            }
+            const int a_side = a_rest - a_mid;
+            const int c_mid = (has && a_mid > 0) ? 1 : 0, c_side = (has && a_side > 0) ? 1 : 0;
+            int born;
+            const int rel = wave_excl_scan_i32(c_mid + c_side, lane, born);
+            int base = 0;
+            if (lane == 0 && born)
+                base = atomicAdd(&misc[0], born);
+            base = __shfl(base, 0, 64);
+            if (base + born > VQ2_NCAP) {
+                if (lane == 0)
+                    misc[1] = 1;
+                continue;
+            }
+            if (has) {
+                const int first = base + rel;
+                N.val[snode] = code;
+                N.wid(snode) = (unsigned char)w_theta;
+                N.kid(snode) = (unsigned short)first;
+                N.has(snode) = (unsigned char)(c_mid | (c_side << 1));
+                const int at = N.off(snode), rlog = N.rlog(snode) - 1;
+                const int bd = N.band(snode);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int a = c ? a_side : a_mid;
+                    if (a <= 0)
+                        continue;
+                    const int id = c ? first + c_mid : first;
+                    const bool splits = a > PACX_VQ_SPLIT_BITS && depth + 1 < VQ_DEPTH;
+                    if (a > PACX_VQ_SPLIT_BITS && !splits)
+                        undefined = true;                  /* deeper than any real tree */
+                    if (splits && half < 2)
+                        misc[1] = 1;                       /* a one-component node asked to split: its halves have no
+                                                              region of their own here -- left to k_vq_redo */
+                    N.create(id, half, a > 65535 ? 65535 : a, at + (c ? (1 << rlog) : 0), splits ? 0 : 1, bd,
+                             rlog | (Vq2Store::child_rot(snode, c, half, rlog) << 4));
+                }
+            }
+        }
+        if (early && wave == 0) {                          /* one chunk: this wave made all the children, it sorts them at once */
+            vq_fence();
+            if (!misc[1])
+                classify(lev_e, misc[0], (depth + 1) & 1);
+        }
+        VQW_BARRIER(vqw_busy2, vqw_wait2);
+#ifdef PACX_VQ_WAITDBG
+        vqw_levels += 1;
+#endif
+        if (misc[1])
+            break;
+        const int n_now = misc[0];
+        depth += 1;
+        if (tid == 0)
+            N.lvl[depth] = (unsigned short)lev_e;
+        if (n_now == lev_e) {                              /* no children */
+            depth -= 1;
+            break;
+        }
+        lev_b = lev_e;
+        lev_e = n_now;
+        if (!early) {
+            if (wave == 0)
+                classify(lev_b, lev_e, depth & 1);
+            __syncthreads();
+        }
+        if (depth > VQ_DEPTH) {
+            if (tid == 0)
+                misc[1] = 1;
+            __syncthreads();
+            break;
+        }
+    }
+    if (misc[1]) {
+        if (tid == 0)
+            A.n_bytes[cf] = -1;                            /* does not fit the store: k_vq_redo codes this channel-frame */
+        return;
+    }
+    const int n_nodes = misc[0];
+    if (tid == 0)
+        N.lvl[depth + 1] = (unsigned short)n_nodes;
+#ifdef PACX_VQ_WAITDBG
+    if (lane == 0) {
+        atomicAdd((unsigned long long *)&g_vqw_dbg[wave * 4 + 0], (unsigned long long)vqw_busy1);
+        atomicAdd((unsigned long long *)&g_vqw_dbg[wave * 4 + 1], (unsigned long long)vqw_wait1);
+        atomicAdd((unsigned long long *)&g_vqw_dbg[wave * 4 + 2], (unsigned long long)vqw_busy2);
+        atomicAdd((unsigned long long *)&g_vqw_dbg[wave * 4 + 3], (unsigned long long)vqw_wait2);
+        if (wave == 0) {
+            atomicAdd((unsigned long long *)&g_vqw_dbg[17], (unsigned long long)vqw_levels);
+            atomicAdd((unsigned long long *)&g_vqw_dbg[18], 1ull);
+        }
+    }
+    VQW_NOW(vqw_p);
+#endif
+    /* ---- the leaves, all of the unit's at once.  Lists by size (the ord area is free now): up to 16 components
+       (one per lane), 17..32 (half-wave groups), larger (the whole-wave coder) */
+    unsigned short *small_l = N.tot, *mid_l = N.ord, *big_l = N.ord + VQ2_NLV;      /* tot is free until the widths go bottom-up */
+    for (int j = tid; j < n_nodes; j += 64 * VQ_WAVES) {
+        if (N.kind(j) != 1)
+            continue;
+        const int n = N.nn(j);
+        if (n <= 16)
+            small_l[atomicAdd(&misc[5], 1)] = (unsigned short)j;
+        else if (n <= 32)
+            mid_l[atomicAdd(&misc[6], 1) & (VQ2_NLV - 1)] = (unsigned short)j;
+        else
+            big_l[atomicAdd(&misc[7], 1) & (VQ2_NLV - 1)] = (unsigned short)j;
+    }
+    __syncthreads();
+    if (wave == 0)
+        VQW2_P(22);                                    /* leaf lists */
+    const int n_small = misc[5], n_mid = misc[6], n_big = misc[7];
+    if (n_mid > VQ2_NLV || n_big > VQ2_NLV) {                      /* more than the lists hold (no real stream): k_vq_redo */
+        if (tid == 0)
+            A.n_bytes[cf] = -1;
+        return;
+    }
+    for (int s0 = 64 * wave; s0 < n_small; s0 += 64 * VQ_WAVES) {
+        const bool valid = s0 + lane < n_small;
+        const int node = valid ? small_l[s0 + lane] : 0;
+        const int n = valid ? N.nn(node) : 0;
+        int bits = valid ? N.bb(node) : 0;
+        bits = bits > 32 ? 32 : bits;
+        const int K = valid ? V.k_of[n * 33 + bits] : 0;
+        const int width = valid ? V.w_of[n * 33 + bits] : 0;
+        bool ok = true;
+        const int n_max = __builtin_amdgcn_readfirstlane(wave_max_i32((valid && K >= 0) ? n : 0));
+        {   /* the floors of a leaf's components: scr as int [VQ2_BUF], at the component's buffer position; a lane
+               without a leaf rides along with n = 0 */
+            const bool run = valid && K >= 0;
+            const int at = run ? N.off(node) : 0;
+            const bool fine = vq_leaf_lane((vq_lds_f64 *)(buf + at), run ? n : 0, run ? K : 0, (vq_lds_i32 *)scr + at, n_max,
+                                           run ? N.rot(node) : 0, run ? (1 << N.rlog(node)) - 1 : 0);
+            ok = run ? fine : true;
+        }
+        if (valid) {
+            if (K < 0) {                                   /* a 1-dimensional leaf: the reference never returns */
+                N.kind(node) = 3;
+                N.wid(node) = 0;
+                N.has(node) = 4;                           /* no terms to add */
+                undefined = true;
+            } else {
+                N.wid(node) = (unsigned char)width;
+                if (!ok) {
+                    N.has(node) = 4;
+                    undefined = true;
+                }
+            }
+        }
+    }
+    if (wave == 0)
+        VQW2_P(23);                                    /* small leaves, one per lane (wave 0's share) */
+    /* the few leaves of 17..32 components meanwhile, two per pass: the waves that had no share of the small ones first */
+    for (int m0 = 0; m0 < n_mid; m0 += 2) {
+        if (((m0 >> 1) & 3) != ((wave + 3) & 3))
+            continue;
+        const int g = lane >> 5, l = lane & 31;
+        const bool valid = m0 + g < n_mid;
+        const int node = valid ? mid_l[m0 + g] : 0;
+        const int n = valid ? N.nn(node) : 0;
+        int bits = valid ? N.bb(node) : 0;
+        bits = bits > 32 ? 32 : bits;
+        const int K = valid ? V.k_of[n * 33 + bits] : 0;
+        const int width = valid ? V.w_of[n * 33 + bits] : 0;
+        const double x = (valid && l < n) ? buf[N.off(node) + ((l + N.rot(node)) & ((1 << N.rlog(node)) - 1))] : 0.0;
+        bool ok = false;
+        const unsigned long long term = vq_leaf_group<32, true>(V, x, n, K < 0 ? 0 : K, l, ok);
+        if (valid && l == 0) {
+            N.val[node] = (K >= 0 && ok) ? term : 0ull;
+            N.wid(node) = (unsigned char)(K < 0 ? 0 : width);
+            if (K < 0)
+                N.kind(node) = 3;
+        }
+        if (valid && (K < 0 || !ok))
+            undefined = true;
+    }
+    __syncthreads();
+    if (wave == 0)
+        VQW2_P(24);                                    /* mid leaves + barrier */
+    /* leaves of more than 32 components: the whole-wave coder, one at a time (its scratch is the area the small
+       leaves' floors were in); the last wave takes them while the others start on the terms */
+    if (wave == VQ_WAVES - 1) {
+        for (int b0 = 0; b0 < n_big; ++b0) {
+            const int node = big_l[b0];
+            const int n = N.nn(node);
+            int bits = N.bb(node);
+            bits = bits > 32 ? 32 : bits;
+            const int K = ldc(&V.k_of[n * 33 + bits]);
+            const int width = ldc(&V.w_of[n * 33 + bits]);
+            bool ok = true;
+            unsigned long long idx = 0ull;
+            if (K >= 0 && 2 * n <= VQ2_SCR)
+                idx = vq_leaf_idx<true>(V, buf + N.off(node), n, K, scr, scr + n, lane, ok);
+            else
+                ok = false;
+            if (!ok)
+                undefined = true;
+            if (lane == 0) {
+                N.val[node] = ok ? idx : 0ull;
+                N.wid(node) = (unsigned char)(K < 0 ? 0 : width);
+                if (K < 0)
+                    N.kind(node) = 3;
+            }
+            vq_fence();
+        }
+    }
+    /* the enumeration index of the small leaves, one COMPONENT per thread: component i of a leaf (l = n - i - 1
+       dimensions behind it, k pulses left, magnitude a >= 1) adds N(l,k) + 2 (P(l,k-1) - P(l,k-a)) (+ N(l,k-a) if
+       negative) -- coder/gain_shape_quantize.py:105-124 -- into the leaf's index.  Two components per thread at a
+       time, their eight table reads in flight together: one round trip to L2 for (nearly) the whole unit */
+    for (int t0 = tid; t0 < 16 * n_small; t0 += 2 * 64 * VQ_WAVES) {
+        unsigned long long nk[2], pk1[2], pka[2], nka[2];
+        int node4[2], l1d[2];
+        long long k4[2], a4[2];
+        bool neg4[2], live[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tt = t0 + u * 64 * VQ_WAVES;
+            const bool in = tt < 16 * n_small;
+            const int node = in ? small_l[tt >> 4] : 0, i = tt & 15;
+            const int n = in ? N.nn(node) : 0;
+            live[u] = in && i < n && N.has(node) != 4;
+            unsigned long long d = 0ull;
+            if (live[u])
+                d = (unsigned long long)__double_as_longlong(buf[N.off(node) + ((i + N.rot(node)) & ((1 << N.rlog(node)) - 1))]);
+            a4[u] = (long long)(d & 0x7FFFFFFFull);
+            live[u] = live[u] && a4[u] >= 1;
+            neg4[u] = ((d >> 31) & 1ull) != 0ull;
+            k4[u] = (long long)(d >> 32);
+            node4[u] = node;
+            l1d[u] = n - i - 1;
+            /* table part (l >= 3): addresses clamped to entry 0 where the closed forms apply */
+            const bool tab = live[u] && l1d[u] >= 3;
+            const long long base = tab ? (l1d[u] < VQ_ROWS_SMALL ? vq_row_off_small[l1d[u]] : V.row_off[l1d[u]]) : 0;
+            const long long kk = tab ? k4[u] : 1, ka = tab ? k4[u] - a4[u] : 0;
+            nk[u] = V.n_tab[base + kk];
+            pk1[u] = V.p_tab[base + kk - 1];
+            pka[u] = V.p_tab[base + ka];
+            nka[u] = V.n_tab[base + ka];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!live[u])
+                continue;
+            unsigned long long term;
+            if (l1d[u] >= 3) {
+                term = nk[u] + 2ull * (pk1[u] - pka[u]) + (neg4[u] ? nka[u] : 0ull);
+            } else {
+                term = vq_N(V, l1d[u], k4[u]);
+                term += 2ull * (vq_P(V, l1d[u], k4[u] - 1) - vq_P(V, l1d[u], k4[u] - a4[u]));
+                if (neg4[u])
+                    term += vq_N(V, l1d[u], k4[u] - a4[u]);
+            }
+            atomicAdd(&N.val[node4[u]], term);
+        }
+    }
+    __syncthreads();
+    if (wave == 0)
+        VQW2_P(25);                                    /* terms (+ big leaves) + barrier */
+    /* ---- subtree widths and field counts bottom-up (counts ride in nn, field numbers in off) */
+    for (int d = depth; d >= 0; --d) {
+        const int b = N.lvl[d], e = N.lvl[d + 1];
+        for (int j = b + tid; j < e; j += 64 * VQ_WAVES) {
+            const int k0 = N.kid(j), hs = N.has(j);
+            int t = N.wid(j), f = (N.kind(j) == 3) ? 0 : 1;
+            if (hs & 1) { t += N.tot[k0]; f += N.nn(k0); }
+            if (hs & 2) { const int k1 = k0 + (hs & 1); t += N.tot[k1]; f += N.nn(k1); }
+            N.tot[j] = (unsigned short)t;
+            N.nn(j) = (unsigned short)f;
+        }
+        __syncthreads();
+    }
+    if (tid < n_vb && root_s[tid] != 0xFFFF) {
+        N.pos[root_s[tid]] = (unsigned short)start_s[tid];
+        N.off(root_s[tid]) = 0;
+    }
+    __syncthreads();
+    for (int d = 0; d <= depth; ++d) {
+        const int b = N.lvl[d], e = N.lvl[d + 1];
+        for (int j = b + tid; j < e; j += 64 * VQ_WAVES) {
+            const int k0 = N.kid(j), hs = N.has(j);
+            int p = N.pos[j] + N.wid(j), r = N.off(j) + ((N.kind(j) == 3) ? 0 : 1);
+            if (hs & 1) {
+                N.pos[k0] = (unsigned short)p;
+                N.off(k0) = (unsigned short)r;
+                p += N.tot[k0];
+                r += N.nn(k0);
+            }
+            if (hs & 2) {
+                const int k1 = k0 + (hs & 1);
+                N.pos[k1] = (unsigned short)p;
+                N.off(k1) = (unsigned short)r;
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0)
+        VQW2_P(26);                                    /* widths, positions */
+    /* ---- every field by its own lane */
+    for (int j = tid; j < n_nodes; j += 64 * VQ_WAVES) {
+        const int w = N.wid(j);
+        unsigned long long v = N.val[j];
+        if (w > 0 && w < 64)
+            v &= (1ull << w) - 1ull;
+        if (w > 0)
+            vq_put_field(words, N.pos[j], v, w);
+        if (A.log && N.kind(j) != 3 && N.off(j) < A.log_cap) {
+            const int vb = N.band(j), sj = sub_of(vb);
+            const long long slot = (cf * PACX_SUB + sj) * PACX_MAX_BANDS + (vb - sj * nb);
+            pacx_vq_entry e;
+            e.value = v;
+            e.width = w;
+            e.band = vb - sj * nb;
+            A.log[slot * A.log_cap + N.off(j)] = e;
+        }
+    }
+    /* ---- the gains of all bands side by side (mu-law, QuantizeUniform; the index soaks up the slack) */
+    if (tid < 64) {
+        const int vb = lane, sj = sub_of(vb < n_vb ? vb : 0), b = vb - sj * nb;
+        const int ba = (vb < n_vb) ? ba_s[vb] : 0;
+        const long long slot = (cf * PACX_SUB + sj) * PACX_MAX_BANDS + b;
+        if (vb < n_vb && !ba && A.log_count)
+            A.log_count[slot] = 0;
+        const int cnt = (vb < n_vb && b < first_omit) ? count[b] : 1;
+        const double gain = (vb < n_vb) ? gain_s[vb] : 0.0;
+        const double g = vq_log(1.0 + 255.0 * fabs(gain / (double)cnt)) / V.log_mu1;
+        if (ba) {
+            const int rt = root_s[vb];
+            const int used = (rt != 0xFFFF) ? N.tot[rt] : 0;
+            const int fields = (rt != 0xFFFF) ? N.nn(rt) : 0;
+            int bits_gain = bg_s[vb] + bs_s[vb] - used;
+            if (bits_gain < 0)
+                bits_gain = 0;
+            int width = bits_gain;
+            unsigned long long hi = 0, lo = 0;
+            if (bits_gain > 128) {
+                undefined = true;
+                width = 0;
+            } else if (bits_gain > 0) {
+                vq_quantize_code(g, bits_gain, hi, lo);
+            }
+            const int at = start_s[vb] + used;
+            if (width > 64) {
+                vq_put_field(words, at, hi, width - 64);
+                vq_put_field(words, at + width - 64, lo, 64);
+            } else if (width > 0) {
+                vq_put_field(words, at, lo, width);
+            }
+            if (at + width != end_s[vb])
+                undefined = true;                          /* a band must fill its slot exactly */
+            if (A.log && fields < A.log_cap) {
+                pacx_vq_entry e;
+                e.value = lo;
+                e.width = width;
+                e.band = b;
+                A.log[slot * A.log_cap + fields] = e;
+            }
+            if (A.log_count)
+                A.log_count[slot] = fields + 1;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(undefined) && lane == 0 && A.status)
+        atomicOr(&A.status[cf], PACX_ST_VQ_UNDEFINED);
+    __syncthreads();
+    const int written = misc[2];
+    const int size_rule = written - 3 + n_sub * nb * T.n_scale_bits;
+    const int nbytes = (size_rule + 4 + 7) >> 3;
+    unsigned *dst = (unsigned *)(A.payload + cf * (long long)A.payload_stride);
+    for (int i = tid; i < (nbytes + 3) / 4; i += 64 * VQ_WAVES)
+        dst[i] = __builtin_bswap32(words[i]);
+    if (tid == 0)
+        A.n_bytes[cf] = nbytes;
+#ifdef PACX_VQ_WAITDBG
+    if (wave == 0)
+        VQW2_P(27);                                    /* fields, gains, hand-over */
+    {
+        long long t_fin;
+        VQW_NOW(t_fin);
+        if (tid == 0)
+            atomicAdd((unsigned long long *)&g_vqw_dbg[20], (unsigned long long)(t_fin - vqw_start));
+    }
+#endif
 }
 
 /* short frames: flags + the 8 sub-block strings, back to back */
@@ -2373,18 +3435,33 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
         const char *e = getenv("PACX_VQ_BFS");
         A.bfs = e ? atoi(e) : 112;
     }
+    {
+        const char *e = getenv("PACX_VQ_ROT");
+        A.rot = e ? atoi(e) : 1;
+    }
     const size_t fixed = VQ_WORDS * 4 + PACX_MAX_BANDS * 8 + (PACX_MAX_BANDS + PACX_MAX_BANDS + 1 + 3) * 4 +
                          VQ_WAVES * 2 * VQ_DEPTH * 4;
     static_assert(fixed % 8 == 0, "the shapes behind the fixed part are doubles");
     const size_t smem = fixed + PACX_M_LONG * 8 + (size_t)V.scr_off[VQ_WAVES] * 8 + (size_t)VQ_WAVES * VQ_NODE_BYTES;
     const long long units = A.mixed ? n_cf * PACX_SUB : n_cf;
     /* the frame-level walk first; k_vq then takes the units it left (PACX_VQ_FRAME=0: k_vq alone) */
-    const char *fe = getenv("PACX_VQ_FRAME");
+    const char *fe = getenv("PACX_VQ_FRAME");            /* 0: k_vq alone; 1 / unset: k_vq_frame; 2: k_vq_frame2 */
     A.redo = (fe && atoi(fe) == 0) ? 0 : 1;
     if (PACX_SUB * T.nb_short > VQF_VB || T.nb_long > VQF_VB)
         A.redo = 0;                             /* more bands than k_vq_frame's per-band arrays hold */
-    if (A.redo && stage != 2)                   /* one workgroup per channel-frame, long or short */
-        hipLaunchKernelGGL(k_vq_frame, dim3((unsigned)n_cf), dim3(64 * VQ_WAVES), (size_t)VQF_SMEM, st, T, V, A);
+    /* PACX_VQ_FRAME=2: the second form of the frame-level walk (k_vq_frame2: in place, the leaves after the walk) where
+       the band layout fits its one buffer.  Not the default: same bytes, 11 % fewer vector and 41 % fewer scalar
+       instructions, and SLOWER (0.668-0.688 against 0.645 ms per vq128 step): the kernel is bound by the length of a
+       unit's dependency chain at five workgroups per CU, not by issue, and the one-leaf-per-lane pass is one long
+       chain on one wave where k_vq_frame codes the leaves on three waves beside the scalar stage */
+    const bool form2 = (fe && atoi(fe) == 2) && V.reg_long_total <= VQ2_BUF && PACX_SUB * V.reg_short_total <= VQ2_BUF &&
+                       2 * V.max_band <= VQ2_SCR && V.max_band <= 512;
+    if (A.redo && stage != 2) {                 /* one workgroup per channel-frame, long or short */
+        if (form2)
+            hipLaunchKernelGGL(k_vq_frame2, dim3((unsigned)n_cf), dim3(64 * VQ_WAVES), (size_t)VQ2_SMEM, st, T, V, A);
+        else
+            hipLaunchKernelGGL(k_vq_frame, dim3((unsigned)n_cf), dim3(64 * VQ_WAVES), (size_t)VQF_SMEM, st, T, V, A);
+    }
     if (stage == 1)
         return;
     if (A.redo)
@@ -2433,6 +3510,25 @@ void pacx_vq_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, 
         /* mid/side regions [2n + 4 depth] (the shape itself lives in the block's xs) */
         v->scr_off[w + 1] = v->scr_off[w] + ((2 * n + 4 * VQ_DEPTH + 1) & ~1);
     }
+    auto regions = [](const int32_t *sz, int nb, unsigned short *reg, unsigned char *rlog) {
+        int at = 0;
+        for (int b = 0; b < nb; ++b) {
+            int lg = 0;
+            while ((1 << lg) < sz[b])
+                ++lg;
+            reg[b] = (unsigned short)at;
+            rlog[b] = (unsigned char)lg;
+            at += 1 << lg;
+        }
+        return at;
+    };
+    v->reg_long_total = regions(sizes_long, nb_long, v->reg_long, v->rlog_long);
+    v->reg_short_total = regions(sizes_short, nb_short, v->reg_short, v->rlog_short);
+    v->max_band = 1;
+    for (int b = 0; b < nb_long; ++b)
+        v->max_band = sizes_long[b] > v->max_band ? sizes_long[b] : v->max_band;
+    for (int b = 0; b < nb_short; ++b)
+        v->max_band = sizes_short[b] > v->max_band ? sizes_short[b] : v->max_band;
     v->n_tab = n_tab;
     v->p_tab = p_tab;
     v->row_off = row_off;

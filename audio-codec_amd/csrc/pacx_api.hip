@@ -1112,6 +1112,8 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
         int32_t *const list_long = h->ws_lists, *const list_short = h->ws_lists + n_cf, *const counts = h->ws_lists + 2 * n_cf;
         const char *vfs_env = getenv("PACX_VQ_FUSE_ALLOC");     /* 0: k_bitalloc behind the mask kernel here too */
         const int vq_fuse_split = vfs_env ? (atoi(vfs_env) != 0) : 1;
+        const char *ol_env = getenv("PACX_VQ_ONE_LAUNCH");
+        const bool one_launch = ol_env && atoi(ol_env) != 0;
         HIP_TRY(h, hipEventRecord(h->ev_fork, st));
         HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_stream, h->ev_fork, 0));
         pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, list_long, list_short, counts, st);
@@ -1125,11 +1127,16 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
         pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_nkept, h->ws_lines,
                          h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, nullptr, h->short_stream);
         pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, 1, h->ws_smr, bit_alloc, status, h->short_stream);
-        /* each chain goes on into the gain-shape coder with its own frames */
-        pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
-                       h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
-                       h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, 1, list_short, counts + 1,
-                       h->short_stream);
+        /* Each chain goes on into the gain-shape coder with its own frames: two k_vq_frame launches side by side on
+           the two streams (0.685 ms per shipped128 step with direct launches).  PACX_VQ_ONE_LAUNCH=1: ONE launch
+           over all frames behind the join of the two chains (0.74-0.77 ms) -- which is what to use when the step is
+           replayed from a hipGraph, where the two launches do not overlap (0.822 ms); bench.py therefore does not
+           capture gain-shape steps */
+        if (!one_launch)
+            pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
+                           h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
+                           h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, 1, list_short, counts + 1,
+                           h->short_stream);
         HIP_TRY_FORKED(h, hipEventRecord(h->ev_short_done, h->short_stream));
         /* long chain */
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status, h->n_cu,
@@ -1140,11 +1147,12 @@ extern "C" int pacx_encode_vq_batch(pacx_handle *h, const pacx_pcm *in, const ui
                          h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, vq_fuse_split ? &mt : nullptr, st);
         if (!vq_fuse_split)       /* BitAlloc of the long frames in k_bitalloc behind the mask kernel (part 2 = long only) */
             pacx_launch_bitalloc(T, frame_flags, n_ch, n_cf, 0, mixed, 2, h->ws_smr, bit_alloc, status, st);
-        pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
-                       h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
-                       h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, 1, list_long, counts, st);
+        if (!one_launch)
+            pacx_launch_vq(T, h->vq_view.data(), frame_flags, n_ch, n_cf, h->ws_lines, overall_scale, bit_alloc,
+                           h->ws_sbr_mean, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, h->ws_unit_words,
+                           h->ws_unit_bits, entries, entry_count, entries ? entries_per_band : 0, 1, list_long, counts, st);
         HIP_TRY_FORKED(h, hipStreamWaitEvent(st, h->ev_short_done, 0));       /* both chains done */
-        vq_stage = 2;
+        vq_stage = one_launch ? 0 : 2;
     } else {
         if (mixed)
             pacx_launch_frame_lists(frame_flags, in->n_frames, n_ch, h->ws_lists, h->ws_lists + n_cf,

@@ -72,7 +72,9 @@ def test_every_kernel_is_reported(res):
 
 def test_only_listed_kernels_use_scratch(res):
     """anything else with scratch is a function-level mirror off the hot path, named here"""
-    allowed = {"k_bitalloc_generic"}        # serial reference-shaped BitAlloc (bitalloc.BitAlloc mirror), one lane per call
+    allowed = {"k_bitalloc_generic",        # serial reference-shaped BitAlloc (bitalloc.BitAlloc mirror), one lane per call
+               "k_vq_frame2"}               # opt-in second form of the gain-shape walk (PACX_VQ_FRAME=2; measured slower, kept
+                                            # as the record of that experiment): one register spilled once per unit
     for name, r in res.items():
         if r["scratch"] or r["vgpr_spill"]:
             assert any(a in name for a in allowed), f"{name}: scratch {r['scratch']}, spilled {r['vgpr_spill']}"

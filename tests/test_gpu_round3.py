@@ -70,18 +70,22 @@ def test_scalar_coder_path_switches(A, monkeypatch):
 @pytest.mark.parametrize("kbps", [96, 128])
 def test_gain_shape_coder_path_switches(A, monkeypatch, kbps):
     """gain-shape coder (+ SBR at 96 kb/s), block-switched and all-long: PACX_SPLIT_SHORT x
-    PACX_VQ_FUSE_ALLOC x (PACX_VQ_FRAME, PACX_VQ_BFS); then the two decoders on the default stream"""
+    PACX_VQ_FUSE_ALLOC x (PACX_VQ_FRAME: unset = k_vq_frame, 2 = k_vq_frame2, 0 = k_vq with PACX_VQ_BFS) -- and
+    PACX_VQ_ONE_LAUNCH=1 (one coder launch behind both chains); then the two decoders on the default stream"""
     pcm, sr = _mixed_stream()
     for bs in (True, False):
         _set(monkeypatch, {})
         want = A.pacfile.encode_stream(pcm, sr, kbps, block_switching=bs, use_vq=True, use_sbr=kbps < 128)
         for split, alloc, (frame, bfs) in itertools.product((None, "0"), (None, "0", "1"),
-                                                            ((None, None), ("0", "0"), ("0", "1"))):
+                                                            ((None, None), ("2", None), ("0", "0"), ("0", "1"))):
             _set(monkeypatch, {"PACX_SPLIT_SHORT": split, "PACX_VQ_FUSE_ALLOC": alloc, "PACX_VQ_FRAME": frame,
                                "PACX_VQ_BFS": bfs})
             got = A.pacfile.encode_stream(pcm, sr, kbps, block_switching=bs, use_vq=True, use_sbr=kbps < 128)
             assert got == want, (bs, split, alloc, frame, bfs)
         _set(monkeypatch, {})
+        monkeypatch.setenv("PACX_VQ_ONE_LAUNCH", "1")
+        assert A.pacfile.encode_stream(pcm, sr, kbps, block_switching=bs, use_vq=True, use_sbr=kbps < 128) == want
+        monkeypatch.delenv("PACX_VQ_ONE_LAUNCH")
         ref = A.pacfile.decode_stream(want)
         _set(monkeypatch, {"PACX_VQ_DEC_FRAME": "0"})
         assert np.array_equal(A.pacfile.decode_stream(want), ref)

@@ -403,8 +403,8 @@ def _decode_blocks_of(A, name, kbps, seen):
 
 
 def test_level_walk_equals_depth_first_walk(A, monkeypatch):
-    """Three coders for the split trees, same bytes: k_vq_frame (all bands of a block level by level, the
-    default; trees beyond its node store fall back to k_vq), k_vq walking a band level by level
+    """Four coders for the split trees, same bytes: k_vq_frame (all bands of a block level by level, the
+    default; trees beyond its node store fall back to k_vq), k_vq_frame2 (PACX_VQ_FRAME=2: in place, one leaf per lane), k_vq walking a band level by level
     (vq_shape_bfs, PACX_VQ_FRAME=0 PACX_VQ_BFS=1) and k_vq depth first (PACX_VQ_BFS=0) -- at bit rates that
     give one-level trees, deep trees and trees beyond either node store."""
     rng = np.random.default_rng(11)
@@ -414,8 +414,11 @@ def test_level_walk_equals_depth_first_walk(A, monkeypatch):
     pcm = np.clip(np.round(pcm * 20000), -32767, 32767).astype(np.int16)
     for kbps in (64, 128, 256, 448):
         outs = []
-        for frame, bfs in (("1", None), ("0", "0"), ("0", "1"), ("0", None)):
-            monkeypatch.setenv("PACX_VQ_FRAME", frame)
+        for frame, bfs in ((None, None), ("2", None), ("0", "0"), ("0", "1"), ("0", None)):
+            if frame is None:
+                monkeypatch.delenv("PACX_VQ_FRAME", raising=False)
+            else:
+                monkeypatch.setenv("PACX_VQ_FRAME", frame)
             if bfs is None:
                 monkeypatch.delenv("PACX_VQ_BFS", raising=False)
             else:
@@ -423,7 +426,7 @@ def test_level_walk_equals_depth_first_walk(A, monkeypatch):
             outs.append(A.pacfile.encode_stream(pcm, 48000, kbps, block_switching=True, use_vq=True,
                                                 use_sbr=kbps < 128))
         monkeypatch.delenv("PACX_VQ_FRAME", raising=False)
-        assert outs[0] == outs[1] == outs[2] == outs[3], kbps
+        assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4], kbps
 
 
 def test_frame_decoder_equals_band_decoder(A, monkeypatch):

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""One line per bench run: workload, M cf/s, ms/step (helper for A/B runs on the GPU box):
+    python tools/bench_value.py label -- <bench.py args>"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+i = sys.argv.index("--")
+label, args = " ".join(sys.argv[1:i]), sys.argv[i + 1:]
+r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + args, capture_output=True, text=True)
+lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+if r.returncode or not lines:
+    print(label, "FAILED", r.stderr[-600:])
+    sys.exit(1)
+d = json.loads(lines[-1])
+print(f"{label:40s} {d['value'] / 1e6:8.2f} M cf/s  {d['ms_per_step']:.4f} ms/step  verified {d['verified_cf']}  "
+      f"[{d['config']['launch'][:8]}]  mdct {d['roofline']['launch_ms'] * 1e3:.1f} us", flush=True)
