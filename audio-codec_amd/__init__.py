@@ -14,6 +14,6 @@ def __getattr__(name):
     # engine / mirrors import torch; keep `import audio_codec_amd` light
     import importlib
     if name in ("engine", "codec", "window", "mdct", "psychoac", "bitalloc", "quantize", "pacfile",
-                "pcmfile", "audiofile", "detect_transients", "synth", "tables", "context", "dist", "build"):
+                "pcmfile", "audiofile", "detect_transients", "synth", "tables", "context", "dist", "build", "streaming"):
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

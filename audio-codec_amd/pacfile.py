@@ -208,7 +208,7 @@ def device_stream(enc, pcm, hop=1024):
 
 
 def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, header_samples=None,
-                  n_scale_bits=4, n_mant_size_bits=12, use_vq=False, use_sbr=False):
+                  n_scale_bits=4, n_mant_size_bits=12, use_vq=False, use_sbr=False, chunk_hops=None):
     """Whole-stream batched encode -> .pac bytes identical to what the
     reference's driver (coder/pacfile.py:674-757) writes for the same PCM:
     scalar mantissas by default; use_vq (+ use_sbr) selects the gain-shape
@@ -229,6 +229,16 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, hea
     cp.useSBR, cp.useVQ = bool(use_sbr), bool(use_vq)
     head = header_bytes(cp)
     enc = context.encoder_for_params(cp)
+    if chunk_hops:
+        # host memory to host memory in chunks: PCM in, kernels and bodies out overlap on three streams
+        # (streaming.HostStreamEncoder); same bytes as the one-batch path below
+        from .streaming import HostStreamEncoder
+        hs = HostStreamEncoder(enc, pcm.shape[1], int(chunk_hops), block_switching=block_switching)
+        parts = [bytes(b) for b in hs.encode(pcm)]
+        if not use_vq:
+            for out in hs.outs:
+                _raise_like_reference(out)
+        return head + b"".join(parts)
     planar = device_stream(enc, pcm, hop)
     view = PcmView.stream(planar, hop)
     if block_switching:

@@ -296,6 +296,10 @@ def main():
                     help="BASELINE configs[4]: the tiled, level-scaled corpus sharded over the ranks "
                          "(strong scaling); --corpus-frames stereo frames in all")
     ap.add_argument("--corpus-frames", type=int, default=CORPUS_FRAMES)
+    ap.add_argument("--host-stream-frames", type=int, default=65536,
+                    help="stereo frames per chunk of the host-memory-to-host-memory measurement reported as "
+                         "config.host_to_host_cf_per_s (pinned PCM in, packed bodies out, copies overlapped with the "
+                         "kernels: audio-codec_amd/streaming.py); 0 = skip.  Never `value`.")
     args = ap.parse_args()
 
     if (args.gpus > 1 or os.environ.get("PACX_BENCH_FORCE_DIST")) and "WORLD_SIZE" not in os.environ:
@@ -550,6 +554,41 @@ def main():
         except Exception:
             pass
 
+    # ---- host memory to host memory (never `value`): the same coder fed from pinned host buffers in chunks, the
+    # PCIe copies of neighbouring chunks overlapping the kernels (streaming.HostStreamEncoder)
+    host_stream = None
+    if rank == 0 and not multi and not corpus and args.host_stream_frames > 0:
+        hf = args.host_stream_frames
+        hs = A.streaming.HostStreamEncoder(enc, N_CH, hf, depth=2, block_switching=block_switched)
+        src_planar = shard[:, 1024:]                      # the workload's own stream, repeated to fill a chunk
+        reps = -(-hf * 1024 // src_planar.shape[1])
+        chunk = np.ascontiguousarray(np.tile(src_planar, (1, reps))[:, :hf * 1024])
+        for k in range(2):
+            hs.input(k)[:] = chunk
+        for i in range(4):                                 # warm-up, and the bodies' lengths get known
+            k = i & 1
+            if i >= 2:
+                hs.result(k)
+            hs.submit(k)
+        hs.result(0), hs.result(1)
+        torch.cuda.synchronize()
+        n_chunks = 10
+        t0 = time.perf_counter()
+        out_bytes = 0
+        for i in range(n_chunks):
+            k = i & 1
+            if i >= 2:
+                out_bytes += len(hs.result(k))
+            hs.submit(k)
+        out_bytes += len(hs.result(0)) + len(hs.result(1))
+        dt_h = time.perf_counter() - t0
+        host_stream = {"cf_per_s": n_chunks * hf * N_CH / dt_h, "chunk_cf": hf * N_CH, "chunks": n_chunks,
+                       "ms_per_chunk": dt_h / n_chunks * 1e3, "pcm_bytes_per_chunk": int(chunk.nbytes),
+                       "body_bytes_per_chunk": out_bytes // n_chunks,
+                       "how": "pinned int16 PCM -> HBM, encode + pack + body, body -> pinned host memory; three streams, "
+                              "two buffers of everything, no host synchronisation inside the loop but taking a finished body"}
+        del hs
+
     if rank == 0:
         total_cf = world * n_cf if not corpus else N_CH * args.corpus_frames
         what = ("scalar mantissas" if not vq_kbps else "gain-shape PVQ" + (" + SBR" if kbps < 128 else ""))
@@ -613,6 +652,9 @@ def main():
                          "bytes_per_cf": MDCT_BYTES_PER_CF, "cf_per_launch": mdct_cf,
                          "mdct_cf_per_s": mdct_cf / (mdct_ms * 1e-3)},
         }
+        if host_stream:
+            res["config"]["host_to_host_cf_per_s"] = host_stream["cf_per_s"]
+            res["config"]["host_to_host"] = host_stream
         sk = step_kernels(args.workload, n_cf)
         if sk:
             res["config"]["step_kernels"] = sk

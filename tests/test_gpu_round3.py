@@ -341,3 +341,62 @@ def test_transient_detector_mirror_matches_oracle(A):
     tie[0, 0] = 4.5
     tie[0, 1:500] = 1.0                      # peak / mean of the first 500 = 4.5 / ((4.5 + 499) / 500)
     assert A.detect_transients.parTransientDetect(tie) == po.transient_detect(tie)
+
+
+# ------------------------------------------------------------ host memory to host memory (VERDICT r2 missing #5)
+@pytest.mark.parametrize("coder", ["scalar", "scalar_bs", "shipped128", "shipped96"])
+def test_host_stream_chunks_equal_one_batch(A, coder):
+    """streaming.HostStreamEncoder: a stream cut into chunks of 7 hops (the one-hop halo and the transient decisions
+    carried from chunk to chunk on the device, the copies of neighbouring chunks overlapping the kernels) gives the
+    bytes of the one-batch path -- and with that the reference's (the excerpt is one of its own test files)"""
+    pcm, sr = _mixed_stream()
+    kw = {"scalar": dict(block_switching=False), "scalar_bs": dict(block_switching=True),
+          "shipped128": dict(block_switching=True, use_vq=True),
+          "shipped96": dict(block_switching=True, use_vq=True, use_sbr=True)}[coder]
+    kbps = 96 if coder == "shipped96" else 128
+    want = A.pacfile.encode_stream(pcm, sr, kbps, **kw)
+    for chunk in (7, 16, 64):
+        assert A.pacfile.encode_stream(pcm, sr, kbps, chunk_hops=chunk, **kw) == want, (coder, chunk)
+
+
+def test_host_stream_zero_copy_api(A):
+    """the caller fills the pinned staging buffers itself; slots in flight are refused until their result is taken"""
+    import torch
+    enc = A.engine.Encoder(48000, 128 / 48.0)
+    pcm = A.synth.stream(24, 2)
+    hs = A.streaming.HostStreamEncoder(enc, 2, 8, depth=2)
+    want = A.pacfile.encode_stream(pcm, 48000, 128)
+    head_len = len(want) - sum(len(b) for b in A.streaming.HostStreamEncoder(enc, 2, 8).encode(pcm))
+    got = []
+    for i in range(3):
+        k = i % 2
+        if i >= 2:
+            got.append(bytes(hs.result(k)))
+        hs.input(k)[:] = pcm[i * 8 * 1024:(i + 1) * 8 * 1024].T
+        hs.submit(k)
+        with pytest.raises(RuntimeError):
+            hs.submit(k)                                  # still in flight
+    got.append(bytes(hs.result(1)))
+    got.append(bytes(hs.result(0)))
+    body = b"".join(got)
+    assert want[head_len:head_len + len(body)] == body     # the three chunks; the file's last two blocks follow
+
+
+def test_bench_line_fields(A):
+    """one small default-form bench run: the line carries roofline, verified_cf, the hipGraph launch mode of the scalar
+    coder's step and the host-to-host figure (never `value`)"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "256", "--steps", "2", "--repeats", "2",
+                        "--warmup", "1", "--host-stream-frames", "1024", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["verified_cf"] == 32 and d["dtype"] == "f64"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["config"]["launch"].startswith("hipGraph")
+    assert d["config"]["host_to_host_cf_per_s"] > 0 and d["config"]["host_to_host"]["chunk_cf"] == 2048
+    assert d["vs_baseline"] is None
