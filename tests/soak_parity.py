@@ -482,8 +482,10 @@ def main():
         v = tally[key]
         say(f"{key[0]:<10} {key[1]:>5} {key[2]:>4}  {v[0]:>7}  {v[1]:>14}  {v[2]:>8}  {v[3]:>8}")
     say(f"noise-decided streams by class (a stream can be in both): {noise}")
+    n_diff = sum(v[3] for v in tally.values())
     say(f"total: {sum(v[0] for v in tally.values())} streams, {sum(v[1] for v in tally.values())} channel-frames, "
-        f"{raised} streams where both encoders raised, {dec_raised} where both decoders raised, {len(bad)} mismatches")
+        f"{raised} streams where both encoders raised, {dec_raised} where both decoders raised; "
+        f"{n_diff + len(bad)} streams differ from the oracle in bytes or decoded PCM: {n_diff} classified (above), {len(bad)} NOT classified")
     for case, why in bad:
         say(f"  {case}: {why}")
     return 1 if bad else 0
