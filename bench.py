@@ -275,9 +275,10 @@ def main():
     ap.add_argument("--mdct-launches", type=int, default=50)
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="the step's kernel launches are captured once into a hipGraph and the timed regions replay "
-                         "it: the launch gaps between the step's kernels go.  Default: on for the scalar coder's "
-                         "workloads (scalar128 +2.6 %%, bs128 +3.4 %%), off for the gain-shape ones, whose two coder "
-                         "launches on two streams do not overlap when replayed (shipped128: 0.82 against 0.69 ms)")
+                         "it: the launch gaps between the step's kernels go.  Default: on only with --pipeline 1 and the "
+                         "scalar coder (scalar128 +2.6 %%, bs128 +3.4 %% there); with two steps in flight direct launches "
+                         "overlap better, and the gain-shape coder's two launches on two streams do not overlap when "
+                         "replayed (shipped128: 0.82 against 0.69 ms)")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="launch the step's kernels one by one")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -296,6 +297,13 @@ def main():
                     help="BASELINE configs[4]: the tiled, level-scaled corpus sharded over the ranks "
                          "(strong scaling); --corpus-frames stereo frames in all")
     ap.add_argument("--corpus-frames", type=int, default=CORPUS_FRAMES)
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="steps in flight: consecutive steps (independent batches) alternate between this many "
+                         "handles, each with its own stream, workspaces, output buffers and hipGraph -- the kernels of "
+                         "step i+1 fill the vector-issue slots those of step i leave idle (every kernel of the step is "
+                         "latency- or issue-bound at 50-60 %% VALU utilisation: DESIGN.md 5.3).  Every step is still one "
+                         "full pass over one batch and all K of them are inside the timed region.  1 = one step at a "
+                         "time (round 2's figure; reported as config.value_one_step_in_flight either way)")
     ap.add_argument("--host-stream-frames", type=int, default=65536,
                     help="stereo frames per chunk of the host-memory-to-host-memory measurement reported as "
                          "config.host_to_host_cf_per_s (pinned PCM in, packed bodies out, copies overlapped with the "
@@ -361,24 +369,23 @@ def main():
         else:
             pcm = A.synth.stream(n_frames, N_CH, seed=A.synth.SEED + rank)
         shard = A.synth.planar_with_halo(pcm)
-    enc = A.engine.Encoder(sample_rate, kbps / (sample_rate / 1000), use_vq=bool(vq_kbps),
-                           use_sbr=bool(vq_kbps and vq_kbps < 128))
+    P = max(1, args.pipeline)
+    if multi:
+        P = 2                                  # the gather's two send buffers
+    encs = [A.engine.Encoder(sample_rate, kbps / (sample_rate / 1000), use_vq=bool(vq_kbps),
+                             use_sbr=bool(vq_kbps and vq_kbps < 128)) for _ in range(P)]
+    enc = encs[0]
     planar = torch.as_tensor(shard, device=dev)
     view = A.engine.PcmView.stream(planar)
+    n_cf = view.n_cf
     hop_view = None
     if block_switched:      # the hops as the transient detector sees them (hop h = planar hop h+1)
         hop_view = A._lib.PacxPcm(planar.data_ptr() + 2 * 1024, A._lib.PCM_I16, N_CH, n_frames, 1024,
                                   planar.shape[1], 1)
-        tr_buf = torch.empty(n_frames, dtype=torch.uint8, device=dev)
-        fl_buf = torch.empty(n_frames + 2, dtype=torch.uint8, device=dev)
-    n_cf = view.n_cf
-    enc.reserve(n_cf)
-    out = enc.alloc_outputs(n_cf, with_payload=True)
-    if corpus:
-        out["mantissa"] = None                 # 1 GB per 131 072 frames nobody reads
-    total = torch.zeros(1, dtype=torch.int64, device=dev)
-    gather = None
+    import ctypes
+    from audio_codec_amd.engine import _ptr
     slot = A.dist.slot_bytes(n_cf, kbps / (sample_rate / 1000))      # bound on one rank's body
+    gather = None
     if multi:
         # fixed-slot asynchronous gather of the packed bodies to rank 0 (RCCL): two send
         # buffers alternate, the gather of step i overlaps the encode of step i+1, no host
@@ -389,66 +396,80 @@ def main():
         if on_host:
             host_bodies, bodies = bodies, [torch.empty_like(b, device=dev) for b in bodies]
     else:
-        bodies = [torch.empty(slot, dtype=torch.uint8, device=dev)]
+        bodies = [torch.empty(slot, dtype=torch.uint8, device=dev) for _ in range(P)]
     cap = int(bodies[0].numel())
+    # one pipeline = one handle with its workspaces, its own output buffers, body, stream (and hipGraph)
+    pipes = []
+    for q in range(P):
+        e = encs[q]
+        e.reserve(n_cf)
+        o = e.alloc_outputs(n_cf, with_payload=True)
+        if corpus:
+            o["mantissa"] = None               # 1 GB per 131 072 frames nobody reads
+        pipes.append({"enc": e, "out": o, "body": bodies[q], "total": torch.zeros(1, dtype=torch.int64, device=dev),
+                      "vq_out": {k: o[k] for k in ("overall", "bit_alloc", "status", "payload", "n_bytes")} if vq_kbps else None,
+                      "tr": torch.empty(n_frames, dtype=torch.uint8, device=dev) if block_switched else None,
+                      "fl": torch.empty(n_frames + 2, dtype=torch.uint8, device=dev) if block_switched else None,
+                      "stream": torch.cuda.Stream(device=dev), "graph": None})
+    out, total = pipes[0]["out"], pipes[0]["total"]
+    fl_buf = pipes[0]["fl"]
     step_no = [0]
-    import ctypes
-    from audio_codec_amd.engine import _ptr
-
-    vq_out = None
-    if vq_kbps:
-        vq_out = {k: out[k] for k in ("overall", "bit_alloc", "status", "payload", "n_bytes")}
     do_gather = [True]
+    in_flight = [P]
 
-    def encode_part(k):
-        """the kernels of one step, body into buffer k: what a hipGraph of the step holds"""
-        if vq_kbps and block_switched:
-            enc._call("pacx_transient_flags", ctypes.byref(hop_view), _ptr(tr_buf), _ptr(fl_buf), enc._stream())
-            enc.encode_vq(view, fl_buf[:n_frames], vq_out)
-        elif vq_kbps:
-            enc.encode_vq(view, None, vq_out)
-        elif block_switched:
-            enc._call("pacx_transient_flags", ctypes.byref(hop_view), _ptr(tr_buf), _ptr(fl_buf), enc._stream())
-            enc.encode_pack(view, fl_buf[:n_frames], out)
+    def encode_part(q):
+        """the kernels of one step on pipeline q: what a hipGraph of the step holds"""
+        pp = pipes[q]
+        e, o = pp["enc"], pp["out"]
+        if block_switched:
+            e._call("pacx_transient_flags", ctypes.byref(hop_view), _ptr(pp["tr"]), _ptr(pp["fl"]), e._stream())
+        flags = pp["fl"][:n_frames] if block_switched else None
+        if vq_kbps:
+            e.encode_vq(view, flags, pp["vq_out"])
         else:
-            enc.encode_pack(view, None, out)
-        enc._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(out["payload"]), _ptr(out["n_bytes"]),
-                  _ptr(bodies[k]), ctypes.c_int64(cap), _ptr(total), enc._stream())
+            e.encode_pack(view, flags, o)
+        e._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(o["payload"]), _ptr(o["n_bytes"]),
+                _ptr(pp["body"]), ctypes.c_int64(cap), _ptr(pp["total"]), e._stream())
 
-    # the kernel launches of a step captured once into a hipGraph (one per body buffer) and replayed:
-    # the default.  The gather of the bodies (RCCL) stays outside the graph.
-    graphs = [None] * len(bodies)
-    if args.graph is None:
-        args.graph = not vq_kbps
+    # the kernel launches of a step captured once into a hipGraph (one per pipeline) and replayed.
+    # The gather of the bodies (RCCL) stays outside the graph.
+    if args.graph is None:                 # measured (profiles/r03_pipeline_sweep.txt): with two steps in flight direct launches
+        args.graph = P == 1 and not vq_kbps   # overlap better than two replayed graphs (45.1 against 42.0 M cf/s); alone, a graph saves the gaps
+    torch.cuda.synchronize()
     if args.graph:
-        for k in range(len(bodies)):
-            encode_part(k)
+        for q in range(P):
+            with torch.cuda.stream(pipes[q]["stream"]):
+                encode_part(q)
         torch.cuda.synchronize()
         try:
-            for k in range(len(bodies)):
+            for q in range(P):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    encode_part(k)
-                graphs[k] = g
+                with torch.cuda.graph(g, stream=pipes[q]["stream"]):
+                    encode_part(q)
+                pipes[q]["graph"] = g
         except Exception as e:                      # capture not possible: plain launches
             print(f"bench: hipGraph capture failed ({e}); launching kernels directly", file=sys.stderr)
-            graphs = [None] * len(bodies)
+            for pp in pipes:
+                pp["graph"] = None
         torch.cuda.synchronize()
+    graphs = [pp["graph"] for pp in pipes]
 
     def step():
-        k = step_no[0] % len(bodies)
-        if gather is not None:
-            gather.wait(k)                      # the gather that last used this buffer (stream-level wait)
-        if graphs[k] is not None:
-            graphs[k].replay()
-        else:
-            encode_part(k)
-        if gather is not None and do_gather[0]:
-            if dist.get_backend() == "gloo":            # rehearsal: stage through the host
-                host_bodies[k].copy_(bodies[k])
-                gather.launch(k, total.cpu())
+        q = step_no[0] % in_flight[0]
+        pp = pipes[q]
+        with torch.cuda.stream(pp["stream"]):
+            if gather is not None:
+                gather.wait(q)                      # the gather that last used this buffer (stream-level wait)
+            if pp["graph"] is not None:
+                pp["graph"].replay()
             else:
-                gather.launch(k, total)
+                encode_part(q)
+            if gather is not None and do_gather[0]:
+                if dist.get_backend() == "gloo":            # rehearsal: stage through the host
+                    host_bodies[q].copy_(pp["body"])
+                    gather.launch(q, pp["total"].cpu())
+                else:
+                    gather.launch(q, pp["total"])
         step_no[0] += 1
 
     def sync_all():
@@ -477,6 +498,12 @@ def main():
         step()
     regions = [timed_region() for _ in range(max(1, args.repeats))]
     dt = float(np.median(regions))
+    regions_one = None
+    if P > 1 and not multi:                # the same K steps with one step in flight at a time (round 2's figure)
+        in_flight[0] = 1
+        step_no[0] = 0
+        regions_one = [timed_region() for _ in range(max(3, args.repeats // 2))]
+        in_flight[0] = P
     regions_nogather = None
     if corpus and multi:                   # with and without the gather
         do_gather[0] = False
@@ -501,6 +528,12 @@ def main():
         stream_h = pcm if pcm is not None else np.ascontiguousarray(shard[:, 1024:].T)
         halo_h = None if pcm is not None else np.ascontiguousarray(shard[:, :1024].T)
         verified = verify_against_oracle(stream_h, sample_rate, kbps, vq_kbps, flags_h, rows, n_bytes_h, picks, halo_h)
+        for pp in pipes[1:]:               # every pipeline encoded the same batch: same records
+            nb_q = pp["out"]["n_bytes"].cpu().numpy()
+            assert np.array_equal(nb_q, n_bytes_h), "pipelines disagree on the record lengths"
+            for i, row in rows.items():
+                assert np.array_equal(pp["out"]["payload"][i].cpu().numpy()[:int(nb_q[i])], row[:int(nb_q[i])]), \
+                    f"cf {i}: the pipelines' payloads differ"
     verified_per_rank = [verified]
     if multi:                              # rank 0 reports every rank's count; a rank whose check fails has raised
         cnt = torch.tensor([verified], dtype=torch.int64,
@@ -636,7 +669,10 @@ def main():
                                    "payload bytes equal" + (f" (per rank: {verified_per_rank})" if multi else "")
                                    if verified else "not verified",
                        "verified_per_rank": verified_per_rank,
-                       "launch": "hipGraph replay of the captured step" if graphs[0] is not None else "direct launches",
+                       "launch": ("hipGraph replay of the captured step" if graphs[0] is not None else "direct launches") +
+                                 (f"; {P} steps in flight: consecutive steps alternate between {P} handles, each with its own "
+                                  "stream, workspaces and output buffers" if P > 1 else "; one step in flight"),
+                       "steps_in_flight": P,
                        "sharding": f"{world} x frame-range shards, no data-path collective; process group: "
                                    + (f"{dist.get_backend()} with {dist.get_world_size()} ranks" if multi
                                       else "none (one process)")},
@@ -652,6 +688,10 @@ def main():
                          "bytes_per_cf": MDCT_BYTES_PER_CF, "cf_per_launch": mdct_cf,
                          "mdct_cf_per_s": mdct_cf / (mdct_ms * 1e-3)},
         }
+        if regions_one is not None:
+            d1 = float(np.median(regions_one))
+            res["config"]["value_one_step_in_flight"] = total_cf * args.steps / d1
+            res["config"]["ms_per_step_one_step_in_flight"] = d1 / args.steps * 1e3
         if host_stream:
             res["config"]["host_to_host_cf_per_s"] = host_stream["cf_per_s"]
             res["config"]["host_to_host"] = host_stream

@@ -383,8 +383,8 @@ def test_host_stream_zero_copy_api(A):
 
 
 def test_bench_line_fields(A):
-    """one small default-form bench run: the line carries roofline, verified_cf, the hipGraph launch mode of the scalar
-    coder's step and the host-to-host figure (never `value`)"""
+    """one small default-form bench run: the line carries roofline, verified_cf, the two steps in flight of the default
+    timed path with the one-step-in-flight figure beside it, and the host-to-host figure (never `value`)"""
     import json
     import subprocess
     import sys
@@ -397,6 +397,7 @@ def test_bench_line_fields(A):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["verified_cf"] == 32 and d["dtype"] == "f64"
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
-    assert d["config"]["launch"].startswith("hipGraph")
+    assert d["config"]["steps_in_flight"] == 2 and "2 steps in flight" in d["config"]["launch"]
+    assert 0 < d["config"]["value_one_step_in_flight"]
     assert d["config"]["host_to_host_cf_per_s"] > 0 and d["config"]["host_to_host"]["chunk_cf"] == 2048
     assert d["vs_baseline"] is None
