@@ -235,9 +235,8 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, hea
         from .streaming import HostStreamEncoder
         hs = HostStreamEncoder(enc, pcm.shape[1], int(chunk_hops), block_switching=block_switching)
         parts = [bytes(b) for b in hs.encode(pcm)]
-        if not use_vq:
-            for out in hs.outs:
-                _raise_like_reference(out)
+        if hs.reference_raises():
+            raise TypeError(_lib.REF_SCALAR_SBR_ERROR)
         return head + b"".join(parts)
     planar = device_stream(enc, pcm, hop)
     view = PcmView.stream(planar, hop)

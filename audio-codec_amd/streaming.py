@@ -62,6 +62,7 @@ class HostStreamEncoder:
         self.pending = [False] * depth
         self.n_hops_of = [0] * depth
         self.next_slot = 0
+        self.raises = torch.zeros(1, dtype=torch.int32, device=dev)              # PACX_ST_REF_RAISES seen in any chunk
 
     def _alloc_out(self):
         if self.enc.use_vq:
@@ -123,6 +124,8 @@ class HostStreamEncoder:
                 enc.encode_vq(view, flags, sub)
             else:
                 enc.encode_pack(view, flags, sub)
+                if enc.use_sbr:                                      # scalar mantissas in an SBR file: where the reference raises
+                    self.raises |= (sub["status"] & _lib.ST_REF_RAISES).max()
             enc._call("pacx_gather_body", ctypes.c_int64(n_cf), _ptr(sub["payload"]), _ptr(sub["n_bytes"]),
                       _ptr(self.bodies[k]), ctypes.c_int64(self.cap), _ptr(self.totals[k]), enc._stream())
             self.ev_k[k].record(self.s_k)
@@ -183,9 +186,15 @@ class HostStreamEncoder:
         for k in order:
             yield self.result(k)
 
+    def reference_raises(self):
+        """True if a block of the stream so far is one the reference cannot write (PACX_ST_REF_RAISES: scalar
+        mantissas in an SBR file, an omitted band got bits -- coder/quantize.py:73-74 raises TypeError there)"""
+        return bool(int(self.raises.item()))
+
     def reset(self):
         """start a new stream (halo and transient carry back to the start of a file)"""
         torch.cuda.synchronize(self.enc.device)
         self.halo.zero_()
         self.carry.zero_()
+        self.raises.zero_()
         self.pending = [False] * self.depth
