@@ -253,7 +253,11 @@ extern "C" int pacx_debug_read(long long *out, int n)
    checks the compiled code against it. */
 constexpr int EPI_STORES = 8;
 
-template <int WAVES, int MINW>
+/* STEP: the instantiation the whole-path entry points launch (it also initialises the frames' status words and
+   sub-block scales); the stand-alone pacx_mdct_batch launches STEP = false.  Two symbols, so that a kernel trace
+   tells the stand-alone launches -- the ones the HBM roofline figure is quoted on -- from the in-step ones, which
+   run beside the side chain and, with two steps in flight, beside another step's kernels, and are stretched by it */
+template <int WAVES, int MINW, bool STEP>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T, PacxPcmView in, long long n_cf,
                                                                    double *__restrict__ lines,
                                                                    int32_t *__restrict__ scale_out,
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
             /* PACX_ST_GUARD: the lanes that decide the minimum hold a maximum within a factor
                two of the block's; theirs sitting at a boundary of ScaleFactor flags the frame
                (line error bound relative to the block maximum, pacx_exact.h) */
-            guard = T.guard && status_init && s == lo && pacx_scale_guard(mx, T.n_scale_bits, 5, 2.0 * PACX_GUARD_LINE_ERR * mx);
+            guard = STEP && T.guard && status_init && s == lo && pacx_scale_guard(mx, T.n_scale_bits, 5, 2.0 * PACX_GUARD_LINE_ERR * mx);
         }
         double2 *__restrict__ out = (double2 *)(lines + (long long)cf * PACX_M_LONG);
         static_assert(EPI_STORES * 64 * 2 == PACX_M_LONG, "one epilogue = EPI_STORES 16-byte stores per lane");
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mdct_long_x2p(PacxTables T
            initialisation goes first so that it is older than the DMA. */
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         DBG_T(1);
-        if (status_init) {
+        if (STEP && status_init) {
             if (lane == 0) {
                 status_init[cfa] = 0u;
                 if (has_b)
@@ -509,8 +513,12 @@ void pacx_launch_mdct_x2(const PacxTables &T, const PacxPcmView &in, long long n
         long long blocks = (n_cf + 2 * 8 - 1) / (2 * 8);
         if (blocks > n_cu)
             blocks = n_cu;
-        hipLaunchKernelGGL((k_mdct_long_x2p<8, 2>), dim3((unsigned)blocks), dim3(64 * 8), 0, st, T, in, n_cf, lines,
-                           scale_out, scale_stride, status_init);
+        if (status_init)
+            hipLaunchKernelGGL((k_mdct_long_x2p<8, 2, true>), dim3((unsigned)blocks), dim3(64 * 8), 0, st, T, in, n_cf, lines,
+                               scale_out, scale_stride, status_init);
+        else
+            hipLaunchKernelGGL((k_mdct_long_x2p<8, 2, false>), dim3((unsigned)blocks), dim3(64 * 8), 0, st, T, in, n_cf, lines,
+                               scale_out, scale_stride, status_init);
         return;
     }
     if (n_cf <= 0)

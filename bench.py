@@ -689,7 +689,7 @@ def main():
                        "sharding": f"{world} x frame-range shards, no data-path collective; process group: "
                                    + (f"{dist.get_backend()} with {dist.get_world_size()} ranks" if multi
                                       else "none (one process)")},
-            "roofline": {"kernel": "k_mdct_long_x2p (window + MDCT, int16 in, float64 lines out; two frames per wave alternating on one FFT tile, PCM prefetched a whole iteration ahead)",
+            "roofline": {"kernel": "k_mdct_long_x2p<8, 2, false> (the stand-alone launches of the kernel; the step launches the <8, 2, true> instantiation, which also initialises status words: window + MDCT, int16 in, float64 lines out; two frames per wave alternating on one FFT tile, PCM prefetched a whole iteration ahead)",
                          "bound": "hbm", "achieved": mdct_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": mdct_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": ("HBM bytes per launch from the COMMITTED rocprofv3 PMC passes of this "

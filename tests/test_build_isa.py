@@ -101,12 +101,13 @@ def kernel(fns, pattern):
     return hits[0], fns[hits[0]]
 
 
-def test_x2p_dma_and_counted_wait(B):
+@pytest.mark.parametrize("step", ["Lb0E", "Lb1E"])      # the stand-alone instantiation and the in-step one
+def test_x2p_dma_and_counted_wait(B, step):
     src = open(B.CSRC + "/k_mdct3.hip").read()
     m = re.search(r"constexpr int EPI_STORES = (\d+);", src)
     assert m, "k_mdct3.hip must define EPI_STORES (line stores per epilogue)"
     epi = int(m.group(1))
-    name, ins = kernel(functions(B.device_asm("k_mdct3.hip")), r"k_mdct_long_x2pILi8ELi2E")
+    name, ins = kernel(functions(B.device_asm("k_mdct3.hip")), r"k_mdct_long_x2pILi8ELi2E%sE" % step)
     groups = check_h1(ins, name)                                        # H1
     assert all(b - a == 3 or sum(map(is_dma, ins[a:b + 1])) == 4 for a, b in groups), "4 DMA instructions per 4 KB frame"
     # the counted wait, once, inside the loop

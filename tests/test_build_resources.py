@@ -26,7 +26,8 @@ def _find(res, pattern):
 
 # (regex on the demangled name, max VGPRs or None, min waves/SIMD or None)
 HOT = [
-    (r"^void k_mdct_long_x2p<8, 2>\(", 256, 2),          # headline MDCT kernel
+    (r"^void k_mdct_long_x2p<8, 2, false>\(", 256, 2),   # headline MDCT kernel, stand-alone launches (the roofline figure)
+    (r"^void k_mdct_long_x2p<8, 2, true>\(", 256, 2),    # ... and as the step launches it
     (r"^void k_mdct_long_v2<true>\(", 256, 2),           # batches with block-switching flags
     (r"^void k_mdct_long_v2<false>\(", 256, 2),
     (r"^void k_mdct_short<0, true>\(", 128, 3),

@@ -4,7 +4,7 @@ import collections, csv, glob, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("gpurun_out/pmcs/*/out_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"].split("(")[0][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     if not any(t in k for t in ("k_mask", "k_side", "k_mdct", "k_tail", "k_vq")):
         continue
