@@ -268,7 +268,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--repeats", type=int, default=10, help="timed K-step regions; value = median")
+    ap.add_argument("--repeats", type=int, default=10, help="timed K-step regions (at least); value = median")
+    ap.add_argument("--min-seconds", type=float, default=1.5,
+                    help="keep timing K-step regions until this much wall time has gone into them (and --repeats regions "
+                         "are done): the median then describes the card under sustained load, clocks settled")
     ap.add_argument("--frames", type=int, default=None, help="stereo frames per GPU and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -496,7 +499,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    regions = [timed_region() for _ in range(max(1, args.repeats))]
+    regions, t_begin = [], time.perf_counter()
+    while len(regions) < max(1, args.repeats) or (time.perf_counter() - t_begin < args.min_seconds and len(regions) < 20000):
+        regions.append(timed_region())
+        if multi and len(regions) >= max(1, args.repeats):      # ranks must agree on when to stop
+            flag = torch.tensor([1.0 if time.perf_counter() - t_begin < args.min_seconds else 0.0], dtype=torch.float64,
+                                device=torch.device("cpu") if dist.get_backend() == "gloo" else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) == 0.0:
+                break
     dt = float(np.median(regions))
     regions_one = None
     if P > 1 and not multi:                # the same K steps with one step in flight at a time (round 2's figure)
@@ -676,7 +687,10 @@ def main():
                        "timing": f"median of {len(regions)} regions of {args.steps} steps",
                        "value_min": total_cf * args.steps / max(regions),
                        "value_max": total_cf * args.steps / min(regions),
-                       "ms_per_step_regions": [r / args.steps * 1e3 for r in regions],
+                       "regions": len(regions),
+                       "ms_per_step_regions": [r / args.steps * 1e3 for r in (regions if len(regions) <= 24 else
+                                                                                regions[:8] + regions[-16:])],
+                       "ms_per_step_regions_note": "all regions" if len(regions) <= 24 else "the first 8 and the last 16 regions",
                        "body_bytes_per_step": body_bytes,
                        "verified": f"{verified} channel-frames of the timed run's output re-encoded by the oracle, "
                                    "payload bytes equal" + (f" (per rank: {verified_per_rank})" if multi else "")

@@ -112,7 +112,7 @@ def test_bench_multi_gpu_flow_over_rccl_single_rank():
     env.pop("WORLD_SIZE", None)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-           "--repeats", "2", "--frames", "512", "--no-cpu-baseline"]
+           "--repeats", "2", "--min-seconds", "0", "--frames", "512", "--no-cpu-baseline"]
     d = _bench_line(_run(cmd, env, 400, cwd=ROOT))
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["verified_cf"] > 0
     assert "RCCL gather" in d["config"]["workload"]
@@ -130,7 +130,7 @@ def test_bench_plain_command_starts_two_ranks():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PACX_BENCH_FORCE_DIST"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--repeats", "2", "--frames", "256", "--no-cpu-baseline"]
+           "--repeats", "2", "--min-seconds", "0", "--frames", "256", "--no-cpu-baseline"]
     d = _bench_line(_run(cmd, env, 400, cwd=ROOT))
     assert d["n_gpus"] == 2 and d["value"] > 0
     assert len(d["config"]["verified_per_rank"]) == 2 and min(d["config"]["verified_per_rank"]) > 0

@@ -389,7 +389,7 @@ def test_bench_line_fields(A):
     import subprocess
     import sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "256", "--steps", "2", "--repeats", "2",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "256", "--steps", "2", "--repeats", "2", "--min-seconds", "0.2",
                         "--warmup", "1", "--host-stream-frames", "1024", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
