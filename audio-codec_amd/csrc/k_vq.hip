@@ -411,9 +411,15 @@ __device__ __forceinline__ void vq_leaf(const VqView &V, VqOut &o, const double 
  * xor butterfly over W lanes with zeros in the unused ones adds in the order of
  * the 64-lane one).  Returns the enumeration index in every lane of the group;
  * ok = false for an all-zero vector (NaN pulses in the reference). */
+/* PACX_ST_GUARD for a leaf (handles with pacx_config.guard): the pulse search has two kinds of decisions that the last
+   bits of the unit vector can turn -- floor(K |x_i| / l1) where the quotient sits at an integer, and which components get
+   the `missing` pulses where the last remainder to get one and the first to go without are (nearly) equal.  The unit
+   vectors agree with the reference's to a few ulps (another summation order in the norms), so the quotients to
+   ~K * 4e-15 absolute: within that margin the leaf is flagged. */
+#define VQ_GUARD_REL 4e-15
 template <int W, bool ROWS64 = false>
 __device__ __forceinline__ unsigned long long vq_leaf_group(const VqView &V, double x, int n, int K, int l,
-                                                            bool &ok)
+                                                            bool &ok, bool want_guard = false, bool *near = nullptr)
 {
     /* L1 norm in np.sum order (n <= 32: sequential below 8, else eight interleaved
        accumulators, fixed tree, scalar tail) */
@@ -456,6 +462,22 @@ __device__ __forceinline__ unsigned long long vq_leaf_group(const VqView &V, dou
         }
         if (l < n && rank < missing)
             y += 1.0;
+        if (want_guard) {
+            const double thr = (kd < 1.0 ? 1.0 : kd) * VQ_GUARD_REL;
+            const double fr = tgt - floor(tgt);
+            bool nr = l < n && ok && (fr < thr || fr > 1.0 - thr);
+            double ra = (l < n && rank == missing - 1) ? r : -1.0;     /* the last remainder to get a pulse ... */
+            double rb = (l < n && rank == missing) ? r : -1.0;         /* ... and the first to go without */
+#pragma unroll
+            for (int off = W / 2; off > 0; off >>= 1) {
+                ra = fmax(ra, __shfl_xor(ra, off, W));
+                rb = fmax(rb, __shfl_xor(rb, off, W));
+            }
+            nr = nr || (missing > 0 && ra >= 0.0 && rb >= 0.0 && ra - rb < 2.0 * thr);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(nr);
+            const int g0 = (threadIdx.x & 63) & ~(W - 1);
+            *near = ((m >> g0) & ((W == 64) ? ~0ull : ((1ull << W) - 1ull))) != 0ull;
+        }
     }
 #else
     if (l < missing)
@@ -1462,6 +1484,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQ_OCC) void k_vq_redo(PacxTables T,
             __syncthreads();                               /* the previous unit's LDS is done with */
             vq_unit_body(T, V, A, A.mixed ? cf * PACX_SUB + sb : cf);
         }
+        if (T.guard && A.status && threadIdx.x == 0)
+            atomicOr(&A.status[cf], PACX_ST_GUARD);        /* the band-by-band coder takes no margins: flagged as it comes */
     }
 }
 
@@ -1584,6 +1608,10 @@ __shared__ double vqf_log2_tan[VQF_LT + 1];
 #ifndef VQF_OCC
 #define VQF_OCC 5
 #endif
+/* GUARD: the instantiation handles with pacx_config.guard launch -- it also takes the margins of PACX_ST_GUARD (split angles,
+   band gains, pulse-search floors and ties, rounding-noise lines); the other one is the kernel as it was (the margins cost
+   2.5 % even when switched off at run time: registers and code size) */
+template <bool GUARD>
 __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables T, VqView V, VqArgs A)
 {
 #ifdef PACX_VQ_DEBUG
@@ -1668,8 +1696,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
         vqf_half_log2[tid] = V.half_log2[tid];
     if (tid < VQF_LT)
         vqf_log2_tan[tid] = V.log2_tan[tid];
-    if (tid < 3)
-        misc[tid] = 0;
+    if (tid < 8)
+        misc[tid] = 0;                                       /* [7]: guard bits raised while the lines were placed */
     VQF_T(15);
     /* phase A: gains; the unit shapes x / gain are level 0 of the walk (bufs[0], at the band's lines) */
     double *xs = buf0;
@@ -1701,6 +1729,15 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 acc = fma(x, x, acc);
             }
             g = sqrt(wave_sum_f64(acc));
+            if (GUARD) {
+                /* a line at rounding-noise level (exactly zero in exact arithmetic: 0.0 here, 1e-21 from the reference's
+                   FFT) keeps or loses its pulse by the sign of that noise (np.sign(0) = 0 erases it) */
+                bool tiny = false;
+                for (int i = lane; i < cnt; i += 64)
+                    tiny = tiny || (g > 0.0 && fabs(xs[lo + i]) < 1e-12 * g);
+                if (__builtin_amdgcn_ballot_w64(tiny) && lane == 0)
+                    atomicOr((unsigned *)&misc[7], 1u);
+            }
             for (int i = lane; i < cnt; i += 64)
                 xs[lo + i] = xs[lo + i] / g;
         }
@@ -1851,6 +1888,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
             misc[1] = 1;
     };
     VQW_P(2);
+    bool guarded = false;                                  /* PACX_ST_GUARD: a decision within rounding distance of its boundary */
     VQF_T(0);
 #ifdef PACX_VQ_WAITDBG
     long long vqw_busy1 = 0, vqw_wait1 = 0, vqw_busy2 = 0, vqw_wait2 = 0, vqw_t, vqw_t0, vqw_levels = 0;
@@ -1886,19 +1924,31 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 /* pulse count and index width: looked up here, beside the scalar stage, not in it */
                 int bits = valid ? N.bb[node] : 0;
                 bits = bits > 32 ? 32 : bits;
+#ifdef VQF_STUB_KOF        /* timing experiment only (wrong pulse counts): what the dependent table read in front of a leaf pass costs */
+                const int K = valid ? (bits * 3) / (n > 8 ? 2 : 1) + 1 : 0;
+                const int width = valid ? bits : 0;
+#else
                 const int K = valid ? V.k_of[n * 33 + bits] : 0;
                 const int width = valid ? V.w_of[n * 33 + bits] : 0;
+#endif
                 const double x = (valid && l < n) ? cur[N.off[node] + l] : 0.0;
-                bool ok = false;
+                bool ok = false, near = false;
                 unsigned long long term;
 #ifdef VQF_STUB_LEAF       /* timing experiment only (wrong indices): what the small leaves cost */
                 ok = true;
                 term = (unsigned long long)(x != 0.0) + (unsigned long long)K;
 #else
-                if (c == 0)
+                if (GUARD) {                       /* the margins are taken by a copy of the leaf code of its own */
+                    if (c == 0)
+                        term = vq_leaf_group<16, true>(V, x, n, K < 0 ? 0 : K, l, ok, true, &near);
+                    else
+                        term = vq_leaf_group<32, true>(V, x, n, K < 0 ? 0 : K, l, ok, true, &near);
+                    guarded = guarded || (valid && near);
+                } else if (c == 0) {
                     term = vq_leaf_group<16, true>(V, x, n, K < 0 ? 0 : K, l, ok);
-                else
+                } else {
                     term = vq_leaf_group<32, true>(V, x, n, K < 0 ? 0 : K, l, ok);
+                }
 #endif
                 if (valid && l == 0) {
                     if (K < 0) {                   /* a 1-dimensional leaf: the reference never returns */
@@ -1924,6 +1974,7 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 const unsigned long long idx = vq_leaf_idx<true>(V, cur + N.off[node], n, K, t1, t1 + n, lane, ok);
                 if (!ok)
                     undefined = true;
+                guarded = guarded || GUARD;         /* whole-wave leaves: no margin is taken, flagged as they come */
                 if (lane == 0) {
                     N.val[node] = ok ? idx : 0ull;
                     N.wid[node] = (unsigned char)width;
@@ -2093,6 +2144,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                     dq = -dq;
                 theta_q = dq * half_pi;
             }
+            if (GUARD && has && a_theta > 0 && a_theta <= 53 && pacx_quant_guard(tn, a_theta, 1e-13))
+                guarded = true;                              /* the split angle sits at a boundary of its quantiser */
             VQF_SUB(27);
             int a_mid = 0;
             if (theta_q != 0.0) {
@@ -2318,6 +2371,8 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
                 width = 0;
             } else if (bits_gain > 0) {
                 vq_quantize_code(g, bits_gain, hi, lo);
+                if (GUARD && bits_gain <= 53 && pacx_quant_guard(g, bits_gain, 1e-13))
+                    guarded = true;                          /* the band's mu-law gain sits at a boundary of its index */
             }
             const int at = start_s[vb] + used;
             if (width > 64) {
@@ -2341,6 +2396,11 @@ __global__ __launch_bounds__(64 * VQ_WAVES, VQF_OCC) void k_vq_frame(PacxTables 
     }
     if (__builtin_amdgcn_ballot_w64(undefined) && lane == 0 && A.status)
         atomicOr(&A.status[cf], PACX_ST_VQ_UNDEFINED);
+    if (GUARD && A.status) {
+        const unsigned long long gm = __builtin_amdgcn_ballot_w64(guarded || (tid == 0 && misc[7] != 0));
+        if (gm && lane == 0)
+            atomicOr(&A.status[cf], PACX_ST_GUARD);
+    }
     __syncthreads();
     VQW_P(4);
 
@@ -3459,8 +3519,10 @@ void pacx_launch_vq(const PacxTables &T, const void *vq_view, const uint8_t *fla
     if (A.redo && stage != 2) {                 /* one workgroup per channel-frame, long or short */
         if (form2)
             hipLaunchKernelGGL(k_vq_frame2, dim3((unsigned)n_cf), dim3(64 * VQ_WAVES), (size_t)VQ2_SMEM, st, T, V, A);
+        else if (T.guard)
+            hipLaunchKernelGGL(k_vq_frame<true>, dim3((unsigned)n_cf), dim3(64 * VQ_WAVES), (size_t)VQF_SMEM, st, T, V, A);
         else
-            hipLaunchKernelGGL(k_vq_frame, dim3((unsigned)n_cf), dim3(64 * VQ_WAVES), (size_t)VQF_SMEM, st, T, V, A);
+            hipLaunchKernelGGL(k_vq_frame<false>, dim3((unsigned)n_cf), dim3(64 * VQ_WAVES), (size_t)VQF_SMEM, st, T, V, A);
     }
     if (stage == 1)
         return;

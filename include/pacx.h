@@ -94,7 +94,13 @@ extern "C" {
                                      quantiser input (2^R-1)|x|+1 next to an even
                                      integer (coder/quantize.py:73), or a BitAlloc
                                      value Ropt - level next to k + 1/2
-                                     (coder/bitalloc.py:103).  The codes are still the
+                                     (coder/bitalloc.py:103); with use_vq also a split
+                                     angle or a band's mu-law gain at a boundary of its
+                                     quantiser, a pulse search whose floor(K|x|/l1) or
+                                     whose last pulse hangs on the last bits of the unit
+                                     vector (coder/gain_shape_quantize.py:30-54, 315-408),
+                                     and a coded band with a line at rounding-noise level
+                                     (np.sign(0) erases a pulse).  The codes are still the
                                      ones this arithmetic gives; a harness that needs
                                      certainty recomputes flagged frames on the CPU  */
 #define PACX_ST_MALFORMED    32u   /* decode: the payload of this channel-block is
@@ -181,7 +187,7 @@ typedef struct pacx_config {
     const double *kbd_long;         /* [2*n_lines_long]                              */
     const double *kbd_short;        /* [2*n_lines_short]                             */
     /* 1: compute PACX_ST_GUARD (rounding decisions near their boundaries) in the whole-path
-       entry points; costs about 3 % of the scalar encode throughput, off by default */
+       entry points, the gain-shape one included; costs about 3 % of the encode throughput, off by default */
     int32_t guard;
 } pacx_config;
 

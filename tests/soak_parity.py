@@ -155,14 +155,20 @@ def degenerate(po, samples, windowed_lines=None):
 
 
 def classify_vq_mismatch(A, case, pcm, got, want):
-    """gain-shape streams: every differing block must hold a degenerate (sub-)block (see degenerate()), else 'REAL'"""
+    """gain-shape streams: every differing block must carry the product's PACX_ST_GUARD flag (round 3: the gain-shape
+    coder raises it for split angles, band gains, pulse-search floors and ties, and lines at rounding-noise level) or
+    hold a degenerate (sub-)block (see degenerate()) / an exactly-zero line, else 'REAL'"""
     from oracle import pac_oracle as po
     p = po.make_params(case["sr"], case["n_ch"], case["kbps"])
     hdr = len(po.pac_header(p, len(pcm)))
     bg, bw = _blocks(got, hdr), _blocks(want, hdr)
     if got[:hdr] != want[:hdr] or len(bg) != len(bw):
         return ["REAL: header or block count"]
-    enc = A.context.encoder(case["sr"], case["kbps"] / (case["sr"] / 1000), use_vq=True, use_sbr=case["kbps"] < 128)
+    key = (case["sr"], case["kbps"], "vq")
+    if key not in _GUARD_ENCODERS:                   # a handle that raises PACX_ST_GUARD (same bytes, a few per cent slower)
+        _GUARD_ENCODERS[key] = A.engine.Encoder(case["sr"], case["kbps"] / (case["sr"] / 1000), use_vq=True,
+                                                use_sbr=case["kbps"] < 128, guard=True)
+    enc = _GUARD_ENCODERS[key]
     planar = A.pacfile.device_stream(enc, pcm)
     flags = enc.transient_flags(planar, len(pcm) // 1024, 1024)[1]
     status = enc.encode_vq(A.engine.PcmView.stream(planar, 1024), flags)["status"].cpu().numpy()
@@ -181,6 +187,10 @@ def classify_vq_mismatch(A, case, pcm, got, want):
         blk = host[ch, f * 1024:(f + 2) * 1024]
         if (x[0] >> 5) != (y[0] >> 5):
             classes.append(f"REAL: block {i} flags")
+        elif int(status[f * n_ch + ch]) & A._lib.ST_GUARD:
+            # the product's own flag: a BitAlloc value, a split angle, a band gain, a pulse-search floor or tie, or a
+            # line at rounding-noise level sits within rounding distance of its decision boundary in this channel-frame
+            classes.append(f"guard: block {i} (frame {f} of {n_frames}, channel {ch})")
         elif (int(fl[f]) >> 1) & 1:
             deg = any(degenerate(po, blk[448 + 128 * s_:448 + 128 * s_ + 256]) for s_ in range(8))
             classes.append(("degenerate" if deg else "REAL") + f": block {i} (frame {f} of {n_frames}, channel {ch}, short)")

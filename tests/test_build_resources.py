@@ -39,7 +39,7 @@ HOT = [
     (r"^k_tail_long\(", 128, 4),
     (r"^k_tail_short\(", 72, 7),
     (r"^k_gather_small\(", None, None),
-    (r"^k_vq_frame\(", 102, 5),                          # gain-shape coder: five workgroups per CU is what it runs on
+    (r"^void k_vq_frame<(false|true)>\(", 102, 5),                          # gain-shape coder: five workgroups per CU is what it runs on
     (r"^k_vq\(", 128, 4),                                # ... its fallback for trees beyond the node store
     (r"^k_vq_join\(", None, None),
     (r"^k_vq_dec_frame\(", 102, 5),                      # gain-shape decoder: five workgroups per CU
@@ -94,5 +94,5 @@ def test_vq_frame_lds_allows_five_workgroups(res):
     fixed = int(macro("VQF_FIXED"))
     buf = eval(macro("VQF_BUF").replace("PACX_M_LONG", "1024"))
     smem = fixed + 2 * buf * 8 + ncap * 8 + 6 * ncap * 2 + 4 * ncap + 2 * nlv * 2 + 128 + 64
-    static_lds = max(v["lds"] for k, v in res.items() if k.startswith("k_vq_frame("))   # its static arrays
+    static_lds = max(v["lds"] for k, v in res.items() if k.startswith("void k_vq_frame<false>("))   # its static arrays
     assert 5 * (smem + static_lds) <= 160 * 1024 - 5 * 512, (smem, static_lds)
