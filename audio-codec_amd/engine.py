@@ -479,3 +479,62 @@ class Encoder:
         self._call("pacx_bitalloc_generic", ctypes.c_int64(n), int(nb), _ptr(nl), _ptr(budget.contiguous()),
                    int(max_mant_bits), _ptr(smr), _ptr(bits), self._stream())
         return bits
+
+
+class EncoderPool:
+    """Several steps in flight: N handles (each with its own workspaces) on N HIP streams, for callers with many
+    INDEPENDENT batches.  A handle serialises its calls -- its workspaces are shared between them -- and every kernel of
+    the path leaves a third to a half of the vector issue slots idle, bound by latency chains at the occupancy its
+    registers and LDS allow; kernels of another batch fill those slots (two batches side by side: +15-28 % on one
+    MI355X; more than two add nothing).  What `bench.py` times by default.
+
+        pool = EncoderPool(2, 48000, 128 / 48.0)
+        for i, batch in enumerate(batches):
+            k = pool.next()                       # round robin; waits (on the device) for what last ran in slot k
+            with pool.slot(k) as enc:             # enc: that slot's Encoder; the body is queued on the slot's stream
+                enc.encode_pack(batch.view, None, outs[k])
+        pool.synchronize()
+
+    The caller keeps one set of output buffers per slot and must not read slot k's outputs before pool.wait(k) (or
+    synchronize()).  The reference runs its own workers side by side too (Pool(8), coder/pacfile.py:771-781)."""
+
+    def __init__(self, n, *args, **kwargs):
+        self.encs = [Encoder(*args, **kwargs) for _ in range(max(1, int(n)))]
+        dev = self.encs[0].device
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.encs]
+        self.done = [torch.cuda.Event() for _ in self.encs]
+        self._turn = 0
+
+    def __len__(self):
+        return len(self.encs)
+
+    def next(self):
+        k = self._turn
+        self._turn = (k + 1) % len(self.encs)
+        return k
+
+    def slot(self, k):
+        pool = self
+
+        class _Slot:
+            def __enter__(self_inner):
+                self_inner.ctx = torch.cuda.stream(pool.streams[k])
+                self_inner.ctx.__enter__()
+                return pool.encs[k]
+
+            def __exit__(self_inner, *exc):
+                pool.done[k].record(pool.streams[k])
+                return self_inner.ctx.__exit__(*exc)
+        return _Slot()
+
+    def wait(self, k, stream=None):
+        """make `stream` (default: the current one) wait for what was last queued in slot k"""
+        (stream or torch.cuda.current_stream(self.encs[0].device)).wait_event(self.done[k])
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def close(self):
+        for e in self.encs:
+            e.close()

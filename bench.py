@@ -375,8 +375,10 @@ def main():
     P = max(1, args.pipeline)
     if multi:
         P = 2                                  # the gather's two send buffers
-    encs = [A.engine.Encoder(sample_rate, kbps / (sample_rate / 1000), use_vq=bool(vq_kbps),
-                             use_sbr=bool(vq_kbps and vq_kbps < 128)) for _ in range(P)]
+    # the product's pool of handles and streams (engine.EncoderPool): consecutive steps alternate between its slots
+    pool = A.engine.EncoderPool(P, sample_rate, kbps / (sample_rate / 1000), use_vq=bool(vq_kbps),
+                                use_sbr=bool(vq_kbps and vq_kbps < 128))
+    encs = pool.encs
     enc = encs[0]
     planar = torch.as_tensor(shard, device=dev)
     view = A.engine.PcmView.stream(planar)
@@ -413,7 +415,7 @@ def main():
                       "vq_out": {k: o[k] for k in ("overall", "bit_alloc", "status", "payload", "n_bytes")} if vq_kbps else None,
                       "tr": torch.empty(n_frames, dtype=torch.uint8, device=dev) if block_switched else None,
                       "fl": torch.empty(n_frames + 2, dtype=torch.uint8, device=dev) if block_switched else None,
-                      "stream": torch.cuda.Stream(device=dev), "graph": None})
+                      "stream": pool.streams[q], "graph": None})
     out, total = pipes[0]["out"], pipes[0]["total"]
     fl_buf = pipes[0]["fl"]
     step_no = [0]

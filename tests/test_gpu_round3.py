@@ -433,3 +433,37 @@ def test_gain_shape_guard_flag(A, kbps):
     planar = A.pacfile.device_stream(enc, sq)
     st = enc.encode_vq(A.engine.PcmView.stream(planar, 1024), None)["status"].cpu().numpy()
     assert (st[2:-4] & A._lib.ST_GUARD).all(), st
+
+
+def test_encoder_pool_two_batches_in_flight(A):
+    """engine.EncoderPool: independent batches alternating between two handles on two streams give the bytes of one
+    handle doing them one after the other"""
+    import torch
+    pool = A.engine.EncoderPool(2, 48000, 128 / 48.0)
+    one = A.engine.Encoder(48000, 128 / 48.0)
+    views, outs, want = [], [], []
+    for i in range(4):
+        pcm = A.synth.stream(32, 2, seed=900 + i)
+        planar = torch.as_tensor(A.synth.planar_with_halo(pcm), device=one.device)
+        v = A.engine.PcmView.stream(planar)
+        views.append(v)
+        o = one.encode_pack(v)
+        want.append((o["n_bytes"].cpu().numpy().copy(), o["payload"].cpu().numpy().copy()))
+    torch.cuda.synchronize()
+    outs = [pool.encs[k].alloc_outputs(views[0].n_cf, with_payload=True) for k in range(2)]
+    got = []
+    for i, v in enumerate(views):
+        k = pool.next()
+        if i >= 2:                                     # slot k's buffers are about to be reused: take its result first
+            pool.wait(k)
+            torch.cuda.current_stream().synchronize()
+            got.append((outs[k]["n_bytes"].cpu().numpy().copy(), outs[k]["payload"].cpu().numpy().copy()))
+        with pool.slot(k) as enc:
+            enc.encode_pack(v, None, outs[k])
+    pool.synchronize()
+    for k in (0, 1):
+        got.append((outs[k]["n_bytes"].cpu().numpy().copy(), outs[k]["payload"].cpu().numpy().copy()))
+    assert len(pool) == 2 and len(got) == 4
+    for (nb, pay), (nb_w, pay_w) in zip(got, want):
+        assert np.array_equal(nb, nb_w)
+        assert all(np.array_equal(pay[i, :nb[i]], pay_w[i, :nb[i]]) for i in range(len(nb)))
