@@ -988,7 +988,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 const bool has = half == 0 && l < nb;
                 const int nl = has ? n_lines[l] : 0;
                 int bits = 0, cap = 0;
-                bitalloc_half(half == 0, has, has ? s_l : 0.0, nl, budget, max_mant, cp + 32 * half, half, l, bits, cap, T.guard != 0);
+                bitalloc_half(half == 0, has, has ? s_l : 0.0, nl, budget, max_mant, cp + 32 * half, half, l, bits, cap, T.guard != 0, T.nb_long);
                 if (has) {
                     tail.bit_alloc[boff + l] = bits;
                     ba_s[l] = bits;

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64) void k_bitalloc(PacxTables T, const uint8_t *__
     const double s = has ? smr[off + l] : 0.0;
     const int nl = has ? n_lines[l] : 0;
     int bits = 0, cap = 0;
-    bitalloc_half(alive, has, s, nl, budget, max_mant, cp[half], half, l, bits, cap, T.guard != 0);
+    bitalloc_half(alive, has, s, nl, budget, max_mant, cp[half], half, l, bits, cap, T.guard != 0,
+                  T.nb_long > T.nb_short ? T.nb_long : T.nb_short);
     if (has)
         bit_alloc[off + l] = bits;
     if (alive && cap && status && l == 0)
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(64, 4) void k_tail_long(PacxTables T, const uint8_t
         const double sv = has ? smr[boff + l] : 0.0;
         const int nl = has ? n_lines[l] : 0;
         int bits = 0, cap = 0;
-        bitalloc_half(alive, has, sv, nl, budget, max_mant, cp[half], half, l, bits, cap, T.guard != 0);
+        bitalloc_half(alive, has, sv, nl, budget, max_mant, cp[half], half, l, bits, cap, T.guard != 0, T.nb_long);
         if (has) {
             bit_alloc[boff + l] = bits;
             ba_2[half][l] = bits;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void k_tail_short(PacxTables T, const uint8_t 
         const double sv = has ? smr[off + l] : 0.0;
         const int nl = has ? T.band_lines_short[l] : 0;
         int bits = 0, cap = 0;
-        bitalloc_half(true, has, sv, nl, budget, max_mant, cp[wv][half], half, l, bits, cap, T.guard != 0);
+        bitalloc_half(true, has, sv, nl, budget, max_mant, cp[wv][half], half, l, bits, cap, T.guard != 0, nb);
         if (has) {
             bit_alloc[off + l] = bits;
             ba_s[sb][l] = bits;
@@ -545,27 +546,21 @@ __global__ __launch_bounds__(256) void k_tail_short(PacxTables T, const uint8_t 
         const double x0 = v.x * up, x1 = v.y * up;
         {
             /* ScaleFactor is non-increasing in the magnitude, so a band's scale factor is the
-               minimum of its lines' own scale factors: small integers, whose wave minimum
-               per band is a bisection with one ballot per bit -- no LDS round trips (a 64-bit
-               wave maximum per band was six dependent ones, for each of the six bands).  The
-               band's owner lane adds ScaleFactor(0), the value of a band without lines. */
-            const int nsb = T.n_scale_bits, big = 1 << nsb;          /* above every scale factor */
-            const int s0 = (band0 < nb) ? pacx_scale_factor(fabs(x0), nsb, ba_s[sb][band0]) : big;
-            const int s1 = (band1 < nb) ? pacx_scale_factor(fabs(x1), nsb, ba_s[sb][band1]) : big;
-            const int s_own = (lane < nb) ? pacx_scale_factor(0.0, nsb, ba_s[sb][lane]) : big;
-            for (int b = 0; b < nb; ++b) {
-                int c = (lane == b) ? s_own : big;
-                if (band0 == b)
-                    c = min(c, s0);
-                if (band1 == b)
-                    c = min(c, s1);
-                int lo = 0;
-                for (int bit = nsb; bit >= 0; --bit)
-                    if (!__builtin_amdgcn_ballot_w64(c < lo + (1 << bit)))
-                        lo += 1 << bit;
-                if (lane == b)
-                    sf_s[sb][b] = lo;
-            }
+               minimum of its lines' own scale factors: small integers (a 64-bit wave maximum of
+               the magnitudes per band was six dependent LDS round trips for each of the six bands;
+               round 2 took the minimum by bisection with one ballot per bit). */
+            const int nsb = T.n_scale_bits;
+            /* round 3: the per-band minimum as a 32-bit LDS atomic min -- each band's owner lane posts ScaleFactor(0),
+               the value of a band without lines, then every lane posts its two lines' own scale factors (one
+               ds_min_i32 each, no return value): one LDS round trip for all six bands, where the bisection by
+               ballots took five ballots per band (130 instructions per sub-block, a sixth of this kernel) */
+            if (lane < nb)
+                sf_s[sb][lane] = pacx_scale_factor(0.0, nsb, ba_s[sb][lane]);
+            wave_lds_fence();
+            if (band0 < nb)
+                atomicMin(&sf_s[sb][band0], pacx_scale_factor(fabs(x0), nsb, ba_s[sb][band0]));
+            if (band1 < nb)
+                atomicMin(&sf_s[sb][band1], pacx_scale_factor(fabs(x1), nsb, ba_s[sb][band1]));
         }
         wave_lds_fence();
         const int a0 = ba_s[sb][band0], a1 = ba_s[sb][band1];

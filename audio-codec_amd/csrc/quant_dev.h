@@ -37,8 +37,10 @@ __device__ __forceinline__ int half_sum_i(int v)
  * alive = false). */
 __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, int nl, double budget,
                                               int max_mant, double *c, int half, int l, int &bits_out,
-                                              int &cap_out, bool want_guard = false)
+                                              int &cap_out, bool want_guard = false, int n_b = 32)
 {
+    /* n_b (wave-uniform): an upper bound on the band count of either half wave -- lanes l >= n_b never hold a band, so
+       the all-pairs rank count need not visit them (6 for short blocks instead of 32) */
     const unsigned lt_mask = (1u << l) - 1u;
 
     int bits = 0, n_flip = 0, passes = 0, cap = 0;
@@ -110,7 +112,7 @@ __device__ __forceinline__ void bitalloc_half(bool alive, bool has, double s, in
             have_rank = true;
             lt = 0;
             le = 0;
-            for (int k = 0; k < 32; ++k) {
+            for (int k = 0; k < n_b; ++k) {
                 const double fk = __shfl(frac, k, 32);
                 if ((pmask >> k) & 1u) {
                     lt += fk < frac;
