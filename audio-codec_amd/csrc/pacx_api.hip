@@ -895,7 +895,11 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
     const PacxTables &T = h->T;
     const int mixed = frame_flags ? 1 : 0;     /* without flags every frame is a long sine block */
     const int n_ch = in->n_channels;
-    if (!mantissa && mixed) {                  /* short frames pack from a mantissa buffer */
+    /* k_tail_short (and the tails of the long frames) pack from registers; only the separate-kernel fallback for
+       layouts with more than 8 short bands (k_quantize<128> -> k_pack) reads the mantissas back from memory.  Round 3:
+       the workspace copy is no longer written when nobody asked for mantissas (it was 4 KB per channel-frame of HBM
+       writes in every block-switched step) */
+    if (!mantissa && mixed && T.nb_short > 8) {
         if (n_cf > h->ws_mant_cf) {
             HIP_TRY(h, hipDeviceSynchronize());
             if (h->ws_mant)
