@@ -885,12 +885,43 @@ def parse_block_body(br, p, cur_t):
         sf.append(br.get(p.nScaleBits))
         if a:
             if not cur_t and b in p.omittedBands:
-                # coder/pacfile.py:204-205 + Decode_SBR's scalar branch: a block the reference's
-                # encoder cannot write (it raises there, see encode_channel_sbr) -- not restated
-                raise NotImplementedError("scalar-mantissa block with a coded SBR band")
+                # coder/pacfile.py:203-205, 212-213: ONE mantissa, assigned to the whole slice of the band
+                # (the reference's own encoder cannot write such a block -- it raises there, see
+                # encode_channel_sbr -- but its reader and Decode_SBR's scalar branch take one)
+                mant[bands.lowerLine[b]:bands.upperLine[b] + 1] = br.get(a)
+                continue
             for j in range(bands.nLines[b]):
                 mant[bands.lowerLine[b] + j] = br.get(a)
     return sf, alloc, mant, overall
+
+
+def decode_block_sbr_scalar(p, sf, alloc, mant_lines, overall, last_t, cur_t, next_t):
+    """coder/codec.py:95-222 with useVQ off: the line loop of :117-134 counts ONE line for an omitted band
+    (so band b's value lands on line cut + (b - first omitted) and is dequantised from whatever
+    mantissa the reader left at THAT line, :130-133), then the reconstruction of :136-198, the
+    overall scale, IMDCT and window."""
+    from . import pac_oracle_vq as pv
+    bands = p.sfBands
+    half_n = p.nMDCTLines
+    lines = np.zeros(half_n, dtype=np.float64)
+    at = 0
+    for b in range(bands.nBands):
+        n = 1 if b in p.omittedBands else bands.nLines[b]
+        if alloc[b]:
+            lines[at:at + n] = dequantize_vec(sf[b], mant_lines[at:at + n], p.nScaleBits, alloc[b])
+        at += n
+    lines = pv.sbr_reconstruct(lines, p)
+    lines /= 1. * (1 << overall)
+    win = window_table(window_kind(last_t, cur_t, next_t), 2 * half_n)
+    return win * mdct_inverse(lines, half_n, half_n)
+
+
+def decode_any_block(p, sf, alloc, mant_lines, overall, last_t, cur_t, next_t):
+    """PACFile.Decode, coder/pacfile.py:645-668: a long block of an SBR file with bits in an omitted band
+    goes to Decode_SBR, every other block to Decode."""
+    if p.useSBR and not cur_t and np.any(np.array(alloc)[np.array(p.omittedBands, dtype=int)] != 0):
+        return decode_block_sbr_scalar(p, sf, alloc, mant_lines, overall, last_t, cur_t, next_t)
+    return decode_block(p, sf, alloc, mant_lines, overall, last_t, cur_t, next_t)
 
 
 def parse_header(data):
@@ -926,7 +957,7 @@ def decode_stream(data):
             pos += 4 + n_bytes
             last_t, cur_t, next_t = br.get(1), br.get(1), br.get(1)
             if not cur_t:
-                block = decode_block(p, *parse_block_body(br, p, False), last_t, cur_t, next_t)
+                block = decode_any_block(p, *parse_block_body(br, p, False), last_t, cur_t, next_t)
             else:
                 block = np.zeros(2 * hop)
                 p.nMDCTLines = p.nSamplesPerBlock = SHORT_LINES
@@ -942,3 +973,59 @@ def decode_stream(data):
         out.append(np.stack([fraction_to_pcm16(h) for h in hop_out], axis=1))
     out.append(np.stack([fraction_to_pcm16(o) for o in ola], axis=1))
     return np.concatenate(out)
+
+
+def recode_scalar_sbr_stream(data, keep=lambda hop, ch, band: True):
+    """Test material for Decode_SBR's scalar branch: a plain scalar stream (long and short blocks)
+    rewritten as the SBR file whose long blocks CODE their omitted bands the way the reference's
+    reader expects them (coder/pacfile.py:203-205: one mantissa per omitted band) -- band b keeps its
+    allocation and scale factor and carries the mantissa of its first line; keep(hop, ch, band) False
+    drops the band's bits instead.  No reference encoder writes this (encode_channel_sbr), its decoder
+    reads it."""
+    p, n_samples, pos = parse_header(data)
+    assert not p.useSBR
+    q = make_params(p.sampleRate, p.nChannels, 128, p.nMDCTLines, p.nScaleBits, p.nMantSizeBits)
+    q.useSBR = True
+    q.omittedBands = list(omitted_bands(q.sfBands))
+    head = bytearray(data[:pos])
+    struct.pack_into('<H', head, 4 + struct.calcsize('<LHLLHH'), 1)
+    out = bytes(head)
+    hop_no = 0
+    while pos < len(data):
+        for ch in range(p.nChannels):
+            n_bytes = struct.unpack('<L', data[pos:pos + 4])[0]
+            br = BitReader(data[pos + 4:pos + 4 + n_bytes])
+            pos += 4 + n_bytes
+            flags = (br.get(1), br.get(1), br.get(1))
+            if flags[1]:                                   # short blocks are written as they are
+                out += data[pos - 4 - n_bytes:pos]
+                continue
+            sf, alloc, mant, overall = parse_block_body(br, p, False)
+            bands = p.sfBands
+            n_bits = 3 + p.nScaleBits
+            fields = []
+            for b in range(bands.nBands):
+                a = int(alloc[b])
+                lo = int(bands.lowerLine[b])
+                if b in q.omittedBands:
+                    if a and not keep(hop_no, ch, b):
+                        a = 0
+                    codes = [int(mant[lo])] if a else []
+                else:
+                    codes = [int(m) for m in mant[lo:lo + bands.nLines[b]]] if a else []
+                fields.append((a, int(sf[b]), codes))
+                n_bits += p.nMantSizeBits + p.nScaleBits + a * len(codes)
+            tot = n_bits + 1                                # the size rule of coder/pacfile.py:552-565: body + 4 bits, rounded up
+            n_out = tot // 8 if tot % 8 == 0 else tot // 8 + 1
+            bw = BitWriter(n_out)
+            for f in flags:
+                bw.put(f, 1)
+            bw.put(overall, p.nScaleBits)
+            for (a, s, codes) in fields:
+                bw.put(a - 1 if a else 0, p.nMantSizeBits)
+                bw.put(s, p.nScaleBits)
+                for c in codes:
+                    bw.put(c, a)
+            out += struct.pack('<L', n_out) + bw.bytes()
+        hop_no += 1
+    return out

@@ -26,6 +26,8 @@ Outputs
   excerpt_vq_*.npz  (--vq) 24-hop excerpts in the shipped configuration
   decoded_vq_*.npz  (--vq-decoded) those excerpts through the reference's decoder
   vqwav.json        (--vq-decoded) hashes of the decoded WAVs the reference committed
+  sbr_scalar_decode.npz (--sbr-scalar-decode) the reference's reader + Decode_SBR scalar branch on streams
+                    and code sets with coded omitted bands (inputs made with the oracle, outputs the reference's)
   sbr_scalar.json   (--sbr-scalar) what the reference does with scalar mantissas + spectral band
                     replication (useVQ off, useSBR on: the branch of EncodeSingleChannel_SBR the
                     shipped driver never selects, coder/codec.py:529-555): it raises as soon as an
@@ -650,7 +652,70 @@ def make_sbr_scalar():
     json.dump(report, open(os.path.join(HERE, "sbr_scalar.json"), "w"), indent=1)
 
 
+def make_sbr_scalar_decode():
+    """Decode_SBR's scalar branch (coder/codec.py:117-134 with useVQ off) and the reader rule that feeds
+    it (coder/pacfile.py:203-205, 659-663).  No reference ENCODER writes a scalar-mantissa block with a coded
+    omitted band (make_sbr_scalar above), so the inputs are made here: plain scalar streams of the excerpts
+    (the oracle's encoder, bit-identical to the reference's) rewritten with one mantissa per omitted band
+    (oracle.pac_oracle.recode_scalar_sbr_stream), and random code sets.  The OUTPUTS are the reference's:
+    its PACFile reader + PCMFile writer on the streams, its codec.Decode_SBR on the code sets."""
+    from oracle import pac_oracle as po
+    out = {}
+    cases = []
+    for name, kbps, bs, drop, h0 in (("harpsichord", 96, False, False, 0), ("castanet", 192, True, True, 30),
+                                     ("quar48_1", 128, True, False, 40), ("spmg", 192, False, True, 0)):
+        ex = np.load(os.path.join(HERE, f"excerpt_{name}.npz"))
+        pcm, sr = ex["pcm"][h0 * 1024:(h0 + 16) * 1024], int(ex["sr"])
+        plain = po.encode_stream(pcm, sr, kbps, bs)
+        keep = (lambda hop, ch, band: (hop + ch + band) % 3 != 0) if drop else (lambda hop, ch, band: True)
+        pac = po.recode_scalar_sbr_stream(plain, keep)
+        tag = f"{name}_{kbps}_{'bs' if bs else 'long'}"
+        path = os.path.join(_work, f"sbrsd_{tag}.pac")
+        open(path, "wb").write(pac)
+        dec = ref_decode_file(path, os.path.join(_work, f"sbrsd_{tag}.wav"))
+        out[f"pac_{tag}"] = np.frombuffer(pac, dtype=np.uint8)
+        out[f"pcm_{tag}"] = dec.astype(np.int16)
+        cases.append(tag)
+        print(tag, len(pac), dec.shape)
+    rng = np.random.default_rng(20261004)
+    for sr in (48000, 44100, 32000):
+        cp = ref_params(sr, 1, 96)
+        cp.useSBR = True
+        cp.omittedBands = sbr.omitted_bands(cp.sfBands)
+        nb = cp.sfBands.nBands
+        K = 12
+        sfs = rng.integers(0, 16, (K, nb)).astype(np.int32)
+        bas = rng.integers(0, 13, (K, nb)).astype(np.int32)
+        bas[bas == 1] = 0
+        bas[0, cp.omittedBands] = 0                      # (the caller sends this one to Decode; Decode_SBR takes it all the same)
+        bas[1, :] = 0
+        bas[1, cp.omittedBands[-1]] = 5
+        mant = np.zeros((K, 1024), np.int32)
+        for k in range(K):
+            for b in range(nb):
+                a = int(bas[k, b])
+                if not a:
+                    continue
+                lo, hi = cp.sfBands.lowerLine[b], cp.sfBands.upperLine[b] + 1
+                if b in cp.omittedBands:
+                    mant[k, lo:hi] = rng.integers(0, 1 << a)
+                else:
+                    mant[k, lo:hi] = rng.integers(0, 1 << a, hi - lo)
+        ov = rng.integers(0, 16, K).astype(np.int32)
+        fl = rng.integers(0, 2, (K, 2)).astype(np.int32)     # lastTrans, nextTrans
+        blocks = np.stack([codec.Decode_SBR(sfs[k], bas[k], mant[k], int(ov[k]), None, cp,
+                                            bool(fl[k, 0]), False, bool(fl[k, 1])) for k in range(K)])
+        out[f"fn_{sr}_sf"], out[f"fn_{sr}_ba"], out[f"fn_{sr}_mant"] = sfs, bas, mant
+        out[f"fn_{sr}_overall"], out[f"fn_{sr}_flags"], out[f"fn_{sr}_block"] = ov, fl, blocks
+        print(sr, "Decode_SBR scalar:", blocks.shape, float(np.abs(blocks).max()))
+    out["stream_cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "sbr_scalar_decode.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--sbr-scalar-decode" in sys.argv:
+        make_sbr_scalar_decode()
+        sys.exit(0)
     if "--sbr-scalar" in sys.argv:
         make_sbr_scalar()
         sys.exit(0)
