@@ -663,7 +663,7 @@ def make_sbr_scalar_decode():
     out = {}
     cases = []
     for name, kbps, bs, drop, h0 in (("harpsichord", 96, False, False, 0), ("castanet", 192, True, True, 30),
-                                     ("quar48_1", 128, True, False, 40), ("spmg", 192, False, True, 0)):
+                                     ("quar48_1", 256, True, False, 40), ("spmg", 192, False, True, 0)):
         ex = np.load(os.path.join(HERE, f"excerpt_{name}.npz"))
         pcm, sr = ex["pcm"][h0 * 1024:(h0 + 16) * 1024], int(ex["sr"])
         plain = po.encode_stream(pcm, sr, kbps, bs)
