@@ -173,14 +173,11 @@ def EncodeSingleChannel(data, codingParams, lastTrans=False, curTrans=False, nex
     return s[0], b[0], m[0], o[0]
 
 
-def Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,
-           lastTrans=False, curTrans=False, nextTrans=False):
-    """coder/codec.py:47-92 for one channel on the GPU (pacx_decode_batch): the
-    windowed IMDCT output, 2*nMDCTLines samples, before overlap-and-add.
-    `mantissa` is line-indexed, as PACFile.getDecodedBlock builds it."""
+def _decode_scalar_block(scaleFactor, bitAlloc, mantissa, overallScaleFactor, codingParams, lastTrans, curTrans,
+                         nextTrans, sbr):
+    """one channel-block of scalar mantissas on the GPU: pacx_decode_batch (codec.Decode) or, sbr,
+    pacx_decode_sbr_batch with Decode_SBR on the block whatever its allocations"""
     import torch
-    if getattr(codingParams, "useVQ", False):
-        return _decode_vq(bitAlloc, overallScaleFactor, pb, codingParams, lastTrans, curTrans, nextTrans, sbr=False)
     enc = context.encoder_for_params(codingParams)
     n_lines = codingParams.nMDCTLines
     if n_lines not in (1024, 128) or bool(curTrans) != (n_lines == 128):
@@ -196,8 +193,25 @@ def Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams
     codes["scale_factor"][0, :nb] = torch.as_tensor(np.asarray(scaleFactor, dtype=np.int32), device=dev)
     codes["bit_alloc"][0, :nb] = torch.as_tensor(np.asarray(bitAlloc, dtype=np.int32), device=dev)
     codes["mantissa"][0, :n_lines] = torch.as_tensor(np.asarray(mantissa, dtype=np.int32)[:n_lines], device=dev)
-    block = enc.decode(codes, 1, want_blocks=True, want_pcm=False)[0].cpu().numpy()
-    return block[448:448 + 256].copy() if curTrans else block
+    if not sbr:
+        block = enc.decode(codes, 1, want_blocks=True, want_pcm=False)[0].cpu().numpy()
+        return block[448:448 + 256].copy() if curTrans else block
+    extra = {}
+    block = enc.decode(codes, 1, want_blocks=True, want_pcm=False, extra=extra, every_long_block=True)[0].cpu().numpy()
+    if int(extra["status"][0].item()) & _lib.ST_VQ_UNDEFINED:
+        raise IndexError("index 1024 is out of bounds for axis 0 with size 1024")       # coder/codec.py:173-176
+    return block
+
+
+def Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,
+           lastTrans=False, curTrans=False, nextTrans=False):
+    """coder/codec.py:47-92 for one channel on the GPU (pacx_decode_batch): the
+    windowed IMDCT output, 2*nMDCTLines samples, before overlap-and-add.
+    `mantissa` is line-indexed, as PACFile.getDecodedBlock builds it."""
+    if getattr(codingParams, "useVQ", False):
+        return _decode_vq(bitAlloc, overallScaleFactor, pb, codingParams, lastTrans, curTrans, nextTrans, sbr=False)
+    return _decode_scalar_block(scaleFactor, bitAlloc, mantissa, overallScaleFactor, codingParams, lastTrans,
+                                curTrans, nextTrans, sbr=False)
 
 
 class _Bits:
@@ -273,12 +287,15 @@ def _decode_vq(bitAlloc, overallScaleFactor, pb, codingParams, lastTrans, curTra
 
 def Decode_SBR(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,
                lastTrans=False, curTrans=False, nextTrans=False):
-    """coder/codec.py:95-222 (long block of an SBR file, gain-shape coder): dequantised lines,
-    spectral band replication (Gaussian-smoothed envelope, order-1 spline transposition,
-    per-band scaling), IMDCT, window.  Scalar-mantissa SBR streams are not produced by the
-    reference's driver (coder/pacfile.py:703-705) and are not decoded here."""
-    if not getattr(codingParams, "useVQ", False):
-        raise NotImplementedError("scalar-mantissa SBR is not produced by the reference's driver")
+    """coder/codec.py:95-222 (long block of an SBR file): dequantised lines -- an omitted band counts
+    ONE line (:121-134), gain-shape coded or, with useVQ off, dequantised from the mantissa at that
+    line of the line-indexed array --, spectral band replication (Gaussian-smoothed envelope,
+    order-1 spline transposition, per-band scaling), IMDCT, window."""
     if curTrans:
         raise ValueError("Decode_SBR decodes long blocks (coder/pacfile.py:661-666)")
+    if not getattr(codingParams, "useVQ", False):
+        if not getattr(codingParams, "useSBR", False):
+            raise ValueError("Decode_SBR: codingParams.useSBR is off (no omitted bands)")
+        return _decode_scalar_block(scaleFactor, bitAlloc, mantissa, overallScaleFactor, codingParams, lastTrans,
+                                    False, nextTrans, sbr=True)
     return _decode_vq(bitAlloc, overallScaleFactor, pb, codingParams, lastTrans, curTrans, nextTrans, sbr=True)

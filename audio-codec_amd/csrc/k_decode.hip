@@ -80,6 +80,7 @@ __global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, con
         const int nb = shrt ? T.nb_short : T.nb_long;
         const int32_t *cnt = shrt ? T.band_lines_short : T.band_lines_long;
         const int head = T.n_mant_size_bits + T.n_scale_bits;
+        const bool one_code = T.use_sbr && !T.use_vq && !shrt;
         int pos = 3;
         for (int s = 0; s < (shrt ? PACX_SUB : 1) && !bad; ++s) {
             if (pos + T.n_scale_bits > limit) {
@@ -98,7 +99,10 @@ __global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, con
                     a += 1;
                 const int sf = (int)get_bits(words, pos + T.n_mant_size_bits, T.n_scale_bits);
                 pos += head;
-                if (a > 16 || pos + a * cnt[b] > limit) {
+                /* scalar mantissas in an SBR file: a coded omitted band of a long block carries ONE mantissa,
+                   which the reader assigns to every line of the band (coder/pacfile.py:203-205, 212-213) */
+                const int n_codes = (one_code && b >= T.first_omitted) ? 1 : cnt[b];
+                if (a > 16 || pos + a * n_codes > limit) {
                     bad = true;
                     break;
                 }
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, con
                     bas[s][nb] = 0;                        /* dummy band of the lines no band covers */
                 ba_o[s * nb + b] = a;
                 sf_o[s * nb + b] = sf;
-                pos += a * cnt[b];
+                pos += a * n_codes;
             }
         }
         if (bad) {                                         /* all-zero codes for the whole record */
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(64) void k_unpack(PacxTables T, long long n_cf, con
         const int kk = k - s * m_lines;
         const int b = band_of[kk];
         const int a = bad_s ? 0 : bas[s][b];
-        mantissa[cf * PACX_M_LONG + k] = a ? (int32_t)get_bits(words, offs[s][b] + (kk - lower[b]) * a, a) : 0;
+        const int idx = (T.use_sbr && !T.use_vq && !shrt && b >= T.first_omitted) ? 0 : kk - lower[b];
+        mantissa[cf * PACX_M_LONG + k] = a ? (int32_t)get_bits(words, offs[s][b] + idx * a, a) : 0;
     }
 }
 
@@ -151,6 +156,54 @@ __device__ __forceinline__ double dequant_line(int mant, int scale, int ba, int 
     if (!ba)
         return 0.0;
     return pacx_dequantize(mant, scale, n_scale_bits, ba) / (double)(1 << overall);
+}
+
+/* ------------------------------------------- scalar mantissas in an SBR file */
+/* PACFile.Decode (coder/pacfile.py:645-668) sends a long block with bits in an omitted band to
+ * Decode_SBR, whose line loop (coder/codec.py:117-134, useVQ off) counts ONE line for an omitted
+ * band: band b's value lands on line cut + (b - first omitted), dequantised from the mantissa the
+ * reader left at THAT line (the reader broadcast each coded omitted band's one mantissa over the
+ * band's own lines, k_unpack).  Every other block is codec.Decode's.  This kernel writes the
+ * dequantised lines of every channel-block BEFORE the division by 2^overall (k_sbr_recon works on
+ * those, then k_imdct_* divide, as for gain-shape streams) and says which blocks k_sbr_recon takes. */
+__global__ __launch_bounds__(64) void k_sbr_scalar_lines(PacxTables T, long long n_cf, const uint8_t *__restrict__ cf_flags,
+                                                        const int32_t *__restrict__ scale_factor,
+                                                        const int32_t *__restrict__ bit_alloc,
+                                                        const int32_t *__restrict__ mantissa,
+                                                        double *__restrict__ lines, uint8_t *__restrict__ sbr_flag,
+                                                        int routing)
+{
+    /* routing 0: codec.Decode for every block; 1: PACFile.Decode's rule; 2: Decode_SBR for every long block */
+    const int lane = threadIdx.x;
+    const long long cf = blockIdx.x;
+    if (cf >= n_cf)
+        return;
+    const int32_t *ba = bit_alloc + cf * T.band_stride, *sf = scale_factor + cf * T.band_stride;
+    const int32_t *mant = mantissa + cf * PACX_M_LONG;
+    double *out = lines + cf * PACX_M_LONG;
+    if (cf_flags[cf] & 2u) {
+        for (int k = lane; k < PACX_M_LONG; k += 64) {
+            const int s = k / PACX_M_SHORT, kk = k % PACX_M_SHORT;
+            const int b = T.line_band_short[kk];
+            const int a = (b < T.nb_short) ? ba[s * T.nb_short + b] : 0;
+            out[k] = a ? pacx_dequantize(mant[k], sf[s * T.nb_short + b], T.n_scale_bits, a) : 0.0;
+        }
+        if (lane == 0)
+            sbr_flag[cf] = 0;
+        return;
+    }
+    const bool coded = lane >= T.first_omitted && lane < T.nb_long && ba[lane] != 0;
+    const bool sbr = routing == 2 || (routing == 1 && __builtin_amdgcn_ballot_w64(coded) != 0ull);
+    const int cut = T.band_lower_long[T.first_omitted];
+    for (int k = lane; k < PACX_M_LONG; k += 64) {
+        int b = T.line_band_long[k];
+        if (sbr && k >= cut)
+            b = T.first_omitted + (k - cut);               /* one line per omitted band, then nothing */
+        const int a = (b < T.nb_long) ? ba[b] : 0;
+        out[k] = a ? pacx_dequantize(mant[k], sf[b], T.n_scale_bits, a) : 0.0;
+    }
+    if (lane == 0)
+        sbr_flag[cf] = sbr ? 1 : 0;
 }
 
 /* -------------------------------------------------------------- IMDCT long */
@@ -360,6 +413,15 @@ void pacx_launch_decode(const PacxTables &T, long long n_blocks, int n_ch, const
         hipLaunchKernelGGL(k_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n_blocks, n_ch, blocks,
                            pcm);
     }
+}
+
+void pacx_launch_sbr_scalar_lines(const PacxTables &T, long long n_cf, const uint8_t *cf_flags,
+                                  const int32_t *scale_factor, const int32_t *bit_alloc, const int32_t *mantissa,
+                                  double *lines, uint8_t *sbr_flag, int routing, hipStream_t st)
+{
+    if (n_cf > 0)
+        hipLaunchKernelGGL(k_sbr_scalar_lines, dim3((unsigned)n_cf), dim3(64), 0, st, T, n_cf, cf_flags, scale_factor,
+                           bit_alloc, mantissa, lines, sbr_flag, routing);
 }
 
 /* mdct.IMDCT for rows of 1024 lines (short_blocks: rows of 8 x 128 lines) -> 2048 samples each, unwindowed */

@@ -1322,6 +1322,22 @@ __global__ __launch_bounds__(SBR_THREADS) void k_sbr_recon(PacxTables T, VqDecVi
 /* ---------------------------------------------------------------- launchers */
 size_t pacx_vqdec_view_size(void) { return sizeof(VqDecView); }
 
+static size_t sbr_recon_lds(void)
+{
+    /* LDS sized for the worst case (every line above the cut) */
+    return (size_t)(PACX_M_LONG + PACX_M_LONG + PACX_M_LONG + 2) * 8;      /* lines, smoothed envelope, ordinates */
+}
+
+/* Decode_SBR's reconstruction alone (scalar-mantissa SBR streams: the view carries the Gaussian weights and the
+   line frequencies only) */
+void pacx_launch_sbr_recon(const PacxTables &T, const void *view, long long n_cf, const uint8_t *sbr_flag,
+                           double *lines, uint32_t *status, hipStream_t st)
+{
+    if (n_cf > 0)
+        hipLaunchKernelGGL(k_sbr_recon, dim3((unsigned)n_cf), dim3(SBR_THREADS), sbr_recon_lds(), st, T,
+                           *(const VqDecView *)view, n_cf, sbr_flag, lines, status);
+}
+
 void pacx_vqdec_view_fill(void *dst, const uint64_t *n_tab, const uint64_t *p_tab, const int32_t *row_off,
                           const int32_t *k_of, const uint8_t *w_of, const double *half_log2, int l_max,
                           const double *log2_tan, const double *gauss, int gauss_r, const double *line_freq,
@@ -1388,10 +1404,7 @@ void pacx_launch_vq_dec(const PacxTables &T, const void *view, long long n_cf, c
     if (A.redo)
         hipLaunchKernelGGL(k_vq_dec_frame, dim3((unsigned)n_cf), dim3(64 * VQD_WAVES), (size_t)VQDF_SMEM, st, T, V, A);
     hipLaunchKernelGGL(k_vq_dec, dim3((unsigned)n_cf), dim3(64 * VQD_WAVES), smem, st, T, V, A);
-    if (T.use_sbr) {
-        /* LDS sized for the worst case (every line above the cut) */
-        const size_t s2 = (size_t)(PACX_M_LONG + PACX_M_LONG + PACX_M_LONG + 2) * 8;      /* lines, smoothed envelope, ordinates */
-        hipLaunchKernelGGL(k_sbr_recon, dim3((unsigned)n_cf), dim3(SBR_THREADS), s2, st, T, V, n_cf, sbr_flag, lines,
-                           status);
-    }
+    if (T.use_sbr)
+        hipLaunchKernelGGL(k_sbr_recon, dim3((unsigned)n_cf), dim3(SBR_THREADS), sbr_recon_lds(), st, T, V, n_cf,
+                           sbr_flag, lines, status);
 }

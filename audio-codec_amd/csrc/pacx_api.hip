@@ -74,6 +74,11 @@ void pacx_launch_transient_f64(long long n_blocks, int n_ch, int n, const double
 void pacx_launch_transient(const PacxPcmView &in, long long n_hops, int hop, uint8_t *transient,
                            uint8_t *flags, hipStream_t st);
 
+void pacx_launch_sbr_scalar_lines(const PacxTables &T, long long n_cf, const uint8_t *cf_flags,
+                                  const int32_t *scale_factor, const int32_t *bit_alloc, const int32_t *mantissa,
+                                  double *lines, uint8_t *sbr_flag, int routing, hipStream_t st);
+void pacx_launch_sbr_recon(const PacxTables &T, const void *view, long long n_cf, const uint8_t *sbr_flag,
+                           double *lines, uint32_t *status, hipStream_t st);
 void pacx_launch_unpack(const PacxTables &T, long long n_cf, const uint8_t *payload, int payload_stride,
                         const long long *offsets, const int32_t *n_bytes, uint8_t *flags_out, int32_t *overall,
                         int32_t *scale_factor, int32_t *bit_alloc, int32_t *mantissa, uint32_t *status,
@@ -142,6 +147,7 @@ struct pacx_handle {
     long long ws_dec_cf;              /* capacity of the VQ decode buffers      */
     double *ws_dec_lines;             /* [cf][1024]                             */
     uint8_t *ws_dec_sbr;              /* [cf]                                   */
+    uint32_t *ws_dec_status;          /* [cf] (scalar SBR decode without a caller's status) */
     double *ws_sbr_mean;              /* [ws_cf][8] omitted-band means           */
     long long ws_vq_cf;               /* capacity of the short-frame buffers    */
     unsigned *ws_unit_words;          /* [ws_vq_cf*8][548]                      */
@@ -348,6 +354,7 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->ws_dec_cf = 0;
     h->ws_dec_lines = nullptr;
     h->ws_dec_sbr = nullptr;
+    h->ws_dec_status = nullptr;
     h->ws_vq_cf = 0;
     h->ws_unit_words = nullptr;
     h->ws_unit_bits = nullptr;
@@ -558,8 +565,12 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         }
         TRY(upload(h, alloc_lines.data(), alloc_lines.size(), &T.band_lines_long_alloc));
     }
+    const uint64_t *d_n = nullptr, *d_p = nullptr;
+    const int32_t *d_off = nullptr, *d_k = nullptr;
+    const uint8_t *d_w = nullptr;
+    const double *d_hl = nullptr, *d_lt = nullptr;
+    int l_max = 1;
     if (T.use_vq) {
-        int l_max = 1;
         for (int b = 0; b < T.nb_long; ++b)
             l_max = cfg->band_lines_long[b] > l_max ? cfg->band_lines_long[b] : l_max;
         for (int b = 0; b < T.nb_short; ++b)
@@ -568,10 +579,6 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         /* NULL gain-shape tables: the built-in NumPy-evaluated copies (l_max <= 1024 always:
            a band cannot have more lines than the block) */
         pacx_vq_build(l_max, cfg->half_log2 ? cfg->half_log2 : (const double *)PACX_GEN_HALF_LOG2, &vt);
-        const uint64_t *d_n, *d_p;
-        const int32_t *d_off, *d_k;
-        const uint8_t *d_w;
-        const double *d_hl;
         if (vt.n_tab.empty()) {            /* l_max < 3: rows 0..2 are closed forms */
             vt.n_tab.push_back(0);
             vt.p_tab.push_back(0);
@@ -591,13 +598,15 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
         memcpy(lt.data(), cfg->vq_log2_tan ? cfg->vq_log2_tan : (const double *)PACX_GEN_VQ_LOG2_TAN,
                sizeof(double) * lt.size());
         static_assert(sizeof(PACX_GEN_VQ_LOG2_TAN) / 8 == (1u << PACX_VQ_THETA_TABLE_BITS) - 1, "log2-tan table");
-        const double *d_lt;
         TRY(upload(h, lt.data(), lt.size(), &d_lt));
         pacx_vq_view_fill(h->vq_view.data(), d_n, d_p, d_off, d_k, d_w, d_hl, l_max,
                           cfg->log_mu1 != 0.0 ? cfg->log_mu1 : ((const double *)PACX_GEN_LOG_MU1)[0], d_lt, sizes_long.data(), T.nb_long,
                           cfg->band_lines_short, T.nb_short);
+    }
+    if (T.use_vq || T.use_sbr) {
         /* decode side: Gaussian weights of gaussian_filter1d(sigma=200) (radius
-           int(4*200 + 0.5)) and the MDCT line frequencies of Decode_SBR */
+           int(4*200 + 0.5)) and the MDCT line frequencies of Decode_SBR (scalar-mantissa SBR
+           handles: these two alone, for k_sbr_recon) */
         const int gr = cfg->sbr_gauss ? cfg->sbr_gauss_radius : 800;
         if (gr < 1 || gr > 4096) {
             g_create_err = "pacx_create: sbr_gauss_radius out of range";
@@ -687,6 +696,8 @@ extern "C" void pacx_destroy(pacx_handle *h)
         (void)hipFree(h->ws_dec_lines);
     if (h->ws_dec_sbr)
         (void)hipFree(h->ws_dec_sbr);
+    if (h->ws_dec_status)
+        (void)hipFree(h->ws_dec_status);
     for (void *p : h->owned)
         (void)hipFree(p);
     delete h;
@@ -1439,34 +1450,108 @@ extern "C" int pacx_unpack_batch(pacx_handle *h, int64_t n_cf, const uint8_t *pa
     return post_launch(h, "pacx_unpack_batch");
 }
 
+/* the decoders' own workspaces: windowed blocks when the caller wants PCM only; lines + SBR flags (+ status words) */
+static int reserve_dec_blocks(pacx_handle *h, long long n_cf)
+{
+    if (n_cf <= h->ws_blocks_cf)
+        return PACX_OK;
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (h->ws_blocks)
+        (void)hipFree(h->ws_blocks);
+    h->ws_blocks = nullptr;
+    h->ws_blocks_cf = 0;
+    HIP_TRY(h, hipMalloc((void **)&h->ws_blocks, (size_t)n_cf * PACX_N_LONG * sizeof(double)));
+    h->ws_blocks_cf = n_cf;
+    return PACX_OK;
+}
+
+static int reserve_dec_lines(pacx_handle *h, long long n_cf)
+{
+    if (n_cf <= h->ws_dec_cf)
+        return PACX_OK;
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (h->ws_dec_lines) (void)hipFree(h->ws_dec_lines);
+    if (h->ws_dec_sbr) (void)hipFree(h->ws_dec_sbr);
+    if (h->ws_dec_status) (void)hipFree(h->ws_dec_status);
+    h->ws_dec_lines = nullptr;
+    h->ws_dec_sbr = nullptr;
+    h->ws_dec_status = nullptr;
+    h->ws_dec_cf = 0;
+    HIP_TRY(h, hipMalloc((void **)&h->ws_dec_lines, (size_t)n_cf * PACX_M_LONG * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_dec_sbr, (size_t)n_cf));
+    HIP_TRY(h, hipMalloc((void **)&h->ws_dec_status, (size_t)n_cf * sizeof(uint32_t)));
+    h->ws_dec_cf = n_cf;
+    return PACX_OK;
+}
+
+static int decode_scalar(pacx_handle *h, const char *what, int64_t n_blocks, int n_channels, const uint8_t *cf_flags,
+                         const int32_t *overall_scale, const int32_t *scale_factor, const int32_t *bit_alloc,
+                         const int32_t *mantissa, double *lines, double *blocks, int16_t *pcm, uint32_t *status,
+                         int routing, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (routing < 0 || routing > 2 || n_blocks < 0 || n_channels < 1 || (n_blocks > 0 && (!cf_flags || !overall_scale || !scale_factor ||
+                                                              !bit_alloc || !mantissa)) ||
+        (!blocks && !pcm && !lines))
+        return fail(h, PACX_E_ARG, std::string(what) + ": bad argument");
+    if (h->T.use_vq)
+        return fail(h, PACX_E_UNSUPPORTED, std::string(what) + ": handle was created with use_vq "
+                                           "(pacx_decode_vq_batch reads gain-shape streams)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long long n_cf = n_blocks * n_channels;
+    double *work = blocks;
+    if (!work && pcm && n_cf > 0) {
+        const int rc = reserve_dec_blocks(h, n_cf);
+        if (rc != PACX_OK)
+            return rc;
+        work = h->ws_blocks;
+    }
+    const double *lines_in = nullptr;
+    if (!h->T.use_sbr)
+        routing = 0;
+    if (n_cf > 0 && (routing || lines)) {
+        /* an SBR file (PACFile.Decode, coder/pacfile.py:645-668: long blocks with a coded omitted band are
+           Decode_SBR's, coder/codec.py:95-222 scalar branch), or a caller who wants the dequantised lines */
+        const int rc = reserve_dec_lines(h, n_cf);
+        if (rc != PACX_OK)
+            return rc;
+        double *ln = lines ? lines : h->ws_dec_lines;
+        uint32_t *stw = status ? status : h->ws_dec_status;
+        HIP_TRY(h, hipMemsetAsync(stw, 0, (size_t)n_cf * sizeof(uint32_t), st));
+        pacx_launch_sbr_scalar_lines(h->T, n_cf, cf_flags, scale_factor, bit_alloc, mantissa, ln, h->ws_dec_sbr, routing,
+                                     st);
+        if (routing)
+            pacx_launch_sbr_recon(h->T, h->vqdec_view.data(), n_cf, h->ws_dec_sbr, ln, stw, st);
+        lines_in = ln;
+    } else if (status && n_cf > 0) {
+        HIP_TRY(h, hipMemsetAsync(status, 0, (size_t)n_cf * sizeof(uint32_t), st));
+    }
+    if (work || pcm)
+        pacx_launch_decode(h->T, n_blocks, n_channels, cf_flags, overall_scale, scale_factor, bit_alloc, mantissa,
+                           lines_in, work, pcm, st);
+    return post_launch(h, what);
+}
+
 extern "C" int pacx_decode_batch(pacx_handle *h, int64_t n_blocks, int n_channels, const uint8_t *cf_flags,
                                  const int32_t *overall_scale, const int32_t *scale_factor,
                                  const int32_t *bit_alloc, const int32_t *mantissa, double *blocks,
                                  int16_t *pcm, void *stream)
 {
-    if (!h)
-        return PACX_E_ARG;
-    if (n_blocks < 0 || n_channels < 1 || (n_blocks > 0 && (!cf_flags || !overall_scale || !scale_factor ||
-                                                              !bit_alloc || !mantissa)) || (!blocks && !pcm))
+    if (h && !blocks && !pcm)
         return fail(h, PACX_E_ARG, "pacx_decode_batch: bad argument");
-    HIP_TRY(h, hipSetDevice(h->device));
-    const long long n_cf = n_blocks * n_channels;
-    double *work = blocks;
-    if (!work && n_cf > 0) {
-        if (n_cf > h->ws_blocks_cf) {
-            HIP_TRY(h, hipDeviceSynchronize());
-            if (h->ws_blocks)
-                (void)hipFree(h->ws_blocks);
-            h->ws_blocks = nullptr;
-            h->ws_blocks_cf = 0;
-            HIP_TRY(h, hipMalloc((void **)&h->ws_blocks, (size_t)n_cf * PACX_N_LONG * sizeof(double)));
-            h->ws_blocks_cf = n_cf;
-        }
-        work = h->ws_blocks;
-    }
-    pacx_launch_decode(h->T, n_blocks, n_channels, cf_flags, overall_scale, scale_factor, bit_alloc, mantissa,
-                       nullptr, work, pcm, (hipStream_t)stream);
-    return post_launch(h, "pacx_decode_batch");
+    return decode_scalar(h, "pacx_decode_batch", n_blocks, n_channels, cf_flags, overall_scale, scale_factor, bit_alloc,
+                         mantissa, nullptr, blocks, pcm, nullptr, 0, stream);
+}
+
+extern "C" int pacx_decode_sbr_batch(pacx_handle *h, int64_t n_blocks, int n_channels, const uint8_t *cf_flags,
+                                     const int32_t *overall_scale, const int32_t *scale_factor,
+                                     const int32_t *bit_alloc, const int32_t *mantissa, int routing,
+                                     double *lines, double *blocks, int16_t *pcm, uint32_t *status, void *stream)
+{
+    return decode_scalar(h, "pacx_decode_sbr_batch", n_blocks, n_channels, cf_flags, overall_scale, scale_factor,
+                         bit_alloc, mantissa, lines, blocks, pcm, status, routing ? 2 : 1, stream);
 }
 
 extern "C" int pacx_decode_vq_batch(pacx_handle *h, int64_t n_blocks, int n_channels, const uint8_t *payload,
@@ -1486,29 +1571,17 @@ extern "C" int pacx_decode_vq_batch(pacx_handle *h, int64_t n_blocks, int n_chan
     HIP_TRY(h, hipSetDevice(h->device));
     const long long n_cf = n_blocks * n_channels;
     hipStream_t st = (hipStream_t)stream;
-    if (n_cf > h->ws_dec_cf) {
-        HIP_TRY(h, hipDeviceSynchronize());
-        if (h->ws_dec_lines) (void)hipFree(h->ws_dec_lines);
-        if (h->ws_dec_sbr) (void)hipFree(h->ws_dec_sbr);
-        h->ws_dec_lines = nullptr;
-        h->ws_dec_sbr = nullptr;
-        h->ws_dec_cf = 0;
-        HIP_TRY(h, hipMalloc((void **)&h->ws_dec_lines, (size_t)n_cf * PACX_M_LONG * sizeof(double)));
-        HIP_TRY(h, hipMalloc((void **)&h->ws_dec_sbr, (size_t)n_cf));
-        h->ws_dec_cf = n_cf;
+    {
+        const int rc = reserve_dec_lines(h, n_cf);
+        if (rc != PACX_OK)
+            return rc;
     }
     double *ln = lines ? lines : h->ws_dec_lines;
     double *work = blocks;
     if (!work && pcm && n_cf > 0) {
-        if (n_cf > h->ws_blocks_cf) {
-            HIP_TRY(h, hipDeviceSynchronize());
-            if (h->ws_blocks)
-                (void)hipFree(h->ws_blocks);
-            h->ws_blocks = nullptr;
-            h->ws_blocks_cf = 0;
-            HIP_TRY(h, hipMalloc((void **)&h->ws_blocks, (size_t)n_cf * PACX_N_LONG * sizeof(double)));
-            h->ws_blocks_cf = n_cf;
-        }
+        const int rc = reserve_dec_blocks(h, n_cf);
+        if (rc != PACX_OK)
+            return rc;
         work = h->ws_blocks;
     }
     if (n_cf > 0) {

@@ -344,16 +344,29 @@ class Encoder:
                    _ptr(out["bit_alloc"]), _ptr(out["mantissa"]), _ptr(out["status"]), self._stream())
         return out
 
-    def decode(self, codes, n_channels, want_blocks=False, want_pcm=True):
+    def decode(self, codes, n_channels, want_blocks=False, want_pcm=True, extra=None, every_long_block=False):
         """codec.Decode + overlap-and-add + PCM for blocks in stream order.
-        codes: dict with flags (per cf), overall, scale_factor, bit_alloc, mantissa."""
+        codes: dict with flags (per cf), overall, scale_factor, bit_alloc, mantissa.
+        extra (a dict): route the blocks of an SBR file with scalar mantissas as PACFile.Decode does
+        (coder/pacfile.py:645-668: long blocks with a coded omitted band through Decode_SBR's scalar
+        branch; every_long_block: Decode_SBR on all of them); it receives "status"
+        (PACX_ST_VQ_UNDEFINED where Decode_SBR raises IndexError) and "lines" (dequantised,
+        reconstructed, before / 2^overall)."""
         n_cf = codes["bit_alloc"].shape[0]
         n_blocks = n_cf // n_channels
         blocks = self._empty((n_cf, 2 * N_LONG), torch.float64) if want_blocks else None
         pcm = self._empty(((n_blocks + 1) * N_LONG, n_channels), torch.int16) if want_pcm else None
-        self._call("pacx_decode_batch", ctypes.c_int64(n_blocks), int(n_channels), _ptr(codes["flags"]),
-                   _ptr(codes["overall"]), _ptr(codes["scale_factor"]), _ptr(codes["bit_alloc"]),
-                   _ptr(codes["mantissa"]), _ptr(blocks), _ptr(pcm), self._stream())
+        if extra is not None:
+            extra["status"] = self._empty((n_cf,), torch.int32)
+            extra["lines"] = self._empty((n_cf, N_LONG), torch.float64)
+            self._call("pacx_decode_sbr_batch", ctypes.c_int64(n_blocks), int(n_channels), _ptr(codes["flags"]),
+                       _ptr(codes["overall"]), _ptr(codes["scale_factor"]), _ptr(codes["bit_alloc"]),
+                       _ptr(codes["mantissa"]), int(bool(every_long_block)), _ptr(extra["lines"]), _ptr(blocks), _ptr(pcm),
+                       _ptr(extra["status"]), self._stream())
+        else:
+            self._call("pacx_decode_batch", ctypes.c_int64(n_blocks), int(n_channels), _ptr(codes["flags"]),
+                       _ptr(codes["overall"]), _ptr(codes["scale_factor"]), _ptr(codes["bit_alloc"]),
+                       _ptr(codes["mantissa"]), _ptr(blocks), _ptr(pcm), self._stream())
         return (blocks, pcm) if want_blocks and want_pcm else (blocks if want_blocks else pcm)
 
     def decode_vq(self, payload, n_bytes, n_channels, offsets=None, want_lines=False, want_blocks=False,

@@ -52,16 +52,22 @@ def _raise_like_reference(out):
         raise TypeError(_lib.REF_SCALAR_SBR_ERROR)
 
 
-def _refuse_coded_sbr_band(cp, codes):
-    """Scalar mantissas + SBR on the decode side: the reference's encoder cannot write a long block
-    that codes an omitted band (it raises there, see _raise_like_reference), so such a block does
-    not come from it and Decode_SBR's scalar branch (coder/codec.py:117-134) is not built; every
-    other block of such a file decodes through the plain path (coder/pacfile.py:659-668)."""
-    lo = int(omitted_bands(cp.sfBands)[0])
-    is_long = (codes["flags"] & 2) == 0
-    if bool((codes["bit_alloc"][is_long][:, lo:cp.sfBands.nBands] != 0).any().item()):
-        raise NotImplementedError("scalar-mantissa block with a coded SBR band: not something the "
-                                  "reference's encoder can write")
+_SBR_INDEX = ("index 1024 is out of bounds for axis 0 with size 1024 (Decode_SBR, coder/codec.py:173-176: the "
+              "cut lies in the lower half of the spectrum; PACX_ST_VQ_UNDEFINED)")
+
+
+def _decode_scalar(enc, cp, codes, **want):
+    """Scalar-mantissa blocks through PACFile.Decode's routing (coder/pacfile.py:645-668).  In an SBR file a
+    long block with a coded omitted band is Decode_SBR's (scalar branch, coder/codec.py:117-134) -- a block no
+    encoder of the reference writes (it raises there, _raise_like_reference) but its reader and decoder take;
+    where Decode_SBR raises IndexError (band tables of rates above 48 kHz) so does this."""
+    if not getattr(cp, "useSBR", False):
+        return enc.decode(codes, cp.nChannels, **want)
+    extra = {}
+    out = enc.decode(codes, cp.nChannels, extra=extra, **want)
+    if extra["status"].numel() and int(extra["status"].max().item()) & _ST_VQ_UNDEFINED:
+        raise IndexError(_SBR_INDEX)
+    return out
 
 
 class PACFile(AudioFile):
@@ -170,9 +176,7 @@ class PACFile(AudioFile):
             codes = enc.unpack(torch.as_tensor(buf, device=enc.device), sizes)
             if int(codes["status"].max().item()) & _ST_MALFORMED:
                 raise RuntimeError(_PARTIAL)
-            if getattr(cp, "useSBR", False):
-                _refuse_coded_sbr_band(cp, codes)
-            blocks = enc.decode(codes, cp.nChannels, want_blocks=True, want_pcm=False).cpu().numpy()
+            blocks = _decode_scalar(enc, cp, codes, want_blocks=True, want_pcm=False).cpu().numpy()
         data = []
         for ch in range(cp.nChannels):
             data.append(np.add(cp.overlapAndAdd[ch], blocks[ch][:cp.nMDCTLines]))
@@ -321,6 +325,4 @@ def decode_stream(data):
     codes = enc.unpack(body, sizes_t, offs_t)
     if len(sizes) and int(codes["status"].max().item()) & _ST_MALFORMED:
         raise RuntimeError(_PARTIAL)
-    if cp.useSBR and len(sizes):
-        _refuse_coded_sbr_band(cp, codes)
-    return enc.decode(codes, cp.nChannels).cpu().numpy()
+    return _decode_scalar(enc, cp, codes).cpu().numpy()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PACX_ABI_VERSION 4
+#define PACX_ABI_VERSION 5
 
 /* error codes */
 #define PACX_OK            0
@@ -487,6 +487,30 @@ int pacx_decode_batch(pacx_handle *h, int64_t n_blocks, int n_channels, const ui
                       const int32_t *overall_scale, const int32_t *scale_factor,
                       const int32_t *bit_alloc, const int32_t *mantissa, double *blocks,
                       int16_t *pcm, void *stream);
+
+/*
+ * The scalar-mantissa blocks of an SBR file (handle created with use_sbr and without use_vq).
+ * pacx_decode_batch is codec.Decode for every block, whatever the handle.  This entry routes:
+ *   every_long_block == 0: as PACFile.Decode does (coder/pacfile.py:645-668) -- a long block with
+ *           bits in an omitted band is codec.Decode_SBR's, every other block codec.Decode's;
+ *   every_long_block != 0: codec.Decode_SBR on every long block (the function itself).
+ * Decode_SBR's scalar branch (coder/codec.py:95-222 with useVQ off, :117-134): one line per omitted
+ * band, dequantised from the mantissa at THAT line of the line-indexed array -- pacx_unpack_batch
+ * leaves a coded omitted band's single mantissa (coder/pacfile.py:203-205) on every line of the
+ * band, as the reader does -- then the reconstruction of :136-198.  Optional outputs:
+ *   lines:  float64 [n_cf][n_lines_long], the dequantised lines after the reconstruction and
+ *           BEFORE the division by 2^overallScale (short frames: 8 x n_lines_short);
+ *   status: uint32 [n_cf], PACX_ST_VQ_UNDEFINED where Decode_SBR raises IndexError (the cut lies
+ *           in the lower half of the spectrum: band tables of rates above 48 kHz); that block
+ *           decodes from its lines as they stood before the reconstruction.
+ * No encoder of the reference writes a scalar block with a coded omitted band (it raises there:
+ * PACX_ST_REF_RAISES); its reader and decoder take one, so this one does.  On a handle without
+ * use_sbr this is pacx_decode_batch with the lines as an extra output.
+ */
+int pacx_decode_sbr_batch(pacx_handle *h, int64_t n_blocks, int n_channels, const uint8_t *cf_flags,
+                          const int32_t *overall_scale, const int32_t *scale_factor,
+                          const int32_t *bit_alloc, const int32_t *mantissa, int every_long_block,
+                          double *lines, double *blocks, int16_t *pcm, uint32_t *status, void *stream);
 
 /*
  * Decode of gain-shape coded channel-blocks (handle created with use_vq), from

@@ -467,3 +467,100 @@ def test_encoder_pool_two_batches_in_flight(A):
     for (nb, pay), (nb_w, pay_w) in zip(got, want):
         assert np.array_equal(nb, nb_w)
         assert all(np.array_equal(pay[i, :nb[i]], pay_w[i, :nb[i]]) for i in range(len(nb)))
+
+
+# ------------------------------------------------------------------ Decode_SBR, scalar branch (VERDICT r2 missing #7)
+SBRD = np.load(os.path.join(GOLDEN, "sbr_scalar_decode.npz"))
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in SBRD["stream_cases"]])
+def test_scalar_sbr_streams_with_coded_omitted_bands_decode_to_the_references_pcm(A, tag):
+    """streams whose long blocks code their omitted bands (one mantissa each, coder/pacfile.py:203-205) through
+    pacfile.decode_stream: the PCM the REFERENCE's own reader + Decode_SBR (coder/codec.py:117-134, useVQ off) made
+    of the same bytes (tests/golden/make_golden.py --sbr-scalar-decode)"""
+    pac = bytes(SBRD[f"pac_{tag}"])
+    pcm = A.pacfile.decode_stream(pac)
+    want = SBRD[f"pcm_{tag}"]
+    assert pcm.shape == want.shape
+    assert np.array_equal(pcm, want), int(np.abs(pcm.astype(int) - want.astype(int)).max())
+
+
+@pytest.mark.parametrize("sr", [48000, 44100, 32000])
+def test_decode_sbr_mirror_scalar_branch(A, sr):
+    """codec.Decode_SBR with useVQ off on random code sets, against the reference's own outputs; allocation row 0
+    has no coded omitted band (PACFile.Decode would send it to codec.Decode; the function takes it all the same)"""
+    cp = A.audiofile.CodingParams()
+    cp.sampleRate, cp.nChannels, cp.nMDCTLines, cp.nSamplesPerBlock = sr, 1, 1024, 1024
+    cp.nScaleBits, cp.nMantSizeBits, cp.targetBitsPerSample = 4, 12, 96 / (sr / 1000)
+    cp.useSBR, cp.useVQ = True, False
+    cp.sfBands = A.psychoac.ScaleFactorBands(A.psychoac.AssignMDCTLinesFromFreqLimits(1024, sr))
+    cp.sfBandsShort = A.psychoac.ScaleFactorBands(A.psychoac.AssignMDCTLinesFromFreqLimits(128, sr))
+    cp.omittedBands = A.pacfile.omitted_bands(cp.sfBands)
+    want = SBRD[f"fn_{sr}_block"]
+    worst = 0.0
+    for k in range(len(want)):
+        fl = SBRD[f"fn_{sr}_flags"][k]
+        got = A.codec.Decode_SBR(SBRD[f"fn_{sr}_sf"][k], SBRD[f"fn_{sr}_ba"][k], SBRD[f"fn_{sr}_mant"][k],
+                                 int(SBRD[f"fn_{sr}_overall"][k]), None, cp, bool(fl[0]), False, bool(fl[1]))
+        scale = max(float(np.abs(want[k]).max()), 1e-300)
+        worst = max(worst, float(np.abs(got - want[k]).max()) / scale)
+    assert worst <= 1e-12, worst                      # the IMDCT's tolerance (DESIGN section 2), relative to the block's peak
+
+
+def test_scalar_sbr_decode_routing_and_refusal(A):
+    """pacx_decode_batch stays codec.Decode on an SBR handle; PACFile.Decode's routing picks Decode_SBR only for
+    long blocks with a coded omitted band (lines compared with the oracle's); at 96 kHz Decode_SBR raises
+    IndexError (the cut lies in the lower half) and so do the mirrors"""
+    import torch
+    from oracle import pac_oracle as po, pac_oracle_vq as pv
+    tag = "harpsichord_96_long"
+    pac = bytes(SBRD[f"pac_{tag}"])
+    cp, pos = A.pacfile.parse_header(pac)
+    enc = A.context.encoder_for_params(cp)
+    offs, sizes = A.pacfile.record_chain(pac, pos, enc.payload_stride)
+    body = torch.frombuffer(bytearray(pac) + bytearray(8), dtype=torch.uint8).to(enc.device)
+    codes = enc.unpack(body, torch.tensor(sizes, dtype=torch.int32, device=enc.device),
+                       torch.tensor(offs, dtype=torch.int64, device=enc.device))
+    plain = enc.decode(codes, cp.nChannels, want_blocks=True, want_pcm=False).cpu().numpy()
+    extra = {}
+    routed = enc.decode(codes, cp.nChannels, want_blocks=True, want_pcm=False, extra=extra).cpu().numpy()
+    p, _, _ = po.parse_header(pac)
+    ba = codes["bit_alloc"].cpu().numpy()
+    lines = extra["lines"].cpu().numpy()
+    n_sbr = 0
+    for i in range(len(sizes)):
+        br = po.BitReader(pac[offs[i]:offs[i] + sizes[i]])
+        fl = (br.get(1), br.get(1), br.get(1))
+        sf, alloc, mant, ov = po.parse_block_body(br, p, False)
+        assert list(ba[i, :len(alloc)]) == list(alloc)
+        coded = any(alloc[b] for b in p.omittedBands)
+        want_plain = po.decode_block(p, sf, alloc, mant, ov, *fl)
+        assert np.abs(plain[i] - want_plain).max() <= 1e-12 * max(np.abs(want_plain).max(), 1e-300)
+        want = po.decode_any_block(p, sf, alloc, mant, ov, *fl)
+        assert np.abs(routed[i] - want).max() <= 1e-12 * max(np.abs(want).max(), 1e-300), i
+        if coded:
+            n_sbr += 1
+            ln = np.zeros(1024)
+            at = 0
+            for b in range(p.sfBands.nBands):
+                n = 1 if b in p.omittedBands else p.sfBands.nLines[b]
+                if alloc[b]:
+                    ln[at:at + n] = po.dequantize_vec(sf[b], mant[at:at + n], p.nScaleBits, alloc[b])
+                at += n
+            ln = pv.sbr_reconstruct(ln, p)
+            assert np.abs(lines[i] - ln).max() <= 1e-12 * max(np.abs(ln).max(), 1e-300), i
+        else:
+            assert np.array_equal(routed[i], plain[i])
+    assert n_sbr >= 8
+    assert int(extra["status"].max().item()) == 0
+    # 96 kHz: the band table stops at 24 kHz, the cut lies in the lower half
+    cp96 = A.audiofile.CodingParams()
+    cp96.sampleRate, cp96.nChannels, cp96.nMDCTLines, cp96.nSamplesPerBlock = 96000, 1, 1024, 1024
+    cp96.nScaleBits, cp96.nMantSizeBits, cp96.targetBitsPerSample = 4, 12, 1.0
+    cp96.useSBR, cp96.useVQ = True, False
+    cp96.sfBands = A.psychoac.ScaleFactorBands(A.psychoac.AssignMDCTLinesFromFreqLimits(1024, 96000))
+    cp96.sfBandsShort = A.psychoac.ScaleFactorBands(A.psychoac.AssignMDCTLinesFromFreqLimits(128, 96000))
+    cp96.omittedBands = A.pacfile.omitted_bands(cp96.sfBands)
+    nb = cp96.sfBands.nBands
+    with pytest.raises(IndexError):
+        A.codec.Decode_SBR(np.zeros(nb, np.int32), np.full(nb, 4, np.int32), np.ones(1024, np.int32), 0, None, cp96)
