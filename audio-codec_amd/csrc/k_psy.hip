@@ -654,8 +654,14 @@ __global__ __launch_bounds__(64) void k_side_short(PacxTables T, PacxPcmView in,
 #define MASK_LDS_TABLES 1          /* bit 0: Bark table in LDS, bit 1: threshold-in-quiet in LDS (its 8 KB
                                       now hold the maskers of the batch, see mk[]) */
 #endif
+#ifndef MASK_OCC_PLAIN
+#define MASK_OCC_PLAIN 4           /* k_mask<1024, false>: 33 KB of LDS and <= 128 registers, four workgroups per CU */
+#endif
 #ifndef MASK_WG_PER_CU
-#define MASK_WG_PER_CU 3
+#define MASK_WG_PER_CU 3           /* with the fused tail (140 registers) */
+#endif
+#ifndef MASK_WG_PER_CU_PLAIN
+#define MASK_WG_PER_CU_PLAIN 4
 #endif
 
 
@@ -682,8 +688,13 @@ __device__ __forceinline__ double mask_value_of(unsigned long long k)
     return __longlong_as_double((long long)u);
 }
 
+#ifndef MASK_WAVES_PLAIN
+#define MASK_WAVES_PLAIN 4         /* k_mask<1024, false>: waves per workgroup (five: 4 x 39 KB leave the co-running kernels no LDS, measured slower) */
+#endif
+constexpr int mask_waves(int m, bool tail) { return (m == PACX_M_LONG && !tail) ? MASK_WAVES_PLAIN : MASK_WAVES; }
+
 template <int M, bool TAIL>
-__global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T, const uint8_t *__restrict__ flags,
+__global__ __launch_bounds__(64 * mask_waves(M, TAIL), (M == PACX_M_LONG && !TAIL) ? MASK_OCC_PLAIN : MASK_OCC) void k_mask(PacxTables T, const uint8_t *__restrict__ flags,
                                                          int n_ch, long long n_units, int mixed,
                                                          const PacxPeak *__restrict__ peaks,
                                                          const int32_t *__restrict__ n_peaks,
@@ -695,30 +706,38 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                                                          MaskTail tail)
 {
     constexpr bool SHORT = (M == PACX_M_SHORT);
+    constexpr int NW = mask_waves(M, TAIL);                                /* waves per workgroup */
     static_assert(!(TAIL && SHORT), "the fused tail is for long blocks");
     constexpr int PER = M / 64;
     constexpr bool BARK_LDS = (MASK_LDS_TABLES & 1) != 0, QUIET_LDS = (MASK_LDS_TABLES & 2) != 0;
     __shared__ __attribute__((aligned(16))) double bark_l[BARK_LDS ? M : 1];
     __shared__ __attribute__((aligned(16))) double quiet_l[QUIET_LDS ? M : 1];
     __shared__ __attribute__((aligned(16))) double chunk_c[PER][4];        /* zlo-0.5, zhi+0.5, qmin-0.01 */
-    /* per-line state of each wave: running best, then mdct_spl - thr.  Long blocks pad one
-       double per 16 lines (line k at k + k/16), so that both access patterns are conflict-free:
-       lane + 64 j in the masker and per-line loops, 16 consecutive lines per lane in the band
-       reduction */
+    /* per-line state of each wave: running best, then mdct_spl - thr.  Long blocks keep the running best of
+       their first RJ chunks (lines 0..511) in REGISTERS through the masker loop and only the other half in LDS:
+       the per-line phase and the band maxima then run half by half through the same 4.6 KB (the LDS-resident
+       half first, then the register half is written out), which is what lets a fourth workgroup share the CU
+       -- this kernel is bound by its latency chains at the occupancy its LDS allows, the
+       registers were idle (84 of 168).  A half pads one double per 8 lines (line kk of the half at kk + kk/8),
+       so that both access patterns are conflict-free: lane + 64 j in the masker and per-line loops, 8
+       consecutive lines per lane in the band reduction */
     constexpr bool PAD = M / 64 == 16;
-    constexpr int JSTR = PAD ? 68 : 64;                                    /* stride of j in the strided view */
-    __shared__ __attribute__((aligned(16))) double bufs[MASK_WAVES][M + (PAD ? M / 16 : 0)];
+    constexpr int RJ = PAD ? PER / 2 : 0;                                  /* chunks whose running best lives in registers */
+    constexpr int NH = PAD ? 2 : 1, HP = PER / NH;                         /* halves, lines per lane and half */
+    constexpr int MH = M / NH;                                             /* lines per half */
+    constexpr int JSTR = PAD ? 72 : 64;                                    /* stride of j in the strided view */
+    __shared__ __attribute__((aligned(16))) double bufs[NW][MH + (PAD ? MH / 8 : 0)];
     /* the 64 maskers of the current batch, (z, spl, slope, -) each: a surviving masker is
        fetched by all lanes with two broadcast LDS reads -- the LDS pipe idles in this
        kernel, the VALU is its bound, and six v_readlane + two v_mov per survivor were
        40 % of the evaluation loop's VALU instructions */
     /* (z, spl) pairs and slopes apart: 24 bytes per masker, every read aligned */
-    __shared__ __attribute__((aligned(16))) double2 mk_zs_all[MASK_WAVES][64];
-    __shared__ __attribute__((aligned(16))) double mk_u_all[MASK_WAVES][64];
+    __shared__ __attribute__((aligned(16))) double2 mk_zs_all[NW][64];
+    __shared__ __attribute__((aligned(16))) double mk_u_all[NW][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *__restrict__ bark_g = SHORT ? T.bark_short : T.bark_long;
     const double *__restrict__ quiet_g = SHORT ? T.thresh_short : T.thresh_long;
-    for (int i = tid; i < M; i += 64 * MASK_WAVES) {
+    for (int i = tid; i < M; i += 64 * NW) {
         if (BARK_LDS)
             bark_l[i] = bark_g[i];
         if (QUIET_LDS)
@@ -727,7 +746,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     __syncthreads();
     const double *bark_s = BARK_LDS ? (const double *)bark_l : bark_g;
     const double *quiet_s = QUIET_LDS ? (const double *)quiet_l : quiet_g;
-    for (int j = wv; j < PER; j += MASK_WAVES) {
+    for (int j = wv; j < PER; j += NW) {
         double qm = quiet_s[64 * j + lane];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
@@ -741,7 +760,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     __syncthreads();
 
     double *buf = bufs[wv];
-    const int sl = lane + (PAD ? lane >> 4 : 0);       /* line lane + 64 j lives at buf[sl + JSTR * j] */
+    const int sl = lane + (PAD ? lane >> 3 : 0);       /* line lane + 64 j of a half lives at buf[sl + JSTR * j] */
     double2 *mk_zs = mk_zs_all[wv];
     double *mk_u = mk_u_all[wv];
     const int nb = SHORT ? T.nb_short : T.nb_long;
@@ -758,8 +777,8 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
     PSY_T(7);
     dbg_acc[7] = 0;
 #endif
-    for (long long unit = (long long)blockIdx.x * MASK_WAVES + wv; unit < n_units;
-         unit += (long long)gridDim.x * MASK_WAVES) {
+    for (long long unit = (long long)blockIdx.x * NW + wv; unit < n_units;
+         unit += (long long)gridDim.x * NW) {
         long long cf = SHORT ? unit / PACX_SUB : unit;
         const int sb = SHORT ? (int)(unit % PACX_SUB) : 0;
         if (cf_list) {
@@ -778,9 +797,14 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
            read from the LDS table when its chunk is live: neither array occupies
            registers, which is what lets three waves share a SIMD.  Masker batches
            are software-pipelined one ahead, so no loop iteration waits on HBM */
+        double rb[RJ ? RJ : 1];
 #pragma unroll
-        for (int j = 0; j < PER; ++j)
-            buf[sl + JSTR * j] = -INFINITY;
+        for (int j = 0; j < PER; ++j) {
+            if (j < RJ)
+                rb[j] = -INFINITY;
+            else
+                buf[sl + JSTR * (j - RJ)] = -INFINITY;
+        }
         PacxPeak qn;
         qn.z = 0.0; qn.spl = -1000.0; qn.slope = 0.0;             /* padding lanes never survive */
         if (lane < np)
@@ -839,7 +863,11 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 if (!todo)
                     continue;
                 const double zj = bark_s[lane + 64 * j];
-                double bj = buf[sl + JSTR * j];
+                double bj;
+                if (j < RJ)
+                    bj = rb[j];
+                else
+                    bj = buf[sl + JSTR * (j - RJ)];
                 /* survivors four at a time: their broadcast reads are issued together and
                    waited for once (the read latency, not the arithmetic, was what a survivor
                    cost); a short last group repeats its last masker -- max is idempotent */
@@ -875,56 +903,64 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                         asm("v_max_f64 %0, %1, %2" : "=v"(bj) : "v"(bj), "v"(cand));
                     }
                 }
-                buf[sl + JSTR * j] = bj;
+                if (j < RJ)
+                    rb[j] = bj;
+                else
+                    buf[sl + JSTR * (j - RJ)] = bj;
             }
         }
         wave_lds_fence();
         PSY_T(1);
-        /* per line: round trip of the winner, max with quiet, SMR term; the MDCT
-           line is fetched one iteration ahead */
-        double v_next = lines[loff + lane], q_next = quiet_s[lane];
-#pragma unroll 1
-        for (int j = 0; j < PER; ++j) {
-            const int k = lane + 64 * j;
-            const double v = v_next;
-            double thr = q_next;                           /* threshold in quiet, also one ahead */
-            if (j + 1 < PER) {
-                v_next = lines[loff + k + 64];
-                q_next = quiet_s[k + 64];
-            }
-            const double bst = buf[sl + JSTR * j];
-            if (bst > -INFINITY)
-                thr = fmax(thr, mask_round_trip(bst));
-            if (thr_out)
-                thr_out[loff + k] = thr;
-            /* pacx_spl_array((v * v) * 4.0), coder/psychoac.py:10-25, with the lean log10 of
-               pacx_exact.h (the argument is positive and normal) */
-            double it = (v * v) * 4.0;
-            if (it == 0.0)
-                it = 1e-8;
-            double spl = 96.0 + 10.0 * pacx_log10_pos(it + PACX_EPS);
-            if (spl < -30.0)
-                spl = -30.0;
-            buf[sl + JSTR * j] = spl - thr;
-        }
-        wave_lds_fence();
-        PSY_T(2);
+        /* per line: round trip of the winner, max with quiet, SMR term; the MDCT line is fetched one iteration
+           ahead.  Then the band maxima: each lane takes the HP CONSECUTIVE lines it owns in the band layout
+           (bands are runs of lines), folds each run of one band in registers and posts it with one 64-bit LDS
+           atomic max on an order-preserving key of the double; lanes < nb read the results back.  Independent
+           LDS reads and two or three atomics per lane, instead of a dependent read per band and a 31-exchange
+           transposing reduction.  max is exact, so the SMRs are the same bits whatever the order.  Long blocks:
+           half by half, the LDS-resident upper half first */
         double *__restrict__ out = smr ? smr + cf * T.band_stride + sb * T.nb_short : nullptr;
-        /* band maxima.  Each lane takes the M/64 CONSECUTIVE lines it owns in the band layout
-           (bands are runs of lines), folds each run of one band in registers and posts it with one
-           64-bit LDS atomic max on an order-preserving key of the double; lanes < nb read the
-           results back.  Sixteen independent LDS reads and two or three atomics per lane, instead
-           of a dependent read per band and a 31-exchange transposing reduction.  max is exact, so
-           the SMRs are the same bits whatever the order */
-        double s_l;
-        {
-            constexpr int PERL = M / 64;
-            unsigned long long *key = (unsigned long long *)mk_zs;      /* the masker table is dead */
-            key[lane] = 0ull;                              /* below the key of every double */
+        unsigned long long *key = (unsigned long long *)mk_zs;      /* the masker table is dead */
+        key[lane] = 0ull;                                  /* below the key of every double */
+#pragma unroll 1
+        for (int h = NH - 1; h >= 0; --h) {
+            if (RJ && h == 0) {
+                wave_lds_fence();                          /* the upper half's maxima are taken */
+#pragma unroll
+                for (int j = 0; j < RJ; ++j)
+                    buf[sl + JSTR * j] = rb[j];
+                wave_lds_fence();
+            }
+            const int k0 = h * MH;
+            double v_next = lines[loff + k0 + lane], q_next = quiet_s[k0 + lane];
+#pragma unroll 1
+            for (int j = 0; j < HP; ++j) {
+                const int k = k0 + lane + 64 * j;
+                const double v = v_next;
+                double thr = q_next;                       /* threshold in quiet, also one ahead */
+                if (j + 1 < HP) {
+                    v_next = lines[loff + k + 64];
+                    q_next = quiet_s[k + 64];
+                }
+                const double bst = buf[sl + JSTR * j];
+                if (bst > -INFINITY)
+                    thr = fmax(thr, mask_round_trip(bst));
+                if (thr_out)
+                    thr_out[loff + k] = thr;
+                /* pacx_spl_array((v * v) * 4.0), coder/psychoac.py:10-25, with the lean log10 of
+                   pacx_exact.h (the argument is positive and normal) */
+                double it = (v * v) * 4.0;
+                if (it == 0.0)
+                    it = 1e-8;
+                double spl = 96.0 + 10.0 * pacx_log10_pos(it + PACX_EPS);
+                if (spl < -30.0)
+                    spl = -30.0;
+                buf[sl + JSTR * j] = spl - thr;
+            }
+            wave_lds_fence();
             int rl = lane;                                 /* opaque: the band ids are not to be hoisted */
             asm volatile("" : "+v"(rl));
-            double v[PERL];
-            uint8_t bd[PERL];
+            double v[HP];
+            uint8_t bd[HP];
             if constexpr (SHORT) {
                 const double2 t = *(const double2 *)(buf + 2 * rl);
                 v[0] = t.x;
@@ -933,11 +969,12 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 bd[0] = b2.x;
                 bd[1] = b2.y;
             } else {
-                const uint4 b16 = *(const uint4 *)(T.line_band_long + 16 * rl);
-                const unsigned w[4] = {b16.x, b16.y, b16.z, b16.w};
+                static_assert(SHORT || HP == 8, "eight lines per lane and half");
+                const uint2 b8 = *(const uint2 *)(T.line_band_long + k0 + 8 * rl);
+                const unsigned w[2] = {b8.x, b8.y};
 #pragma unroll
-                for (int j = 0; j < PERL; ++j) {
-                    v[j] = buf[17 * rl + j];
+                for (int j = 0; j < HP; ++j) {
+                    v[j] = buf[9 * rl + j];
                     bd[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
                 }
             }
@@ -945,7 +982,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
             int cur = bd[0];
             double mx = v[0];
 #pragma unroll
-            for (int j = 1; j < PERL; ++j) {
+            for (int j = 1; j < HP; ++j) {
                 if (bd[j] != cur) {
                     atomicMax(&key[cur], mask_key_of(mx));
                     cur = bd[j];
@@ -955,11 +992,12 @@ __global__ __launch_bounds__(64 * MASK_WAVES, MASK_OCC) void k_mask(PacxTables T
                 }
             }
             atomicMax(&key[cur], mask_key_of(mx));
-            wave_lds_fence();
-            s_l = mask_value_of(key[lane & 31]);
-            if (out && lane < nb)
-                out[lane] = s_l;
         }
+        wave_lds_fence();
+        PSY_T(2);
+        const double s_l = mask_value_of(key[lane & 31]);
+        if (out && lane < nb)
+            out[lane] = s_l;
         {
             if constexpr (TAIL) {
                 wave_lds_fence();                         /* the band maxima are taken: buf is free */
@@ -1147,15 +1185,17 @@ void pacx_launch_mask(const PacxTables &T, const uint8_t *flags, int n_ch, long 
     /* persistent grids: MASK_WAVES x 8 KB of running maxima + the LDS tables per workgroup,
        MASK_WG_PER_CU workgroups per CU for the long kernel */
     if ((!short_blocks || mixed) && part != 2) {
-        long long blocks = (n_cf + MASK_WAVES - 1) / MASK_WAVES;
-        if (blocks > (long long)MASK_WG_PER_CU * n_cu)
-            blocks = (long long)MASK_WG_PER_CU * n_cu;
+        const int nw = tail ? MASK_WAVES : MASK_WAVES_PLAIN;
+        long long blocks = (n_cf + nw - 1) / nw;
+        const long long per_cu = tail ? MASK_WG_PER_CU : MASK_WG_PER_CU_PLAIN;
+        if (blocks > per_cu * n_cu)
+            blocks = per_cu * n_cu;
         if (tail)           /* BitAlloc (+ quantisation and packing) of the long frames in the same wave */
             hipLaunchKernelGGL((k_mask<PACX_M_LONG, true>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T,
                                flags, n_ch, n_cf, mixed, peaks, n_peaks, lines, (double *)nullptr, thr_out,
                                mixed ? list_long : nullptr, counts, *tail);
         else
-            hipLaunchKernelGGL((k_mask<PACX_M_LONG, false>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES), 0, st, T,
+            hipLaunchKernelGGL((k_mask<PACX_M_LONG, false>), dim3((unsigned)blocks), dim3(64 * MASK_WAVES_PLAIN), 0, st, T,
                                flags, n_ch, n_cf, mixed, peaks, n_peaks, lines, smr, thr_out,
                                mixed ? list_long : nullptr, counts, MaskTail{});
     }

@@ -978,10 +978,16 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
                          mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, list_short, counts + 1, 0, st);
         return post_launch(h, what);
     }
-    /* fork: the side chain only reads the PCM, so it runs on its own stream next to the MDCT */
-    if (!split)
+    /* fork: the side chain only reads the PCM, so it runs on its own stream next to the MDCT.
+       PACX_ONE_STREAM=1: no fork, the whole step on the caller's stream (a caller who keeps several
+       steps in flight on several streams already has the overlap; fewer streams, fewer hardware queues) */
+    const char *one_env = getenv("PACX_ONE_STREAM");
+    const bool one_stream = !split && one_env && atoi(one_env) != 0;
+    hipStream_t side_st = one_stream ? st : h->side_stream;
+    if (!split && !one_stream)
         HIP_TRY_FORKED(h, hipEventRecord(h->ev_fork, st));
-    HIP_TRY_FORKED(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+    if (!one_stream)
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
     if (split) {
         /* A block-switched batch is two independent chains that touch disjoint frames:
              long-coded :  k_mdct_long_v2 || k_side_long  ->  k_mask<1024> (+ tail)
@@ -1021,8 +1027,9 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         return post_launch_forked(h, what);
     }
     pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, h->ws_peaks, h->ws_npeaks, h->ws_nkept,
-                     nullptr, nullptr, h->side_stream);
-    HIP_TRY_FORKED(h, hipEventRecord(h->ev_join, h->side_stream));
+                     nullptr, nullptr, side_st);
+    if (!one_stream)
+        HIP_TRY_FORKED(h, hipEventRecord(h->ev_join, h->side_stream));
     if (fast) {
         /* long frames: persistent roofline kernel; short (CUR) frames: k_mdct_short */
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status,
@@ -1034,7 +1041,8 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed, 0, h->ws_lines, overall_scale,
                          PACX_SUB, status, st);
     }
-    HIP_TRY_FORKED(h, hipStreamWaitEvent(st, h->ev_join, 0));       /* join */
+    if (!one_stream)
+        HIP_TRY_FORKED(h, hipStreamWaitEvent(st, h->ev_join, 0));       /* join */
     pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed, h->ws_peaks, h->ws_nkept, h->ws_lines, h->ws_smr,
                      nullptr, h->n_cu, list_long, list_short, counts, fuse ? &mt : nullptr, st);
     /* what is left: the long frames when not fused, the short-coded frames of a mixed batch */
