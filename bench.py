@@ -458,6 +458,7 @@ def main():
                 pp["graph"] = None
         torch.cuda.synchronize()
     graphs = [pp["graph"] for pp in pipes]
+    dump_regions = os.environ.get("PACX_BENCH_DUMP_REGIONS")      # every region's ms/step, one per line (tools/bench_regions.py)
 
     def step():
         q = step_no[0] % in_flight[0]
@@ -511,6 +512,9 @@ def main():
             if float(flag.item()) == 0.0:
                 break
     dt = float(np.median(regions))
+    if dump_regions and rank == 0:
+        with open(dump_regions, "w") as f:
+            f.write("\n".join(f"{r / args.steps * 1e3:.5f}" for r in regions) + "\n")
     regions_one = None
     if P > 1 and not multi:                # the same K steps with one step in flight at a time (round 2's figure)
         in_flight[0] = 1
@@ -693,6 +697,10 @@ def main():
                        "ms_per_step_regions": [r / args.steps * 1e3 for r in (regions if len(regions) <= 24 else
                                                                                 regions[:8] + regions[-16:])],
                        "ms_per_step_regions_note": "all regions" if len(regions) <= 24 else "the first 8 and the last 16 regions",
+                       # two steps in flight settle, region by region, into one of two phase relations of the pipelines
+                       # (DESIGN.md 5.0): the spread says how the regions of THIS run fell
+                       "ms_per_step_quantiles": {q: sorted(regions)[min(len(regions) - 1, int(len(regions) * f))] / args.steps * 1e3
+                                                 for q, f in (("p10", 0.10), ("p25", 0.25), ("p50", 0.50), ("p75", 0.75), ("p90", 0.90))},
                        "body_bytes_per_step": body_bytes,
                        "verified": f"{verified} channel-frames of the timed run's output re-encoded by the oracle, "
                                    "payload bytes equal" + (f" (per rank: {verified_per_rank})" if multi else "")
