@@ -64,6 +64,12 @@ def test_scalar_coder_path_switches(A, monkeypatch):
             assert A.pacfile.encode_stream(pcm, sr, 128, block_switching=bs) == want, (bs, fuse, split)
             n += 1
         assert n == 6
+        _set(monkeypatch, {})
+        for fuse in (None, "1"):                    # the whole step on the caller's stream (no fork to the side stream)
+            _set(monkeypatch, {"PACX_FUSE_TAIL": fuse})
+            monkeypatch.setenv("PACX_ONE_STREAM", "1")
+            assert A.pacfile.encode_stream(pcm, sr, 128, block_switching=bs) == want, (bs, fuse, "one stream")
+            monkeypatch.delenv("PACX_ONE_STREAM")
     _set(monkeypatch, {})
 
 
