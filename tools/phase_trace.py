@@ -48,3 +48,23 @@ out.sort()
 print("us/step  mean phase of B in A's period  mean mask duration us  share of A's mask time overlapped by a B mask")
 for o in out[:: max(len(out) // 30, 1)]:
     print("%7.1f  %5.2f  %6.1f  %5.2f" % o)
+
+# windows of 24 consecutive mask kernels that hold both pipelines: the fastest and the slowest, every kernel with its queue
+def timeline(w, label):
+    t0, t1 = w[8][0], w[12][0]
+    print("--- %s: kernels starting in four steps from the middle of the window (offset us, duration us, stream, queue, name)" % label)
+    for x in k:
+        if t0 - 5_000 <= x[0] < t1 + 5_000:
+            print("  %8.1f %7.1f  s%-3s q%-3s %s" % ((x[0] - t0) / 1e3, (x[1] - x[0]) / 1e3, x[4], x[3], x[2][:36]))
+
+
+wins = []
+for i in range(0, len(masks) - 24, 6):
+    w = masks[i:i + 24]
+    if len({m[4] for m in w}) == 2 and max(b[0] - a[0] for a, b in zip(w[:-1], w[1:])) < 400_000:
+        wins.append(((w[-1][0] - w[0][0]) / 23.0, i))
+wins.sort()
+if wins:
+    print("windows: %d, us/step fastest %.1f median %.1f slowest %.1f" % (len(wins), wins[0][0] / 1e3, wins[len(wins) // 2][0] / 1e3, wins[-1][0] / 1e3))
+    timeline(masks[wins[0][1]:wins[0][1] + 24], "fastest window (%.1f us/step)" % (wins[0][0] / 1e3))
+    timeline(masks[wins[-1][1]:wins[-1][1] + 24], "slowest window (%.1f us/step)" % (wins[-1][0] / 1e3))
