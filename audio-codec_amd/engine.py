@@ -517,6 +517,7 @@ class EncoderPool:
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.encs]
         self.done = [torch.cuda.Event() for _ in self.encs]
         self._turn = 0
+        self._gate = self._gate_stream = None
 
     def __len__(self):
         return len(self.encs)
@@ -539,6 +540,37 @@ class EncoderPool:
                 pool.done[k].record(pool.streams[k])
                 return self_inner.ctx.__exit__(*exc)
         return _Slot()
+
+    def align(self, delay_us=None):
+        """Start the next calls of all slots at the same instant.  From an idle device the slots' first steps start as
+        far apart as the host takes to queue one (tens of microseconds), and two free-running pipelines then settle
+        into one of two stable relations -- in phase (like kernels side by side: 51.4 M cf/s on the headline batch)
+        or in anti-phase (47.0 M), DESIGN.md 5.0.  A gate event behind a short spin on a third stream holds every
+        slot's stream until all the first calls are queued; started together they stay in phase.  Costs delay_us
+        (default PACX_POOL_GATE_US or 100) once per call of this method."""
+        if len(self.encs) < 2:
+            return
+        if delay_us is None:
+            delay_us = float(os.environ.get("PACX_POOL_GATE_US", "100"))
+        if delay_us <= 0:
+            return
+        dev = self.encs[0].device
+        if self._gate is None:
+            self._gate_stream = torch.cuda.Stream(device=dev)
+            self._gate = torch.cuda.Event()
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(self._gate_stream):          # calibrate the spin: cycles per microsecond
+                torch.cuda._sleep(100_000)
+                t0.record()
+                torch.cuda._sleep(2_000_000)
+                t1.record()
+            t1.synchronize()
+            self._cycles_per_us = 2_000_000 / max(t0.elapsed_time(t1) * 1e3, 1.0)
+        with torch.cuda.stream(self._gate_stream):
+            torch.cuda._sleep(int(delay_us * self._cycles_per_us))
+            self._gate.record(self._gate_stream)
+        for s in self.streams:
+            s.wait_event(self._gate)
 
     def wait(self, k, stream=None):
         """make `stream` (default: the current one) wait for what was last queued in slot k"""

@@ -269,6 +269,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=10, help="timed K-step regions (at least); value = median")
+    ap.add_argument("--gate-us", type=float, default=None,
+                    help="two steps in flight: hold both pipelines' streams for this long at the start of every timed region "
+                         "(INSIDE it) so that their first steps start together and the pipelines stay in phase "
+                         "(engine.EncoderPool.align; DESIGN.md 5.0); 0 = off; default: 20 for all-long scalar batches "
+                         "(the only workload with two timing modes), 0 otherwise")
     ap.add_argument("--min-seconds", type=float, default=1.5,
                     help="keep timing K-step regions until this much wall time has gone into them (and --repeats regions "
                          "are done): the median then describes the card under sustained load, clocks settled")
@@ -351,6 +356,8 @@ def main():
                "shipped96": 96}[args.workload]
     kbps = vq_kbps or KBPS
     block_switched = args.workload in ("bs128", "shipped128", "shipped96")
+    if args.gate_us is None:
+        args.gate_us = float(os.environ.get("PACX_POOL_GATE_US", "0" if (block_switched or vq_kbps) else "20"))
     sample_rate = SAMPLE_RATE
     corpus = args.corpus
     if corpus:
@@ -490,6 +497,8 @@ def main():
     def timed_region():
         sync_all()
         t0 = time.perf_counter()
+        if in_flight[0] > 1 and args.gate_us > 0:
+            pool.align(args.gate_us)                # inside the timed region: both pipelines' first steps start together
         for _ in range(args.steps):
             step()
         sync_all()
@@ -696,6 +705,11 @@ def main():
                        "regions": len(regions),
                        "ms_per_step_regions": [r / args.steps * 1e3 for r in (regions if len(regions) <= 24 else
                                                                                 regions[:8] + regions[-16:])],
+                       "start_gate_us": args.gate_us if P > 1 else 0.0,
+                       "start_gate_note": "inside every timed region: both pipelines' streams wait this long on a gate event so "
+                                          "that their first steps start together (EncoderPool.align): started together the two "
+                                          "pipelines stay in phase, free-running they settle per region into one of two relations "
+                                          "(47.0 or 51.4 M cf/s on the headline batch, DESIGN.md 5.0)",
                        "ms_per_step_regions_note": "all regions" if len(regions) <= 24 else "the first 8 and the last 16 regions",
                        # two steps in flight settle, region by region, into one of two phase relations of the pipelines
                        # (DESIGN.md 5.0): the spread says how the regions of THIS run fell

@@ -460,6 +460,7 @@ def test_encoder_pool_two_batches_in_flight(A):
     torch.cuda.synchronize()
     outs = [pool.encs[k].alloc_outputs(views[0].n_cf, with_payload=True) for k in range(2)]
     got = []
+    pool.align(50)                                     # both slots' first calls start together (a gate event): same bytes
     for i, v in enumerate(views):
         k = pool.next()
         if i >= 2:                                     # slot k's buffers are about to be reused: take its result first
