@@ -269,6 +269,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=10, help="timed K-step regions (at least); value = median")
+    ap.add_argument("--no-decode-leg", action="store_true",
+                    help="skip the decode figure (config.decode_cf_per_s: the timed run's payloads back to PCM; never `value`)")
     ap.add_argument("--gate-us", type=float, default=None,
                     help="two steps in flight: hold both pipelines' streams for this long at the start of every timed region "
                          "(INSIDE it) so that their first steps start together and the pipelines stay in phase "
@@ -661,6 +663,31 @@ def main():
                               "two buffers of everything, no host synchronisation inside the loop but taking a finished body"}
         del hs
 
+    # ---- the other direction (never `value`): the timed run's payloads of pipeline 0 back to 16-bit PCM
+    # (unpack / gain-shape decode, IMDCT, overlap-and-add), one step in flight on the current stream
+    decode_leg = None
+    if rank == 0 and not multi and not corpus and not args.no_decode_leg:
+        o = pipes[0]["out"]
+        e0 = pipes[0]["enc"]
+
+        def decode_step():
+            if vq_kbps:
+                return e0.decode_vq(o["payload"], o["n_bytes"], N_CH)["pcm"]
+            return e0.decode(e0.unpack(o["payload"], o["n_bytes"]), N_CH)
+        for _ in range(2):
+            pcm_dec = decode_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_dec = 5
+        for _ in range(n_dec):
+            pcm_dec = decode_step()
+        torch.cuda.synchronize()
+        dt_d = (time.perf_counter() - t0) / n_dec
+        decode_leg = {"cf_per_s": n_cf / dt_d, "ms_per_step": dt_d * 1e3, "pcm_samples": int(pcm_dec.shape[0]),
+                      "what": "payload slots of the timed run -> " + ("gain-shape decode" if vq_kbps else "unpack + dequantise")
+                              + " -> IMDCT -> overlap-and-add -> int16 PCM, one step in flight"}
+        del pcm_dec
+
     if rank == 0:
         total_cf = world * n_cf if not corpus else N_CH * args.corpus_frames
         what = ("scalar mantissas" if not vq_kbps else "gain-shape PVQ" + (" + SBR" if kbps < 128 else ""))
@@ -746,6 +773,9 @@ def main():
         if host_stream:
             res["config"]["host_to_host_cf_per_s"] = host_stream["cf_per_s"]
             res["config"]["host_to_host"] = host_stream
+        if decode_leg:
+            res["config"]["decode_cf_per_s"] = decode_leg["cf_per_s"]
+            res["config"]["decode"] = decode_leg
         sk = step_kernels(args.workload, n_cf)
         if sk:
             res["config"]["step_kernels"] = sk

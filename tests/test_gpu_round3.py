@@ -407,6 +407,7 @@ def test_bench_line_fields(A):
     assert 0 < d["config"]["value_one_step_in_flight"]
     assert d["config"]["host_to_host_cf_per_s"] > 0 and d["config"]["host_to_host"]["chunk_cf"] == 2048
     assert d["vs_baseline"] is None
+    assert d["config"]["decode_cf_per_s"] > 0 and d["config"]["decode"]["pcm_samples"] == (256 + 1) * 1024
     q = d["config"]["ms_per_step_quantiles"]           # how the timed regions fell (two timing modes with two steps in flight)
     assert 0 < q["p10"] <= q["p25"] <= q["p50"] <= q["p75"] <= q["p90"]
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 i = sys.argv.index("--")
 label, args = " ".join(sys.argv[1:i]), sys.argv[i + 1:]
 dump = "/tmp/pacx_regions_%d.txt" % os.getpid()
-r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-verify"] + args,
+r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-verify", "--no-decode-leg"] + args,
                    capture_output=True, text=True, env=dict(os.environ, PACX_BENCH_DUMP_REGIONS=dump))
 lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
 if r.returncode or not lines:

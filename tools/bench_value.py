@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 i = sys.argv.index("--")
 label, args = " ".join(sys.argv[1:i]), sys.argv[i + 1:]
-r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--min-seconds", "0.4"] + args, capture_output=True, text=True)
+r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-decode-leg", "--min-seconds", "0.4"] + args, capture_output=True, text=True)
 lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
 if r.returncode or not lines:
     print(label, "FAILED", r.stderr[-600:])

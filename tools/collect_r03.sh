@@ -11,14 +11,14 @@ for w in scalar128 bs128 vq128 vq96 shipped128 shipped96; do
   extra="--workload $w"; [ $w = scalar128 ] || extra="$extra --host-stream-frames 0"
   python3 $R/bench.py $extra > $OUT/bench_$w.log 2>&1
   tail -1 $OUT/bench_$w.log > $OUT/bench_$w.json
-  rocprofv3 --kernel-trace --stats -d $OUT/stats_$w -o s --output-format csv -- python3 $R/bench.py --workload $w --no-cpu-baseline --no-verify --host-stream-frames 0 --min-seconds 0 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/stats_$w -o s --output-format csv -- python3 $R/bench.py --workload $w --no-cpu-baseline --no-verify --no-decode-leg --host-stream-frames 0 --min-seconds 0 > /dev/null 2>&1
   cp $OUT/stats_$w/s_kernel_stats.csv $OUT/${w}_kernel_stats.csv
-  rocprofv3 --kernel-trace --stats -d $OUT/stats1_$w -o s --output-format csv -- python3 $R/bench.py --workload $w --no-cpu-baseline --no-verify --host-stream-frames 0 --min-seconds 0 --pipeline 1 --no-graph > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/stats1_$w -o s --output-format csv -- python3 $R/bench.py --workload $w --no-cpu-baseline --no-verify --no-decode-leg --host-stream-frames 0 --min-seconds 0 --pipeline 1 --no-graph > /dev/null 2>&1
   cp $OUT/stats1_$w/s_kernel_stats.csv $OUT/${w}_kernel_stats_one_in_flight.csv
   echo "done $w"
 done
 # HBM bytes (separate FETCH_SIZE / WRITE_SIZE passes; the profiler serialises the kernels)
-A="--min-seconds 0 --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-verify --pipeline 1 --no-graph --host-stream-frames 0"
+A="--min-seconds 0 --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-verify --no-decode-leg --pipeline 1 --no-graph --host-stream-frames 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $A > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $A > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/mdct_pmc.json $OUT/step_traffic.json

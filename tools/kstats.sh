@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/st -o s --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-verify "$@" > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/st -o s --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-verify --no-decode-leg "$@" > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
 grep '^{"metric' $OUT/bench.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$TAG', round(d['value']/1e6,2), 'M/s', round(d['ms_per_step'],4), 'ms')"
 python3 - <<PY
 import csv,glob
