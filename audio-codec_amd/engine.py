@@ -552,7 +552,7 @@ class EncoderPool:
             return
         if delay_us is None:
             delay_us = float(os.environ.get("PACX_POOL_GATE_US", "100"))
-        if delay_us <= 0:
+        if delay_us <= 0 or not hasattr(torch.cuda, "_sleep"):
             return
         dev = self.encs[0].device
         if self._gate is None:
