@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PACX_LIB") or os.path.join(HERE, "libpacx.so")   # PACX_LIB: kernel-variant experiments
 
-PACX_ABI_VERSION = 5
+PACX_ABI_VERSION = 6
 PCM_I16, PCM_F64 = 0, 1
 FLAG_LAST, FLAG_CUR, FLAG_NEXT = 1, 2, 4
 ST_SHORT, ST_ZERO_SUBBLOCK, ST_ALLOC_CAP, ST_VQ_UNDEFINED, ST_GUARD, ST_MALFORMED = 1, 2, 4, 8, 16, 32
@@ -18,6 +18,22 @@ SUB = 8
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+
+class PacxSmrTables(ctypes.Structure):
+    """pacx_smr_tables (include/pacx.h): device pointers to caller-evaluated tables of pacx_smr_generic_batch"""
+    _fields_ = [
+        ("hann", ctypes.c_void_p),
+        ("tw_cos", ctypes.c_void_p),
+        ("tw_sin", ctypes.c_void_p),
+        ("fft_norm", ctypes.c_double),
+        ("fft_freq_step", ctypes.c_double),
+        ("bark", ctypes.c_void_p),
+        ("quiet", ctypes.c_void_p),
+        ("band_lower", ctypes.c_void_p),
+        ("band_lines", ctypes.c_void_p),
+        ("n_bands", ctypes.c_int32),
+    ]
 
 
 class PacxConfig(ctypes.Structure):
@@ -111,6 +127,8 @@ SIGNATURES = {
     "pacx_mdct_direct_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
     "pacx_transient_detect_f64": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _P, ctypes.c_double, _P, _P]),
     "pacx_unpack_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pacx_smr_generic_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, ctypes.POINTER(PacxSmrTables), _P, _P,
+                                              _P, _P]),
     "pacx_decode_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pacx_decode_sbr_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, ctypes.c_int, _P, _P,
                                              _P, _P, _P]),

@@ -69,6 +69,8 @@ def _encode_scalar(data, codingParams, lastTrans, curTrans, nextTrans, sbr):
     bands, np.empty) and the excess is uninitialised memory."""
     import torch
     cp = codingParams
+    if not sbr and cp.nMDCTLines != (128 if curTrans else 1024):
+        return _encode_scalar_any_size(data, cp, lastTrans, curTrans, nextTrans)
     enc = context.encoder(cp.sampleRate, cp.targetBitsPerSample, cp.nScaleBits, cp.nMantSizeBits,
                           getattr(cp, "sfBands", None), getattr(cp, "sfBandsShort", None),
                           use_vq=False, use_sbr=bool(sbr))
@@ -82,6 +84,54 @@ def _encode_scalar(data, codingParams, lastTrans, curTrans, nextTrans, sbr):
     for ch in range(n_ch):
         r = unpack_short(enc, out, ch, 0) if curTrans else unpack_long(enc, out, ch)
         for dst, v in zip(res, r):
+            dst.append(v)
+    return res
+
+
+def _encode_scalar_any_size(data, cp, lastTrans, curTrans, nextTrans):
+    """EncodeSingleChannel (coder/codec.py:266-380, scalar mantissas) for block lengths the batch entry points are not
+    built for -- nMDCTLines = 512, say -- composed statement by statement from the module mirrors, every
+    one of which runs on the GPU: window (table path), MDCT (any split a + b), ScaleFactor, CalcSMRs (k_smr_generic),
+    BitAlloc (k_bitalloc_generic), vMantissa.  A function-level path: a dozen launches per band and block, not a fast one.
+    The bands are codingParams.sfBands (sfBandsShort with curTrans), as in the reference."""
+    from . import bitalloc, mdct, psychoac, quantize, window
+    half = int(cp.nMDCTLines)
+    n = 2 * half
+    bands = cp.sfBandsShort if curTrans else cp.sfBands
+    max_mant = min(1 << cp.nMantSizeBits, 16)
+    n_eff = int(1.45 * half) if curTrans else half                     # coder/codec.py:288-299
+    if lastTrans or nextTrans:
+        n_eff = int(0.85 * n_eff)
+    budget = cp.targetBitsPerSample * n_eff
+    budget -= cp.nScaleBits * (bands.nBands + 1)
+    budget -= cp.nMantSizeBits * bands.nBands
+    res = ([], [], [], [])
+    for ch in range(cp.nChannels):
+        x = np.ascontiguousarray(data[ch], dtype=np.float64)
+        if x.shape[-1] != n:
+            raise ValueError("a block holds 2 * nMDCTLines samples")
+        if curTrans or not (lastTrans or nextTrans):                   # getCorrectWindow, coder/codec.py:30-45
+            xw = window.SineWindow(x)
+        elif lastTrans and nextTrans:
+            xw = window.StartStopWindow(x, n, 256)
+        elif lastTrans:
+            xw = window.StopWindow(x, n, 256)
+        else:
+            xw = window.StartWindow(x, n, 256)
+        lines = np.array(mdct.MDCT(xw, half, half)[:half], dtype=np.float64)
+        overall = int(quantize.ScaleFactor(float(np.max(np.abs(lines))), cp.nScaleBits))
+        lines *= (1 << overall)
+        smr = psychoac.CalcSMRs(x, lines, overall, cp.sampleRate, bands)
+        alloc = np.asarray(bitalloc.BitAlloc(budget, max_mant, bands.nBands, bands.nLines, smr)).astype(np.int64)
+        sf = np.empty(bands.nBands, dtype=np.int32)
+        mant = []
+        for b in range(bands.nBands):
+            lo, hi = int(bands.lowerLine[b]), int(bands.upperLine[b]) + 1
+            sf[b] = quantize.ScaleFactor(float(np.max(np.abs(lines[lo:hi]))), cp.nScaleBits, int(alloc[b]))
+            if alloc[b]:
+                mant.append(np.asarray(quantize.vMantissa(lines[lo:hi], int(sf[b]), cp.nScaleBits, int(alloc[b]))))
+        mant = np.concatenate(mant).astype(np.int32) if mant else np.zeros(0, np.int32)
+        for dst, v in zip(res, (sf, alloc, mant, overall)):
             dst.append(v)
     return res
 

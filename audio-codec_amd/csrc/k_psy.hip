@@ -1131,6 +1131,127 @@ __global__ __launch_bounds__(64 * mask_waves(M, TAIL), (M == PACX_M_LONG && !TAI
 #endif
 }
 
+/* ------------------------------------------------ CalcSMRs for any block size */
+/* psychoac.CalcSMRs / getMaskedThreshold (coder/psychoac.py:163-291) for block lengths the tuned kernels above do
+ * not cover (they are specialised to 2048- and 256-sample blocks: what the reference's driver uses,
+ * coder/pacfile.py:699,490) -- nMDCTLines = 512, say.  A function-level path, not a fast one:
+ * one workgroup per block, the spectrum by a direct DFT over a caller-evaluated twiddle table (index k n mod N,
+ * so every angle is one of the table's N; summed in sample order), then the arithmetic of the tuned kernels --
+ * make_peak, the dB-domain maximum with one SPL(Intensity(.)) round trip per line, the lean log10 -- with
+ * the tables (Hann window, twiddles, Bark values and thresholds in quiet of the lines) evaluated by the caller,
+ * as the tuned path's are at pacx_create.  LDS: windowed block, intensities, maskers. */
+#define SMRG_THREADS 256
+__global__ __launch_bounds__(SMRG_THREADS) void k_smr_generic(long long n_blocks, int n, int nb,
+                                                             const double *__restrict__ data,
+                                                             const double *__restrict__ lines,
+                                                             const double *__restrict__ hann,
+                                                             const double *__restrict__ tw_cos,
+                                                             const double *__restrict__ tw_sin, double norm,
+                                                             double fstep, const double *__restrict__ bark,
+                                                             const double *__restrict__ quiet,
+                                                             const int32_t *__restrict__ band_lower,
+                                                             const int32_t *__restrict__ band_count,
+                                                             double *__restrict__ smr, double *__restrict__ thr_out,
+                                                             int32_t *__restrict__ n_peaks_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smrg_lds[];
+    const int half = n / 2, n_bins = half + 1, max_pk = half / 2 + 1;
+    double *w = (double *)smrg_lds;                       /* [n]      windowed block, later spl - thr of the lines */
+    double *inten = w + n;                                /* [n_bins] */
+    PacxPeak *pk = (PacxPeak *)(inten + n_bins + (n_bins & 1));     /* [max_pk] */
+    __shared__ int n_pk;
+    const int tid = threadIdx.x;
+    const long long blk = blockIdx.x;
+    if (blk >= n_blocks)
+        return;
+    const double *x = data + blk * n;
+    for (int i = tid; i < n; i += SMRG_THREADS)
+        w[i] = hann[i] * x[i];                            /* HanningWindow(data), coder/psychoac.py:175 */
+    if (tid == 0)
+        n_pk = 0;
+    __syncthreads();
+    /* norm * |rfft|^2, coder/psychoac.py:171-179 */
+    for (int k = tid; k < n_bins; k += SMRG_THREADS) {
+        double re = 0.0, im = 0.0;
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            re += w[i] * tw_cos[m];
+            im -= w[i] * tw_sin[m];
+            m += k;
+            if (m >= n)
+                m -= n;
+        }
+        const double a = sqrt(re * re + im * im);
+        inten[k] = norm * (a * a);
+    }
+    __syncthreads();
+    /* estimate_peaks, coder/psychoac.py:308-329: strict local maxima of bins 1 .. n/2, the last one compared to the
+       left only; the list's order does not matter to the maximum taken over it */
+    for (int i = 1 + tid; i < n_bins; i += SMRG_THREADS) {
+        const double c = inten[i];
+        if (c > inten[i - 1] && (i == n_bins - 1 || c > inten[i + 1])) {
+            const int at = atomicAdd(&n_pk, 1);
+            if (at < max_pk)
+                pk[at] = make_peak(inten[i - 1], c, i, fstep);
+        }
+    }
+    __syncthreads();
+    const int np = n_pk < max_pk ? n_pk : max_pk;
+    if (tid == 0 && n_peaks_out)
+        n_peaks_out[blk] = np;
+    /* per line: max over the maskers in dB, one round trip, max with quiet; mdct_spl - thr (psychoac.py:181-217, 246-254) */
+    const double *ln = lines + blk * half;
+    for (int k = tid; k < half; k += SMRG_THREADS) {
+        const double zj = bark[k];
+        double best = -INFINITY;
+        for (int p = 0; p < np; ++p) {
+            const double dz = zj - pk[p].z;
+            const double a = fmax(fabs(dz) - 0.5, 0.0);
+            const double gain = (dz < 0.0 ? -27.0 : pk[p].slope) * a;
+            best = fmax(best, (pk[p].spl + gain) - 16.0);
+        }
+        double thr = quiet[k];
+        if (best > -INFINITY)
+            thr = fmax(thr, mask_round_trip(best));
+        if (thr_out)
+            thr_out[blk * half + k] = thr;
+        const double v = ln[k];
+        double it = (v * v) * 4.0;
+        if (it == 0.0)
+            it = 1e-8;
+        double spl = 96.0 + 10.0 * pacx_log10_pos(it + PACX_EPS);
+        if (spl < -30.0)
+            spl = -30.0;
+        w[k] = spl - thr;
+    }
+    __syncthreads();
+    for (int b = tid; b < nb; b += SMRG_THREADS) {
+        const int lo = band_lower[b], cnt = band_count[b];
+        double mx = w[lo];                                /* np.amax over an empty band raises in the reference: the host refuses it */
+        for (int i = 1; i < cnt; ++i)
+            mx = fmax(mx, w[lo + i]);
+        smr[blk * nb + b] = mx;
+    }
+}
+
+size_t pacx_smr_generic_lds(int n)
+{
+    const int half = n / 2, n_bins = half + 1, max_pk = half / 2 + 1;
+    return (size_t)(n + n_bins + (n_bins & 1)) * 8 + (size_t)max_pk * sizeof(PacxPeak);
+}
+
+void pacx_launch_smr_generic(long long n_blocks, int n, int nb, const double *data, const double *lines,
+                             const double *hann, const double *tw_cos, const double *tw_sin, double norm, double fstep,
+                             const double *bark, const double *quiet, const int32_t *band_lower,
+                             const int32_t *band_count, double *smr, double *thr_out, int32_t *n_peaks_out,
+                             hipStream_t st)
+{
+    if (n_blocks > 0)
+        hipLaunchKernelGGL(k_smr_generic, dim3((unsigned)n_blocks), dim3(SMRG_THREADS), pacx_smr_generic_lds(n), st,
+                           n_blocks, n, nb, data, lines, hann, tw_cos, tw_sin, norm, fstep, bark, quiet, band_lower,
+                           band_count, smr, thr_out, n_peaks_out);
+}
+
 /* ------------------------------------------------------------- launchers */
 template <int DT, bool FAST>
 static void launch_side(const PacxTables &T, const PacxPcmView &in, const uint8_t *flags,

@@ -846,6 +846,35 @@ extern "C" int pacx_smr_batch(pacx_handle *h, const pacx_pcm *in, const double *
     return post_launch(h, "pacx_smr_batch");
 }
 
+size_t pacx_smr_generic_lds(int n);
+void pacx_launch_smr_generic(long long n_blocks, int n, int nb, const double *data, const double *lines,
+                             const double *hann, const double *tw_cos, const double *tw_sin, double norm, double fstep,
+                             const double *bark, const double *quiet, const int32_t *band_lower,
+                             const int32_t *band_count, double *smr, double *thr_out, int32_t *n_peaks_out,
+                             hipStream_t st);
+
+extern "C" int pacx_smr_generic_batch(pacx_handle *h, int64_t n_blocks, int n_samples, const double *data,
+                                      const double *lines, const pacx_smr_tables *t, double *smr, double *threshold,
+                                      int32_t *n_peaks, void *stream)
+{
+    if (!h)
+        return PACX_E_ARG;
+    if (n_blocks == 0)
+        return PACX_OK;
+    if (n_blocks < 0 || !data || !lines || !smr || !t || !t->hann || !t->tw_cos || !t->tw_sin || !t->bark ||
+        !t->quiet || !t->band_lower || !t->band_lines)
+        return fail(h, PACX_E_ARG, "pacx_smr_generic_batch: bad argument");
+    if (n_samples < 16 || n_samples > 8192 || (n_samples & 1) || t->n_bands < 1 || t->n_bands > PACX_MAX_BANDS)
+        return fail(h, PACX_E_UNSUPPORTED, "pacx_smr_generic_batch: blocks of 16..8192 samples (even), 1..32 bands");
+    if (pacx_smr_generic_lds(n_samples) > 150 * 1024)
+        return fail(h, PACX_E_UNSUPPORTED, "pacx_smr_generic_batch: block too long for the LDS of a CU");
+    HIP_TRY(h, hipSetDevice(h->device));
+    pacx_launch_smr_generic(n_blocks, n_samples, t->n_bands, data, lines, t->hann, t->tw_cos, t->tw_sin, t->fft_norm,
+                            t->fft_freq_step, t->bark, t->quiet, t->band_lower, t->band_lines, smr, threshold, n_peaks,
+                            (hipStream_t)stream);
+    return post_launch(h, "pacx_smr_generic_batch");
+}
+
 extern "C" int pacx_bitalloc_batch(pacx_handle *h, int64_t n_cf, int n_channels, const uint8_t *frame_flags,
                                    int short_blocks, const double *smr, int32_t *bit_alloc,
                                    uint32_t *status, void *stream)

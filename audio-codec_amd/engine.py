@@ -203,6 +203,24 @@ class Encoder:
             out.append(npk)
         return out[0] if len(out) == 1 else tuple(out)
 
+    def smr_generic(self, data, lines, t, want_threshold=False, want_peaks=False):
+        """CalcSMRs / getMaskedThreshold for ANY block length (pacx_smr_generic_batch): data [n, N] float64 time
+        blocks, lines [n, N/2] = MDCTdata / 2^MDCTscale; t: dict of device tensors hann, tw_cos, tw_sin [N], bark,
+        quiet [N/2], band_lower, band_lines (int32) and the floats fft_norm, fft_freq_step (psychoac._generic_tables)."""
+        data, lines = data.contiguous(), lines.contiguous()
+        n_blocks, n = data.shape
+        nb = int(t["band_lines"].numel())
+        c = _lib.PacxSmrTables(t["hann"].data_ptr(), t["tw_cos"].data_ptr(), t["tw_sin"].data_ptr(), float(t["fft_norm"]),
+                               float(t["fft_freq_step"]), t["bark"].data_ptr(), t["quiet"].data_ptr(),
+                               t["band_lower"].data_ptr(), t["band_lines"].data_ptr(), nb)
+        smr = self._empty((n_blocks, nb), torch.float64)
+        thr = self._empty((n_blocks, n // 2), torch.float64) if want_threshold else None
+        npk = self._empty((n_blocks,), torch.int32) if want_peaks else None
+        self._call("pacx_smr_generic_batch", ctypes.c_int64(n_blocks), int(n), _ptr(data), _ptr(lines), ctypes.byref(c),
+                   _ptr(smr), _ptr(thr), _ptr(npk), self._stream())
+        out = [smr] + ([thr] if want_threshold else []) + ([npk] if want_peaks else [])
+        return out[0] if len(out) == 1 else tuple(out)
+
     def bit_alloc(self, smr, n_channels=1, flags=None, short=False):
         smr = smr.contiguous()
         n_cf = smr.shape[0]

@@ -58,6 +58,52 @@ def true_line_counts(bands):
     return tuple(int(v) for v in bands.nLines)
 
 
+_generic = {}
+
+
+def _generic_tables(n, sample_rate, sf_bands, device):
+    """device copies of the tables pacx_smr_generic_batch wants, evaluated with NumPy the way the reference
+    evaluates them (window.HanningWindow, np.hanning for the norm, rfftfreq, the Bark values and thresholds in
+    quiet of the MDCT lines: coder/psychoac.py:45-46, 28-42, 171-179, 183-186), cached per (N, rate, band layout)"""
+    import torch
+    from . import tables
+    counts = true_line_counts(sf_bands)
+    key = (int(n), float(sample_rate), counts, str(device))
+    t = _generic.get(key)
+    if t is None:
+        if min(counts) < 1:
+            raise ValueError("zero-size array to reduction operation maximum which has no identity")   # np.amax, coder/psychoac.py:289
+        m = np.arange(n) * (2.0 * np.pi / n)
+        f = tables.line_freqs(n // 2, sample_rate)
+        lower = np.concatenate(([0], np.cumsum(counts)[:-1]))
+        as_t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=device)
+        t = {"hann": as_t(tables.hann(n), np.float64), "tw_cos": as_t(np.cos(m), np.float64),
+             "tw_sin": as_t(np.sin(m), np.float64), "fft_norm": float(tables.fft_norm(n)),
+             "fft_freq_step": float(tables.fft_freq_step(n, sample_rate)), "bark": as_t(tables.bark(f), np.float64),
+             "quiet": as_t(tables.thresh(f), np.float64), "band_lower": as_t(lower, np.int32),
+             "band_lines": as_t(counts, np.int32)}
+        _generic[key] = t
+    return t
+
+
+def _run_generic(data, MDCTdata, MDCTscale, sampleRate, sfBands, want_threshold):
+    """block lengths the tuned kernels are not built for (nMDCTLines other than 1024 / 128): the function-level
+    kernel k_smr_generic, one workgroup per block"""
+    import torch
+    from . import context
+    enc = context.any_encoder()
+    n = len(data)
+    if n % 2 or len(MDCTdata) != n // 2:
+        raise ValueError("CalcSMRs: data holds 2 * len(MDCTdata) samples")
+    t = _generic_tables(n, sampleRate, sfBands, enc.device)
+    lines = np.asarray(MDCTdata, dtype=np.float64) / 2 ** MDCTscale
+    res = enc.smr_generic(torch.as_tensor(data, device=enc.device).view(1, n),
+                          torch.as_tensor(lines, device=enc.device).view(1, n // 2), t, want_threshold=want_threshold)
+    if want_threshold:
+        return res[1][0].cpu().numpy()
+    return res[0].cpu().numpy()
+
+
 def _run(data, MDCTdata, MDCTscale, sampleRate, sfBands, want_threshold):
     import torch
     from . import context
@@ -66,7 +112,7 @@ def _run(data, MDCTdata, MDCTscale, sampleRate, sfBands, want_threshold):
     n_lines = len(MDCTdata)
     short = (n_lines == 128)
     if n_lines not in (1024, 128) or len(data) != 2 * n_lines:
-        raise NotImplementedError("GPU CalcSMRs handles 1024- and 128-line blocks")
+        return _run_generic(data, MDCTdata, MDCTscale, sampleRate, sfBands, want_threshold)
     enc = context.encoder_for_bands(sampleRate, sfBands, short)
     lines = np.asarray(MDCTdata, dtype=np.float64) / 2 ** MDCTscale
     if short:

@@ -16,18 +16,33 @@ def _apply(kind, data, expect):
     return y.cpu().numpy().reshape(data.shape)
 
 
+def _apply_table(table, data):
+    """a block length without a resident table: the window evaluated on the host with the reference's expression
+    (tables.py), multiplied on the GPU (pacx_window_table_batch)"""
+    import torch
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    n = data.shape[-1]
+    enc = context.any_encoder()
+    y = enc.window_table(table, torch.as_tensor(data, device=enc.device).view(-1, n))
+    return y.cpu().numpy().reshape(data.shape)
+
+
 def SineWindow(dataSampleArray):
-    """coder/window.py:14-25 (2048- or 256-sample blocks)."""
+    """coder/window.py:14-25.  2048- and 256-sample blocks use the resident tables."""
+    from . import tables
     n = np.shape(dataSampleArray)[-1]
-    return _apply(_lib.WIN_SINE if n == 2048 else _lib.WIN_SINE_SHORT, dataSampleArray,
-                  2048 if n == 2048 else 256)
+    if n not in (2048, 256):
+        return _apply_table(tables.sine(n), dataSampleArray)
+    return _apply(_lib.WIN_SINE if n == 2048 else _lib.WIN_SINE_SHORT, dataSampleArray, n)
 
 
 def HanningWindow(dataSampleArray):
     """coder/window.py:29-41."""
+    from . import tables
     n = np.shape(dataSampleArray)[-1]
-    return _apply(_lib.WIN_HANN if n == 2048 else _lib.WIN_HANN_SHORT, dataSampleArray,
-                  2048 if n == 2048 else 256)
+    if n not in (2048, 256):
+        return _apply_table(tables.hann(n), dataSampleArray)
+    return _apply(_lib.WIN_HANN if n == 2048 else _lib.WIN_HANN_SHORT, dataSampleArray, n)
 
 
 def KBDWindow(dataSampleArray, alpha=4.):
@@ -45,24 +60,29 @@ def KBDWindow(dataSampleArray, alpha=4.):
     return y.cpu().numpy().reshape(data.shape)
 
 
-def _check(N_long, N_short):
-    if (N_long, N_short) != (2048, 256):
-        raise NotImplementedError("transition windows are resident for N_long=2048, N_short=256")
+def _resident(N_long, N_short):
+    return (N_long, N_short) == (2048, 256)
 
 
 def StartWindow(dataSampleArray, N_long, N_short):
-    """coder/window.py:61-71."""
-    _check(N_long, N_short)
+    """coder/window.py:61-71 (resident table for N_long=2048, N_short=256; any other pair through the table path)."""
+    from . import tables
+    if not _resident(N_long, N_short):
+        return _apply_table(tables.start(N_long, N_short), dataSampleArray)
     return _apply(_lib.WIN_START, dataSampleArray, 2048)
 
 
 def StopWindow(dataSampleArray, N_long, N_short):
     """coder/window.py:73-80."""
-    _check(N_long, N_short)
+    from . import tables
+    if not _resident(N_long, N_short):
+        return _apply_table(tables.stop(N_long, N_short), dataSampleArray)
     return _apply(_lib.WIN_STOP, dataSampleArray, 2048)
 
 
 def StartStopWindow(dataSampleArray, N_long, N_short):
     """coder/window.py:82-92."""
-    _check(N_long, N_short)
+    from . import tables
+    if not _resident(N_long, N_short):
+        return _apply_table(tables.start_stop(N_long, N_short), dataSampleArray)
     return _apply(_lib.WIN_STARTSTOP, dataSampleArray, 2048)

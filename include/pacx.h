@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PACX_ABI_VERSION 5
+#define PACX_ABI_VERSION 6
 
 /* error codes */
 #define PACX_OK            0
@@ -455,6 +455,33 @@ int pacx_transient_flags(pacx_handle *h, const pacx_pcm *hops, uint8_t *transien
  * pairwise order.  The encode path itself uses pacx_transient_flags on the int16 hops. */
 int pacx_transient_detect_f64(pacx_handle *h, int64_t n_blocks, int n_channels, int n_samples,
                               const double *blocks, double thresh, uint8_t *result, void *stream);
+
+/*
+ * psychoac.CalcSMRs / getMaskedThreshold (coder/psychoac.py:163-291) for block lengths other than the two the
+ * handle's tuned kernels are built for (2 * n_lines_long and 2 * n_lines_short samples: 2048 and 256, the
+ * reference driver's, coder/pacfile.py:699,490) -- nMDCTLines = 512, for instance.  A function-level path: one
+ * workgroup per block, the spectrum by a direct DFT, then the tuned kernels' arithmetic.  All tables are the
+ * CALLER's, evaluated the way the reference evaluates them (the Python mirror does it with NumPy), on the device:
+ */
+typedef struct pacx_smr_tables {
+    const double *hann;             /* [n_samples] 0.5 (1 - cos(2 pi (n + 1/2) / N)), window.HanningWindow      */
+    const double *tw_cos, *tw_sin;  /* [n_samples] cos / sin (2 pi m / N)                                       */
+    double fft_norm;                /* 4 / (N^2 mean(np.hanning(N)^2)), coder/psychoac.py:172-173                */
+    double fft_freq_step;           /* rfftfreq(N, 1 / sampleRate)[1]                                            */
+    const double *bark, *quiet;     /* [n_samples / 2] Bark value and threshold in quiet of the MDCT lines       */
+    const int32_t *band_lower;      /* [n_bands] first line of a band                                            */
+    const int32_t *band_lines;      /* [n_bands] its line count (> 0)                                            */
+    int32_t n_bands;                /* 1 .. 32                                                                   */
+} pacx_smr_tables;
+/*
+ *   data:   float64 [n_blocks][n_samples], the time block CalcSMRs gets (unwindowed);
+ *   lines:  float64 [n_blocks][n_samples / 2], MDCTdata / 2^MDCTscale;
+ *   smr:    float64 [n_blocks][n_bands]; threshold (optional): [n_blocks][n_samples / 2] dB SPL;
+ *   n_peaks (optional): int32 [n_blocks].
+ */
+int pacx_smr_generic_batch(pacx_handle *h, int64_t n_blocks, int n_samples, const double *data,
+                           const double *lines, const pacx_smr_tables *t, double *smr, double *threshold,
+                           int32_t *n_peaks, void *stream);
 
 /* ---- decode side (scalar-mantissa streams) ---------- */
 

@@ -574,3 +574,90 @@ def test_scalar_sbr_decode_routing_and_refusal(A):
     nb = cp96.sfBands.nBands
     with pytest.raises(IndexError):
         A.codec.Decode_SBR(np.zeros(nb, np.int32), np.full(nb, 4, np.int32), np.ones(1024, np.int32), 0, None, cp96)
+
+
+# ------------------------------------------------------------------ nMDCTLines other than 1024 / 128 (VERDICT r2 missing #6)
+def _params(A, sr, half, kbps=128):
+    cp = A.audiofile.CodingParams()
+    cp.sampleRate, cp.nChannels, cp.nMDCTLines, cp.nSamplesPerBlock = sr, 1, half, half
+    cp.nScaleBits, cp.nMantSizeBits, cp.targetBitsPerSample = 4, 12, kbps / (sr / 1000)
+    cp.useSBR, cp.useVQ = False, False
+    cp.sfBands = A.psychoac.ScaleFactorBands(A.psychoac.AssignMDCTLinesFromFreqLimits(half, sr))
+    cp.sfBandsShort = A.psychoac.ScaleFactorBands(A.psychoac.AssignMDCTLinesFromFreqLimits(128, sr))
+    cp.omittedBands = []
+    return cp
+
+
+def _blocks(n, count, seed):
+    """blocks of n samples: stretches of the harpsichord and castanet excerpts (as fractions) and synthetic ones"""
+    from oracle import pac_oracle as po
+    rng = np.random.default_rng(seed)
+    out = []
+    for name in ("harpsichord", "castanet"):
+        pcm = np.load(os.path.join(GOLDEN, f"excerpt_{name}.npz"))["pcm"]
+        for k in range(count // 3):
+            at = int(rng.integers(2000, len(pcm) - n - 1))
+            out.append(po.pcm16_to_fraction(pcm[at:at + n, k & 1]))
+    t = np.arange(n)
+    while len(out) < count:
+        x = sum(rng.uniform(0.01, 0.3) * np.cos(2 * np.pi * rng.uniform(50, 15000) * t / 48000 + rng.uniform(0, 6)) for _ in range(5))
+        out.append(x + 10.0 ** rng.uniform(-4, -1.5) * rng.standard_normal(n))
+    return out
+
+
+@pytest.mark.parametrize("sr,half", [(48000, 512), (44100, 512), (48000, 256), (32000, 2048)])
+def test_calc_smrs_any_block_length(A, sr, half):
+    """psychoac.CalcSMRs / getMaskedThreshold through k_smr_generic (pacx_smr_generic_batch) against the oracle's
+    calc_smrs: the tuned kernels' tolerance, 1e-9 dB ('and 512 cheaply')"""
+    from oracle import pac_oracle as po
+    cp = _params(A, sr, half)
+    bands = po.band_table(half, sr)
+    worst = worst_t = 0.0
+    for x in _blocks(2 * half, 9, 50 + half):
+        lines = po.mdct_forward(po.sine_window(2 * half) * x, half, half)[:half]
+        ov = po.scale_factor(np.max(np.abs(lines)), 4)
+        want = po.calc_smrs(x, lines * (1 << ov), ov, sr, bands)
+        got = A.psychoac.CalcSMRs(x, lines * (1 << ov), ov, sr, cp.sfBands)
+        worst = max(worst, float(np.abs(got - want).max()))
+        thr = A.psychoac.getMaskedThreshold(x, lines * (1 << ov), ov, sr, cp.sfBands)
+        worst_t = max(worst_t, float(np.abs(thr - po.masked_threshold(x, half, sr)).max()))
+    assert worst <= 1e-9 and worst_t <= 1e-9, (worst, worst_t)
+
+
+def test_generic_smr_kernel_agrees_with_the_tuned_ones(A):
+    """the same blocks through k_smr_generic and through k_side_long + k_mask<1024> (and the 256-sample pair):
+    SMRs within 1e-9 dB of one another, peak counts equal"""
+    import torch
+    enc = A.context.encoder(48000, 128 / 48.0)
+    for n, short in ((2048, False), (256, True)):
+        half = n // 2
+        bands = enc.sfBandsShort if short else enc.sfBands
+        t = A.psychoac._generic_tables(n, 48000, bands, enc.device)
+        xs = np.stack(_blocks(n, 6, 70 + n))
+        from oracle import pac_oracle as po
+        lines = np.stack([po.mdct_forward(po.sine_window(n) * x, half, half)[:half] for x in xs])
+        g_smr, g_npk = enc.smr_generic(torch.as_tensor(xs, device=enc.device), torch.as_tensor(lines, device=enc.device), t,
+                                       want_peaks=True)
+        for i, x in enumerate(xs):
+            want = A.psychoac.CalcSMRs(x, lines[i], 0, 48000, bands)
+            assert np.abs(g_smr[i].cpu().numpy() - want).max() <= 1e-9, (n, i)
+        assert int(g_npk.min().item()) > 0
+
+
+@pytest.mark.parametrize("sr,half,kbps", [(48000, 512, 128), (44100, 512, 96), (48000, 256, 192)])
+def test_encode_single_channel_with_512_lines(A, sr, half, kbps):
+    """codec.EncodeSingleChannel with nMDCTLines = 512 (and 256): composed from the GPU-backed module mirrors, the codes of the
+    oracle's encode_channel -- overall scale, allocation, scale factors, mantissas -- exactly; all four window kinds"""
+    from oracle import pac_oracle as po
+    cp = _params(A, sr, half, kbps)
+    p = po.make_params(sr, 1, kbps, half)
+    assert list(p.sfBands.nLines) == list(cp.sfBands.nLines)
+    n_mant = 0
+    for i, x in enumerate(_blocks(2 * half, 12, 90 + half + kbps)):
+        fl = ((False, False, False), (True, False, False), (False, False, True), (True, False, True))[i % 4]
+        sf, ba, mant, ov = A.codec.EncodeSingleChannel(x, cp, *fl)
+        w_sf, w_ba, w_mant, w_ov = po.encode_channel(x.copy(), p, *fl)
+        assert ov == w_ov and list(ba) == list(w_ba) and list(sf) == list(w_sf), (i, fl)
+        assert np.array_equal(mant, w_mant), (i, fl)
+        n_mant += len(mant)
+    assert n_mant > 1000
