@@ -228,10 +228,13 @@ def _decode_scalar_block(scaleFactor, bitAlloc, mantissa, overallScaleFactor, co
     """one channel-block of scalar mantissas on the GPU: pacx_decode_batch (codec.Decode) or, sbr,
     pacx_decode_sbr_batch with Decode_SBR on the block whatever its allocations"""
     import torch
-    enc = context.encoder_for_params(codingParams)
     n_lines = codingParams.nMDCTLines
     if n_lines not in (1024, 128) or bool(curTrans) != (n_lines == 128):
-        raise NotImplementedError("long blocks have 1024 lines, short (curTrans) blocks 128")
+        if sbr:
+            raise NotImplementedError("Decode_SBR on the GPU: long blocks of 1024 lines")
+        return _decode_scalar_any_size(scaleFactor, bitAlloc, mantissa, overallScaleFactor, codingParams, lastTrans,
+                                       curTrans, nextTrans)
+    enc = context.encoder_for_params(codingParams)
     nb = len(bitAlloc)
     codes = enc.alloc_outputs(1)
     for k in ("overall", "scale_factor", "bit_alloc", "mantissa"):
@@ -251,6 +254,32 @@ def _decode_scalar_block(scaleFactor, bitAlloc, mantissa, overallScaleFactor, co
     if int(extra["status"][0].item()) & _lib.ST_VQ_UNDEFINED:
         raise IndexError("index 1024 is out of bounds for axis 0 with size 1024")       # coder/codec.py:173-176
     return block
+
+
+def _decode_scalar_any_size(scaleFactor, bitAlloc, mantissa, overallScaleFactor, cp, lastTrans, curTrans, nextTrans):
+    """codec.Decode (coder/codec.py:47-92, scalar mantissas) for block lengths the batch entry points are not built for,
+    composed from the GPU-backed mirrors: vDequantize per coded band, / 2^overall, IMDCT (any split), window."""
+    from . import mdct, quantize, window
+    half = int(cp.nMDCTLines)
+    n = 2 * half
+    bands = cp.sfBandsShort if curTrans else cp.sfBands
+    lines = np.zeros(half, dtype=np.float64)
+    at = 0
+    for b in range(bands.nBands):
+        cnt = int(bands.nLines[b])
+        if bitAlloc[b]:
+            lines[at:at + cnt] = quantize.vDequantize(int(scaleFactor[b]), np.asarray(mantissa[at:at + cnt]), cp.nScaleBits,
+                                                      int(bitAlloc[b]))
+        at += cnt
+    lines /= 1. * (1 << int(overallScaleFactor))
+    y = np.asarray(mdct.IMDCT(lines, half, half), dtype=np.float64)
+    if curTrans or not (lastTrans or nextTrans):                       # getCorrectWindow, coder/codec.py:30-45
+        return window.SineWindow(y)
+    if lastTrans and nextTrans:
+        return window.StartStopWindow(y, n, 256)
+    if lastTrans:
+        return window.StopWindow(y, n, 256)
+    return window.StartWindow(y, n, 256)
 
 
 def Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, pb, codingParams,

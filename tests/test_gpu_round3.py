@@ -660,4 +660,15 @@ def test_encode_single_channel_with_512_lines(A, sr, half, kbps):
         assert ov == w_ov and list(ba) == list(w_ba) and list(sf) == list(w_sf), (i, fl)
         assert np.array_equal(mant, w_mant), (i, fl)
         n_mant += len(mant)
+        # and back: codec.Decode wants the mantissas line-indexed, as PACFile.getDecodedBlock builds them
+        by_line = np.zeros(half, np.int32)
+        at = 0
+        for b in range(cp.sfBands.nBands):
+            if ba[b]:
+                lo = int(cp.sfBands.lowerLine[b])
+                by_line[lo:lo + cp.sfBands.nLines[b]] = mant[at:at + cp.sfBands.nLines[b]]
+                at += cp.sfBands.nLines[b]
+        got = A.codec.Decode(sf, ba, by_line, ov, None, cp, *fl)
+        want = po.decode_block(p, w_sf, w_ba, by_line, w_ov, *fl)
+        assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1e-300), (i, fl)
     assert n_mant > 1000
