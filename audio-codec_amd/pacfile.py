@@ -78,10 +78,129 @@ class PACFile(AudioFile):
         codingParams.priorBlock = [np.zeros(codingParams.nMDCTLines, dtype=np.float64)
                                    for _ in range(codingParams.nChannels)]
 
+    def _write_block_any_size(self, data, cp, lastTrans, curTrans, nextTrans):
+        """WriteDataBlock for nMDCTLines other than 1024 (scalar mantissas): the reference's own sequence
+        (coder/pacfile.py:449-610) with its Encode calls going to the function-level mirrors (codec.Encode composes
+        a block of any length from GPU-backed pieces; 128-line sub-blocks take the tuned kernels) and the bit
+        packing (:404-447, 552-565) restated on the host.  A correctness path: the batched entry points are built
+        for the driver's 1024 lines."""
+        long_n = cp.nMDCTLines
+        full = [np.concatenate((cp.priorBlock[ch], data[ch])) for ch in range(cp.nChannels)]
+        cp.priorBlock = data
+        if not curTrans:
+            parts = [[p] for p in zip(*self.Encode(full, cp, lastTrans, curTrans, nextTrans))]
+            bands = cp.sfBands
+        else:
+            short = 128                                               # coder/pacfile.py:490
+            pad = long_n // 2 - short // 2
+            parts = [[] for _ in range(cp.nChannels)]
+            long_bands, cp.sfBands = cp.sfBands, None                 # the 128-line blocks' handle: default long layout
+            cp.nSamplesPerBlock = cp.nMDCTLines = short
+            try:
+                for n in range(pad, 2 * long_n - short - pad, short):
+                    sub = [f[n:n + 2 * short] for f in full]
+                    if any(np.all(x == 0) for x in sub):
+                        return                                        # the whole hop is dropped (:530-533)
+                    for ch, p in enumerate(zip(*self.Encode(sub, cp, lastTrans, curTrans, nextTrans))):
+                        parts[ch].append(p)
+            finally:
+                cp.nSamplesPerBlock = cp.nMDCTLines = long_n
+                cp.sfBands = long_bands
+            bands = cp.sfBandsShort
+        for ch in range(cp.nChannels):
+            bits = codec._Bits()
+            for f in (lastTrans, curTrans, nextTrans):
+                bits.put(int(bool(f)), 1)
+            n_bits = 4                                                # the size rule of :552-565
+            for (sf, ba, mant, ov) in parts[ch]:
+                bits.put(int(ov), cp.nScaleBits)
+                n_bits += cp.nScaleBits
+                at = 0
+                for b in range(bands.nBands):
+                    a = int(ba[b])
+                    bits.put(a - 1 if a else 0, cp.nMantSizeBits)
+                    bits.put(int(sf[b]), cp.nScaleBits)
+                    n_bits += cp.nMantSizeBits + cp.nScaleBits
+                    if a:
+                        for j in range(int(bands.nLines[b])):
+                            bits.put(int(mant[at + j]), a)
+                        at += int(bands.nLines[b])
+                        n_bits += a * int(bands.nLines[b])
+            n_bytes = n_bits // 8 if n_bits % 8 == 0 else n_bits // 8 + 1
+            blob = bits.tobytes()
+            blob = blob[:n_bytes] + b"\0" * (n_bytes - len(blob))
+            self.fp.write(pack("<L", n_bytes))
+            self.fp.write(blob)
+
+    def _read_block_any_size(self, cp):
+        """ReadDataBlock for nMDCTLines other than 1024 (scalar mantissas): coder/pacfile.py:177-298 with the
+        fields parsed on the host and the blocks decoded through the function-level mirrors."""
+        long_n = cp.nMDCTLines
+        data = []
+        for ch in range(cp.nChannels):
+            s = self.fp.read(4)
+            if not s:
+                if cp.overlapAndAdd:
+                    tail, cp.overlapAndAdd = cp.overlapAndAdd, 0
+                    return tail
+                return None
+            n = int.from_bytes(s, "little") if len(s) == 4 else -1
+            blob = self.fp.read(n) if n > 0 else b""
+            if n < 1 or len(blob) < n:
+                raise RuntimeError(_PARTIAL)
+            acc, pos = int.from_bytes(blob, "big"), [0]
+            total = 8 * len(blob)
+
+            def get(width):
+                if pos[0] + width > total:
+                    raise RuntimeError(_PARTIAL)
+                v = (acc >> (total - pos[0] - width)) & ((1 << width) - 1) if width else 0
+                pos[0] += width
+                return v
+
+            def one(cur):
+                bands = cp.sfBandsShort if cur else cp.sfBands
+                ov = get(cp.nScaleBits)
+                ba, sf = [], []
+                mant = np.zeros(cp.nMDCTLines, np.int32)
+                for b in range(bands.nBands):
+                    a = get(cp.nMantSizeBits)
+                    a = a + 1 if a else 0
+                    ba.append(a)
+                    sf.append(get(cp.nScaleBits))
+                    if a:
+                        lo = int(bands.lowerLine[b])
+                        for j in range(int(bands.nLines[b])):
+                            mant[lo + j] = get(a)
+                if cur:
+                    cp.sfBands = None                                 # the 128-line blocks' handle: default long layout
+                return self.Decode(sf, ba, mant, ov, None, cp, last, cur, nxt)
+
+            last, cur, nxt = get(1), get(1), get(1)
+            if not cur:
+                block = one(False)
+            else:
+                short = 128
+                block = np.zeros(2 * long_n)
+                pad = long_n // 2 - short // 2
+                long_bands = cp.sfBands
+                cp.nSamplesPerBlock = cp.nMDCTLines = short
+                try:
+                    for k in range(pad, 2 * long_n - short - pad, short):
+                        block[k:k + 2 * short] += one(True)
+                finally:
+                    cp.nSamplesPerBlock = cp.nMDCTLines = long_n
+                    cp.sfBands = long_bands
+            data.append(np.add(cp.overlapAndAdd[ch], block[:long_n]))
+            cp.overlapAndAdd[ch] = block[long_n:]
+        return data
+
     def WriteDataBlock(self, data, codingParams, lastTrans=False, curTrans=False, nextTrans=False):
         """coder/pacfile.py:449-610: prior || data per channel, encode, pack, write."""
         import torch
         cp = codingParams
+        if cp.nMDCTLines != 1024 and not getattr(cp, "useVQ", False) and not getattr(cp, "useSBR", False):
+            return self._write_block_any_size(data, cp, lastTrans, curTrans, nextTrans)
         enc = context.encoder_for_params(cp)
         blk = np.stack([np.concatenate((cp.priorBlock[ch], data[ch])) for ch in range(cp.nChannels)])
         cp.priorBlock = data
@@ -143,6 +262,8 @@ class PACFile(AudioFile):
         then None.  Unpacking and codec.Decode run on the GPU."""
         import torch
         cp = codingParams
+        if cp.nMDCTLines != 1024 and not getattr(cp, "useVQ", False) and not getattr(cp, "useSBR", False):
+            return self._read_block_any_size(cp)
         enc = context.encoder_for_params(cp)
         payloads = []
         for ch in range(cp.nChannels):
@@ -211,8 +332,34 @@ def device_stream(enc, pcm, hop=1024):
     return torch.as_tensor(buf, device=enc.device)
 
 
+def _encode_stream_any_size(pcm, cp, block_switching):
+    """the reference's driver loop (coder/pacfile.py:716-757) over the PACFile mirror, block by block: nMDCTLines other
+    than 1024"""
+    import io
+    from .detect_transients import parTransientDetect
+    hop, n_ch = cp.nMDCTLines, cp.nChannels
+    f = PACFile("<memory>")
+    f.fp = io.BytesIO()
+    f.fp.mode = "wb"
+    f.WriteFileHeader(cp)
+    look = np.zeros((n_ch, 2 * hop))
+    cur = last = False
+    n_hops = len(pcm) // hop
+    for h in range(n_hops + 1):
+        if h < n_hops:
+            data = np.stack([codes_to_fraction(pcm[h * hop:(h + 1) * hop, ch]) for ch in range(n_ch)])
+            look = np.concatenate((np.copy(data), look[:, hop:]), axis=1)
+            nxt = bool(parTransientDetect(look)) if block_switching else False
+        else:
+            nxt = False
+        f.WriteDataBlock([look[ch, :hop] for ch in range(n_ch)], cp, lastTrans=last, curTrans=cur, nextTrans=nxt)
+        last, cur = cur, nxt
+    f.WriteDataBlock([np.zeros(hop) for _ in range(n_ch)], cp)          # Close (:612-625)
+    return f.fp.getvalue()
+
+
 def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, header_samples=None,
-                  n_scale_bits=4, n_mant_size_bits=12, use_vq=False, use_sbr=False, chunk_hops=None):
+                  n_scale_bits=4, n_mant_size_bits=12, use_vq=False, use_sbr=False, chunk_hops=None, n_lines=1024):
     """Whole-stream batched encode -> .pac bytes identical to what the
     reference's driver (coder/pacfile.py:674-757) writes for the same PCM:
     scalar mantissas by default; use_vq (+ use_sbr) selects the gain-shape
@@ -222,7 +369,7 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, hea
     WAV files)."""
     from .audiofile import CodingParams
     pcm = np.ascontiguousarray(pcm)
-    hop = 1024
+    hop = int(n_lines)
     assert pcm.ndim == 2 and len(pcm) % hop == 0
     cp = CodingParams()
     cp.sampleRate, cp.nChannels = int(sample_rate), pcm.shape[1]
@@ -231,6 +378,11 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False, hea
     cp.nScaleBits, cp.nMantSizeBits = n_scale_bits, n_mant_size_bits
     cp.targetBitsPerSample = kbps_per_channel / (cp.sampleRate / 1000)
     cp.useSBR, cp.useVQ = bool(use_sbr), bool(use_vq)
+    if hop != 1024:
+        # function level: the driver loop block by block through the mirrors (scalar mantissas; a correctness path)
+        if use_vq or use_sbr:
+            raise NotImplementedError("gain-shape / SBR streams: nMDCTLines 1024")
+        return _encode_stream_any_size(pcm, cp, block_switching)
     head = header_bytes(cp)
     enc = context.encoder_for_params(cp)
     if chunk_hops:
@@ -306,6 +458,20 @@ def decode_stream(data):
     the reference's decode loop (coder/pacfile.py:745-757) writes as PCM."""
     import torch
     cp, pos = parse_header(data)
+    if cp.nMDCTLines != 1024 and not cp.useVQ and not cp.useSBR:
+        # function level: the reference's decode loop block by block through the PACFile mirror
+        import io
+        from .pcmfile import fraction_to_codes
+        f = PACFile("<memory>")
+        f.fp = io.BytesIO(bytes(data))
+        cp = f.ReadFileHeader()
+        out = []
+        while True:
+            block = f.ReadDataBlock(cp)
+            if not block:
+                break
+            out.append(np.stack([fraction_to_codes(x) for x in block], axis=1))
+        return np.concatenate(out).astype(np.int16) if out else np.zeros((0, cp.nChannels), np.int16)
     enc = context.encoder_for_params(cp)
     offs, sizes = record_chain(data, pos, enc.payload_stride)
     if len(offs) % cp.nChannels:

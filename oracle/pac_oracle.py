@@ -787,7 +787,7 @@ def wav_effective_stream(raw, hop=1024):
 
 
 def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False,
-                  max_hops=None, collect=None, header_samples=None, use_sbr=False):
+                  max_hops=None, collect=None, header_samples=None, use_sbr=False, n_lines=1024):
     """Whole-file scalar-path encode: the driver loop of
     coder/pacfile.py:716-757 plus Close (:612-625) on int16 PCM [nSamples, nCh].
     Returns the .pac bytes.  The last hop is written twice (the loop body runs
@@ -796,7 +796,7 @@ def encode_stream(pcm, sample_rate, kbps_per_channel, block_switching=False,
     (flags, per-channel parts or None) per written hop."""
     pcm = np.asarray(pcm)
     n_samples, n_ch = pcm.shape
-    p = make_params(sample_rate, n_ch, kbps_per_channel)
+    p = make_params(sample_rate, n_ch, kbps_per_channel, n_lines)
     if use_sbr:                                   # scalar mantissas + SBR: see encode_channel_sbr
         p.useSBR = True
         p.omittedBands = list(omitted_bands(p.sfBands))
@@ -932,7 +932,7 @@ def parse_header(data):
     pos = 4 + struct.calcsize('<LHLLHHHH')
     n_bands = struct.unpack('<L', data[pos:pos + 4])[0]
     pos += 4 + 2 * n_bands
-    assert not use_vq and n_lines == 1024
+    assert not use_vq
     p = make_params(sr, n_ch, 128, n_lines, n_scale, n_mant_size)
     if use_sbr:                                   # scalar mantissas + SBR, see encode_channel_sbr
         p.useSBR = True

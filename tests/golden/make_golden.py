@@ -26,6 +26,8 @@ Outputs
   excerpt_vq_*.npz  (--vq) 24-hop excerpts in the shipped configuration
   decoded_vq_*.npz  (--vq-decoded) those excerpts through the reference's decoder
   vqwav.json        (--vq-decoded) hashes of the decoded WAVs the reference committed
+  lines512.npz      (--lines512) the reference's file loop with nMDCTLines = 512, long-only and block-switched,
+                    and its decoder on the result
   sbr_scalar_decode.npz (--sbr-scalar-decode) the reference's reader + Decode_SBR scalar branch on streams
                     and code sets with coded omitted bands (inputs made with the oracle, outputs the reference's)
   sbr_scalar.json   (--sbr-scalar) what the reference does with scalar mantissas + spectral band
@@ -127,14 +129,14 @@ def ref_params(sr, n_ch, kbps, n_lines=1024):
     return cp
 
 
-def ref_encode_file(wav_path, kbps, block_switching, out_path, vq=False, sbr=None):
+def ref_encode_file(wav_path, kbps, block_switching, out_path, vq=False, sbr=None, n_lines=1024):
     """The reference's own PCMFile -> PACFile objects driven the way its
     encode_decode_test does, with the scalar mantissa path selected (or, with
     vq=True, exactly the shipped settings: useVQ, useSBR below 128 kb/s)."""
     src = pcmfile.PCMFile(wav_path)
     dst = pacfile.PACFile(out_path)
     cp = src.OpenForReading()
-    cp.nMDCTLines = 1024
+    cp.nMDCTLines = n_lines
     cp.nScaleBits = 4
     cp.nMantSizeBits = 12
     cp.targetBitsPerSample = kbps / (cp.sampleRate / 1000)
@@ -712,7 +714,35 @@ def make_sbr_scalar_decode():
     np.savez_compressed(os.path.join(HERE, "sbr_scalar_decode.npz"), **out)
 
 
+def make_lines512():
+    """nMDCTLines = 512 (SURVEY fact 2): the reference's own file loop with 512-line long blocks (1024-sample windows;
+    a short-coded hop is then FOUR 128-line sub-blocks, coder/pacfile.py:489-547) on 12 288-sample excerpts, long-only
+    and block-switched, and its decoder on the result."""
+    out = {}
+    cases = []
+    for name, kbps, bs, h0 in (("harpsichord", 128, False, 0), ("castanet", 128, True, 30), ("spmg", 96, True, 8)):
+        ex = np.load(os.path.join(HERE, f"excerpt_{name}.npz"))
+        pcm, sr = ex["pcm"][h0 * 1024:(h0 + 12) * 1024], int(ex["sr"])
+        tag = f"{name}_{kbps}_{'bs' if bs else 'long'}"
+        wav = os.path.join(_work, f"l512_{tag}.wav")
+        open(wav, "wb").write(wav_bytes(sr, pcm))
+        pac_path = os.path.join(_work, f"l512_{tag}.pac")
+        pac, flags = ref_encode_file(wav, kbps, bs, pac_path, n_lines=512)
+        dec = ref_decode_file(pac_path, os.path.join(_work, f"l512_{tag}_dec.wav"))
+        out[f"pcm_{tag}"], out[f"sr_{tag}"] = pcm, sr
+        out[f"pac_{tag}"] = np.frombuffer(pac, dtype=np.uint8)
+        out[f"dec_{tag}"] = dec.astype(np.int16)
+        out[f"flags_{tag}"] = np.array(flags, dtype=np.uint8)
+        cases.append(tag)
+        print(tag, len(pac), dec.shape, int(np.array(flags)[:, 1].sum()), "short-coded hops")
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "lines512.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--lines512" in sys.argv:
+        make_lines512()
+        sys.exit(0)
     if "--sbr-scalar-decode" in sys.argv:
         make_sbr_scalar_decode()
         sys.exit(0)

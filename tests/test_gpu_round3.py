@@ -672,3 +672,20 @@ def test_encode_single_channel_with_512_lines(A, sr, half, kbps):
         want = po.decode_block(p, w_sf, w_ba, by_line, w_ov, *fl)
         assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1e-300), (i, fl)
     assert n_mant > 1000
+
+
+L512 = np.load(os.path.join(GOLDEN, "lines512.npz"))
+
+
+@pytest.mark.parametrize("tag", [str(c) for c in L512["cases"]])
+def test_streams_with_512_lines_against_the_reference(A, tag):
+    """whole streams with nMDCTLines = 512 through the PACFile mirror (function-level path: blocks composed from the
+    GPU-backed module mirrors, a short-coded hop is four 128-line sub-blocks on the tuned kernels): the bytes the
+    REFERENCE wrote with cp.nMDCTLines = 512, and its decoder's PCM"""
+    name, kbps, kind = tag.rsplit("_", 2)
+    pac = A.pacfile.encode_stream(L512[f"pcm_{tag}"], int(L512[f"sr_{tag}"]), int(kbps), block_switching=(kind == "bs"),
+                                  n_lines=512)
+    want = bytes(L512[f"pac_{tag}"])
+    assert len(pac) == len(want) and pac == want
+    pcm = A.pacfile.decode_stream(want)
+    assert pcm.shape == L512[f"dec_{tag}"].shape and np.array_equal(pcm, L512[f"dec_{tag}"])
