@@ -687,6 +687,22 @@ def main():
                       "what": "payload slots of the timed run -> " + ("gain-shape decode" if vq_kbps else "unpack + dequantise")
                               + " -> IMDCT -> overlap-and-add -> int16 PCM, one step in flight"}
         del pcm_dec
+        if P > 1:                                   # the same with two decode steps in flight (the pool's two handles and streams)
+            def decode_on(q):
+                oq, eq = pipes[q]["out"], pipes[q]["enc"]
+                with pool.slot(q):
+                    if vq_kbps:
+                        return eq.decode_vq(oq["payload"], oq["n_bytes"], N_CH)["pcm"]
+                    return eq.decode(eq.unpack(oq["payload"], oq["n_bytes"]), N_CH)
+            keep = [decode_on(q % 2) for q in range(4)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_dec2 = 10
+            keep = [decode_on(q % 2) for q in range(n_dec2)]
+            torch.cuda.synchronize()
+            dt_d2 = (time.perf_counter() - t0) / n_dec2
+            decode_leg["cf_per_s_two_in_flight"] = n_cf / dt_d2
+            del keep
 
     if rank == 0:
         total_cf = world * n_cf if not corpus else N_CH * args.corpus_frames
