@@ -412,25 +412,28 @@ __global__ __launch_bounds__(256) void k_frame_lists(const uint8_t *__restrict__
  * memory and ONE barrier: a thread owns up to 16 consecutive frames, reads their flags together, and the
  * counts are scanned over the wave (shuffles) and over the 16 waves (LDS). */
 #define LISTS_SMALL_MAX 16384
-__global__ __launch_bounds__(1024) void k_frame_lists_small(const uint8_t *__restrict__ flags, long long n_frames,
+#define LISTS_SMALL_THREADS 256        /* four waves: a workgroup of sixteen waited for a whole CU's worth of free wave slots
+                                          beside the persistent kernels of the other step in flight (40 us for 16 us of work) */
+__global__ __launch_bounds__(LISTS_SMALL_THREADS) void k_frame_lists_small(const uint8_t *__restrict__ flags, long long n_frames,
                                                             int n_ch, int32_t *__restrict__ list_long,
                                                             int32_t *__restrict__ list_short,
                                                             int32_t *__restrict__ counts)
 {
-    __shared__ int ws[16], wl[16];
+    constexpr int NW = LISTS_SMALL_THREADS / 64, PER_MAX = LISTS_SMALL_MAX / LISTS_SMALL_THREADS;     /* <= 64 frames per thread */
+    static_assert(PER_MAX <= 64, "one 64-bit mask per thread");
+    __shared__ int ws[NW], wl[NW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int per = (int)((n_frames + 1023) / 1024);       /* <= 16 */
+    const int per = (int)((n_frames + LISTS_SMALL_THREADS - 1) / LISTS_SMALL_THREADS);
     const long long f0 = (long long)tid * per;
-    unsigned valid = 0, shorts = 0;                        /* bit j: frame f0 + j */
-#pragma unroll
-    for (int j = 0; j < LISTS_SMALL_MAX / 1024; ++j) {
-        if (j < per && f0 + j < n_frames) {
-            valid |= 1u << j;
+    unsigned long long valid = 0, shorts = 0;              /* bit j: frame f0 + j */
+    for (int j = 0; j < per; ++j) {
+        if (f0 + j < n_frames) {
+            valid |= 1ull << j;
             if (flags[f0 + j] & 2u)
-                shorts |= 1u << j;
+                shorts |= 1ull << j;
         }
     }
-    const int ns = __popc(shorts), nl = __popc(valid & ~shorts);
+    const int ns = __popcll(shorts), nl = __popcll(valid & ~shorts);
     int ss = ns, sl = nl;                                  /* inclusive scans over the wave */
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -447,17 +450,17 @@ __global__ __launch_bounds__(1024) void k_frame_lists_small(const uint8_t *__res
     __syncthreads();
     int at_s = ss - ns, at_l = sl - nl, all_s = 0, all_l = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < NW; ++w) {
         at_s += w < wv ? ws[w] : 0;
         at_l += w < wv ? wl[w] : 0;
         all_s += ws[w];
         all_l += wl[w];
     }
     for (int j = 0; j < per; ++j) {
-        if (!((valid >> j) & 1u))
+        if (!((valid >> j) & 1ull))
             break;
         const long long f = f0 + j;
-        if ((shorts >> j) & 1u) {
+        if ((shorts >> j) & 1ull) {
             for (int c = 0; c < n_ch; ++c)
                 list_short[at_s * n_ch + c] = (int32_t)(f * n_ch + c);
             ++at_s;
@@ -479,7 +482,7 @@ void pacx_launch_frame_lists(const uint8_t *flags, long long n_frames, int n_ch,
     if (n_frames <= 0)
         return;
     if (n_frames <= LISTS_SMALL_MAX) {
-        hipLaunchKernelGGL(k_frame_lists_small, dim3(1), dim3(1024), 0, st, flags, n_frames, n_ch, list_long,
+        hipLaunchKernelGGL(k_frame_lists_small, dim3(1), dim3(LISTS_SMALL_THREADS), 0, st, flags, n_frames, n_ch, list_long,
                            list_short, counts);
         return;
     }

@@ -1024,18 +1024,31 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
            Every one of these kernels is latency-bound at the occupancy its registers and LDS
            allow and none fills the chip with half of the frames, so the two chains run side by
            side on four streams and meet again before the body gather. */
+        /* The side chains run on their chains' own streams: two streams per handle, not four.  HIP maps a process's
+           streams onto four hardware queues; with two handles (two steps in flight) the short side chain of one
+           landed on the other's short-chain queue, behind its mask and tail kernels (kernel trace),
+           and alone the forks and joins of four streams cost more than the overlap of a side chain with its 40 us
+           transform: bs128 33.9 -> 35.4 M cf/s with two steps in flight, 25.9 -> 30.7 M with one.
+           PACX_BS_TWO_STREAMS=0: the four-stream schedule of round 2 */
+        const char *two_s = getenv("PACX_BS_TWO_STREAMS");             /* read per call: a test flips it */
+        const int two_env = (two_s && atoi(two_s) == 0) ? 0 : 1;
+        hipStream_t sl_st = two_env ? st : h->side_stream, ss_st = two_env ? h->short_stream : h->short_side_stream;
         HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_stream, h->ev_fork, 0));
-        HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_side_stream, h->ev_fork, 0));
+        if (!two_env)
+            HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_side_stream, h->ev_fork, 0));
         pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed | PACX_PART_LONG, h->ws_peaks, h->ws_npeaks,
-                         h->ws_nkept, nullptr, nullptr, h->side_stream);
-        HIP_TRY_FORKED(h, hipEventRecord(h->ev_join, h->side_stream));
+                         h->ws_nkept, nullptr, nullptr, sl_st);
+        if (!two_env)
+            HIP_TRY_FORKED(h, hipEventRecord(h->ev_join, h->side_stream));
         pacx_launch_side(T, v, in->dtype, fast, frame_flags, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_npeaks,
-                         h->ws_nkept, nullptr, nullptr, h->short_side_stream);
-        HIP_TRY_FORKED(h, hipEventRecord(h->ev_short_side, h->short_side_stream));
+                         h->ws_nkept, nullptr, nullptr, ss_st);
+        if (!two_env)
+            HIP_TRY_FORKED(h, hipEventRecord(h->ev_short_side, h->short_side_stream));
         /* short chain */
         pacx_launch_mdct(T, v, in->dtype, fast, frame_flags, n_cf, 0, 4, 0, h->ws_lines, overall_scale, PACX_SUB, status,
                          h->short_stream);
-        HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_stream, h->ev_short_side, 0));
+        if (!two_env)
+            HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_stream, h->ev_short_side, 0));
         HIP_TRY_FORKED(h, hipStreamWaitEvent(h->short_stream, h->ev_lists, 0));
         pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_SHORT, h->ws_peaks, h->ws_nkept, h->ws_lines,
                          h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, nullptr, h->short_stream);
@@ -1046,7 +1059,8 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         /* long chain */
         pacx_launch_mdct_v2(T, v, frame_flags, n_cf, mixed, h->ws_lines, overall_scale, PACX_SUB, status, h->n_cu,
                             list_long, counts, st);
-        HIP_TRY_FORKED(h, hipStreamWaitEvent(st, h->ev_join, 0));
+        if (!two_env)
+            HIP_TRY_FORKED(h, hipStreamWaitEvent(st, h->ev_join, 0));
         pacx_launch_mask(T, frame_flags, n_ch, n_cf, 0, mixed | PACX_PART_LONG, h->ws_peaks, h->ws_nkept, h->ws_lines,
                          h->ws_smr, nullptr, h->n_cu, list_long, list_short, counts, fuse ? &mt : nullptr, st);
         if (!fuse)

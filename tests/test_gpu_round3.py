@@ -65,6 +65,9 @@ def test_scalar_coder_path_switches(A, monkeypatch):
             n += 1
         assert n == 6
         _set(monkeypatch, {})
+        monkeypatch.setenv("PACX_BS_TWO_STREAMS", "0")   # round 2's four-stream schedule of block-switched batches
+        assert A.pacfile.encode_stream(pcm, sr, 128, block_switching=bs) == want, (bs, "four streams")
+        monkeypatch.delenv("PACX_BS_TWO_STREAMS")
         for fuse in (None, "1"):                    # the whole step on the caller's stream (no fork to the side stream)
             _set(monkeypatch, {"PACX_FUSE_TAIL": fuse})
             monkeypatch.setenv("PACX_ONE_STREAM", "1")
