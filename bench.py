@@ -496,6 +496,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    enqueue_s = []
+
     def timed_region():
         sync_all()
         t0 = time.perf_counter()
@@ -503,6 +505,7 @@ def main():
             pool.align(args.gate_us)                # inside the timed region: both pipelines' first steps start together
         for _ in range(args.steps):
             step()
+        enqueue_s.append(time.perf_counter() - t0)     # the host's share: all K steps queued (nothing waited for yet)
         sync_all()
         dt = time.perf_counter() - t0
         if multi:
@@ -748,6 +751,10 @@ def main():
                        "regions": len(regions),
                        "ms_per_step_regions": [r / args.steps * 1e3 for r in (regions if len(regions) <= 24 else
                                                                                 regions[:8] + regions[-16:])],
+                       "host_enqueue_ms_per_step": float(np.median(enqueue_s)) / args.steps * 1e3 if enqueue_s else None,
+                       "host_enqueue_note": "median over the regions of the time the host takes to queue the K steps of a region "
+                                            "(Python + HIP launches), per step; the regions' own time is ms_per_step: where the "
+                                            "two are close the host, not the GPU, sets the rate",
                        "start_gate_us": args.gate_us if P > 1 else 0.0,
                        "start_gate_note": "inside every timed region: both pipelines' streams wait this long on a gate event so "
                                           "that their first steps start together (EncoderPool.align): started together the two "

@@ -18,4 +18,4 @@ d = json.loads(lines[-1])
 c = d["config"]
 print(f"{label:36s} {d['value'] / 1e6:8.2f} M cf/s  {d['ms_per_step']:.4f} ms/step  verified {d['verified_cf']}  "
       f"[{c['launch'][:8]} x{c.get('steps_in_flight', 1)}; one in flight {c.get('value_one_step_in_flight', 0) / 1e6:.2f} M]  "
-      f"mdct {d['roofline']['launch_ms'] * 1e3:.1f} us", flush=True)
+      f"mdct {d['roofline']['launch_ms'] * 1e3:.1f} us  host {c.get('host_enqueue_ms_per_step') or 0:.4f} ms/step", flush=True)
