@@ -536,6 +536,7 @@ class EncoderPool:
         self.done = [torch.cuda.Event() for _ in self.encs]
         self._turn = 0
         self._gate = self._gate_stream = None
+        self._used = [False] * len(self.encs)
 
     def __len__(self):
         return len(self.encs)
@@ -556,6 +557,7 @@ class EncoderPool:
 
             def __exit__(self_inner, *exc):
                 pool.done[k].record(pool.streams[k])
+                pool._used[k] = True
                 return self_inner.ctx.__exit__(*exc)
         return _Slot()
 
@@ -564,8 +566,11 @@ class EncoderPool:
         far apart as the host takes to queue one (tens of microseconds), and two free-running pipelines then settle
         into one of two stable relations -- in phase (like kernels side by side: 51.4 M cf/s on the headline batch)
         or in anti-phase (47.0 M), DESIGN.md 5.0.  A gate event behind a short spin on a third stream holds every
-        slot's stream until all the first calls are queued; started together they stay in phase.  Costs delay_us
-        (default PACX_POOL_GATE_US or 100) once per call of this method."""
+        slot's stream until all the first calls are queued; started together they stay in phase for a hundred steps or
+        so (bench.py: 51.9 M cf/s over 100-step regions, 47.9 M over 200-step ones -- the pipelines drift into the other
+        relation; calling this again mid-stream, where it is a barrier between the slots followed by the common start,
+        did not bring the faster relation back in the measurements of round 3).  Costs delay_us (default
+        PACX_POOL_GATE_US or 100) per call."""
         if len(self.encs) < 2:
             return
         if delay_us is None:
@@ -585,6 +590,9 @@ class EncoderPool:
             t1.synchronize()
             self._cycles_per_us = 2_000_000 / max(t0.elapsed_time(t1) * 1e3, 1.0)
         with torch.cuda.stream(self._gate_stream):
+            for k in range(len(self.encs)):             # mid-stream: a barrier between the slots (what they have queued
+                if self._used[k]:                       # so far finishes), then the common start
+                    self._gate_stream.wait_event(self.done[k])
             torch.cuda._sleep(int(delay_us * self._cycles_per_us))
             self._gate.record(self._gate_stream)
         for s in self.streams:
