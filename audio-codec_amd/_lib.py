@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PACX_LIB") or os.path.join(HERE, "libpacx.so")   # PACX_LIB: kernel-variant experiments
 
-PACX_ABI_VERSION = 6
+PACX_ABI_VERSION = 7
 PCM_I16, PCM_F64 = 0, 1
 FLAG_LAST, FLAG_CUR, FLAG_NEXT = 1, 2, 4
 ST_SHORT, ST_ZERO_SUBBLOCK, ST_ALLOC_CAP, ST_VQ_UNDEFINED, ST_GUARD, ST_MALFORMED = 1, 2, 4, 8, 16, 32
@@ -127,6 +127,7 @@ SIGNATURES = {
     "pacx_mdct_direct_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
     "pacx_transient_detect_f64": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _P, ctypes.c_double, _P, _P]),
     "pacx_unpack_batch": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pacx_set_side_fork": (ctypes.c_int, [_P, ctypes.c_int]),
     "pacx_smr_generic_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, ctypes.POINTER(PacxSmrTables), _P, _P,
                                               _P, _P]),
     "pacx_decode_batch": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -133,6 +133,7 @@ struct pacx_handle {
     double *ws_blocks;                /* [cf][2048] blocks before overlap-add   */
     /* gain-shape coder (use_vq) */
     /* fork-join: the side chain (VALU/latency bound) runs beside the MDCT (HBM bound) */
+    int fork_side;                    /* all-long scalar batches: side chain on side_stream (pacx_set_side_fork) */
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
     /* mixed batches: the short-coded frames' chain (MDCT, side chain, mask, tail) runs on
@@ -341,6 +342,7 @@ extern "C" int pacx_create(const pacx_config *cfg, pacx_handle **out)
     h->ws_blocks_cf = 0;
     h->ws_blocks = nullptr;
     h->ws_sbr_mean = nullptr;
+    h->fork_side = 0;
     h->side_stream = nullptr;
     h->ev_fork = nullptr;
     h->ev_join = nullptr;
@@ -1007,11 +1009,14 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
                          mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, list_short, counts + 1, 0, st);
         return post_launch(h, what);
     }
-    /* fork: the side chain only reads the PCM, so it runs on its own stream next to the MDCT.
-       PACX_ONE_STREAM=1: no fork, the whole step on the caller's stream (a caller who keeps several
-       steps in flight on several streams already has the overlap; fewer streams, fewer hardware queues) */
+    /* All-long batches: the whole step on the caller's stream, or (pacx_set_side_fork) the side chain, which only
+       reads the PCM, forked to the handle's second stream next to the transform.  The fork pays only where HIP puts
+       the two streams on ONE hardware queue -- with two handles in a process it does (50.6 against 49.3 M cf/s with
+       two steps in flight), with one handle it does not, and a fork and a join across hardware queues (13 + 12 us)
+       cost more than the 20 us of overlap: 39.1 against 42.6 M cf/s with one step in flight.
+       PACX_ONE_STREAM=0/1 forces either for every handle (read per call: a test flips it) */
     const char *one_env = getenv("PACX_ONE_STREAM");
-    const bool one_stream = !split && one_env && atoi(one_env) != 0;
+    const bool one_stream = !split && (one_env ? atoi(one_env) != 0 : !h->fork_side);
     hipStream_t side_st = one_stream ? st : h->side_stream;
     if (!split && !one_stream)
         HIP_TRY_FORKED(h, hipEventRecord(h->ev_fork, st));
@@ -1093,6 +1098,14 @@ static int encode_scalar(pacx_handle *h, const pacx_pcm *in, const uint8_t *fram
         pacx_launch_tail(T, frame_flags, n_ch, n_cf, h->ws_smr, h->ws_lines, overall_scale, bit_alloc, scale_factor,
                          mantissa, status, payload, PACX_PAYLOAD_STRIDE, n_bytes, list_short, counts + 1, fuse, st);
     return post_launch_forked(h, what);
+}
+
+extern "C" int pacx_set_side_fork(pacx_handle *h, int enable)
+{
+    if (!h)
+        return PACX_E_ARG;
+    h->fork_side = enable ? 1 : 0;
+    return PACX_OK;
 }
 
 extern "C" int pacx_encode_batch(pacx_handle *h, const pacx_pcm *in, const uint8_t *frame_flags,

@@ -132,6 +132,11 @@ class Encoder:
         self.band_stride = self.lib.pacx_band_stride(h)
         self.payload_stride = self.lib.pacx_payload_stride(h)
 
+    def set_side_fork(self, enable):
+        """all-long scalar batches: the side chain on the handle's second stream beside the transform (pays with several
+        handles in the process, costs with one: include/pacx.h)"""
+        self._call("pacx_set_side_fork", int(bool(enable)))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.pacx_destroy(self.h)
@@ -537,6 +542,9 @@ class EncoderPool:
         self._turn = 0
         self._gate = self._gate_stream = None
         self._used = [False] * len(self.encs)
+        if len(self.encs) > 1:                       # two handles: their two streams each share a hardware queue, the fork pays
+            for e in self.encs:
+                e.set_side_fork(True)
 
     def __len__(self):
         return len(self.encs)

@@ -447,8 +447,9 @@ def main():
 
     # the kernel launches of a step captured once into a hipGraph (one per pipeline) and replayed.
     # The gather of the bodies (RCCL) stays outside the graph.
-    if args.graph is None:                 # measured (profiles/r03_pipeline_sweep.txt): with two steps in flight direct launches
-        args.graph = P == 1 and not vq_kbps   # overlap better than two replayed graphs (45.1 against 42.0 M cf/s); alone, a graph saves the gaps
+    if args.graph is None:                 # measured: with two steps in flight direct launches overlap better than two replayed
+        args.graph = False                 # graphs (50.6 against 46.6 M cf/s); with one, the step on ONE stream needs no graph
+                                           # either (42.6 M direct, 41.5 M replayed; the forked step 39.1 / 40.3 M)
     torch.cuda.synchronize()
     if args.graph:
         for q in range(P):
@@ -534,19 +535,12 @@ def main():
         in_flight[0] = 1
         step_no[0] = 0
         one_graph = None
-        if not vq_kbps and pipes[0]["graph"] is None:      # that mode's best form: the scalar coder's step as a hipGraph
-            try:
-                torch.cuda.synchronize()
-                one_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(one_graph, stream=pipes[0]["stream"]):
-                    encode_part(0)
-                pipes[0]["graph"] = one_graph
-            except Exception:
-                one_graph = None
-            torch.cuda.synchronize()
+        pipes[0]["enc"].set_side_fork(False)            # that mode's best form: the whole step on one stream (no fork across
+        torch.cuda.synchronize()                        # hardware queues), direct launches
         regions_one = [timed_region() for _ in range(max(3, args.repeats // 2))]
         if one_graph is not None:
             pipes[0]["graph"] = None
+        pipes[0]["enc"].set_side_fork(True)
         in_flight[0] = P
     regions_nogather = None
     if corpus and multi:                   # with and without the gather

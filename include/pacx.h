@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PACX_ABI_VERSION 6
+#define PACX_ABI_VERSION 7
 
 /* error codes */
 #define PACX_OK            0
@@ -455,6 +455,15 @@ int pacx_transient_flags(pacx_handle *h, const pacx_pcm *hops, uint8_t *transien
  * pairwise order.  The encode path itself uses pacx_transient_flags on the int16 hops. */
 int pacx_transient_detect_f64(pacx_handle *h, int64_t n_blocks, int n_channels, int n_samples,
                               const double *blocks, double thresh, uint8_t *result, void *stream);
+
+/*
+ * All-long scalar batches run on the caller's stream alone (the default), or with the side chain (FFT, peaks: it
+ * only reads the PCM) forked to a second stream of the handle beside the transform.  The fork pays where the
+ * runtime puts both streams on one hardware queue -- a process that keeps several steps in flight on several
+ * handles (engine.EncoderPool switches it on) -- and costs where it does not: a fork and a join across hardware
+ * queues take longer than the transform they hide (one handle, one step in flight: 39.1 against 42.6 M cf/s).
+ */
+int pacx_set_side_fork(pacx_handle *h, int enable);
 
 /*
  * psychoac.CalcSMRs / getMaskedThreshold (coder/psychoac.py:163-291) for block lengths other than the two the

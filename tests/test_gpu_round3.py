@@ -68,10 +68,10 @@ def test_scalar_coder_path_switches(A, monkeypatch):
         monkeypatch.setenv("PACX_BS_TWO_STREAMS", "0")   # round 2's four-stream schedule of block-switched batches
         assert A.pacfile.encode_stream(pcm, sr, 128, block_switching=bs) == want, (bs, "four streams")
         monkeypatch.delenv("PACX_BS_TWO_STREAMS")
-        for fuse in (None, "1"):                    # the whole step on the caller's stream (no fork to the side stream)
-            _set(monkeypatch, {"PACX_FUSE_TAIL": fuse})
-            monkeypatch.setenv("PACX_ONE_STREAM", "1")
-            assert A.pacfile.encode_stream(pcm, sr, 128, block_switching=bs) == want, (bs, fuse, "one stream")
+        for fuse, one in itertools.product((None, "1"), ("1", "0")):   # all-long batches: the whole step on the caller's stream
+            _set(monkeypatch, {"PACX_FUSE_TAIL": fuse})                  # (a handle's default) / the side chain forked to a second one
+            monkeypatch.setenv("PACX_ONE_STREAM", one)
+            assert A.pacfile.encode_stream(pcm, sr, 128, block_switching=bs) == want, (bs, fuse, "one stream", one)
             monkeypatch.delenv("PACX_ONE_STREAM")
     _set(monkeypatch, {})
 

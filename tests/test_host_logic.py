@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(A):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in pacx.h but not exported"
     assert set(A._lib.SIGNATURES) == declared
-    assert lib.pacx_abi_version() == A._lib.PACX_ABI_VERSION == 6
+    assert lib.pacx_abi_version() == A._lib.PACX_ABI_VERSION == 7
 
 
 def test_no_cpu_fallback(A):
